@@ -1,0 +1,142 @@
+/* peekvit_hip.h - C ABI of libpeekvit_hip.so: the MI355X (gfx950) kernels behind peekvit's ViT
+ * encoder hot path (SURVEY.md section 8b "inner boundary").
+ *
+ * The reference (alessiodevoto/peekvit) has no FFI: its arithmetic is dispatched by stock torch.nn
+ * modules to ATen kernels.  Each entry point below replaces the ATen op(s) behind ONE reference call
+ * site (cited as <reference file>:<line>) and is what a binding for that call site would bind
+ * (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - stateless, re-entrant: never allocates, never synchronises, never owns memory; the caller passes
+ *     outputs/workspaces and the hipStream_t (as void*) to launch on; safe to capture in a hipGraph;
+ *   - returns PV_OK (0) or a negative PV_ERR_* code; pv_error_string() explains it;
+ *   - "bf16" buffers are uint16_t bit patterns (round-to-nearest-even from fp32);
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef PEEKVIT_HIP_H
+#define PEEKVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_OK 0
+#define PV_ERR_INVALID_ARG (-1)   /* null pointer, non-positive size, misaligned leading dimension */
+#define PV_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels are built for (see each entry) */
+#define PV_ERR_LAUNCH (-3)        /* hipGetLastError() != hipSuccess after the launch */
+
+/* ABI version (bumped on any signature change) and build target ("gfx950"). */
+int pv_version(void);
+const char* pv_arch(void);
+const char* pv_error_string(int code);
+
+/* fp32 -> bf16 cast of a contiguous buffer (weights packing at load time). n elements. */
+int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+/* Patch gather ("im2col") for the stride-P, kernel-P convolution of
+ *   models/vit.py:212  `x = self.conv_proj(x)`  (+ reshape/permute 214-220).
+ * x: fp32 [B,C,H,W] contiguous NCHW.  cols: bf16 [B*(H/P)*(W/P), C*P*P], K order (c,kh,kw) = the
+ * conv weight's own layout, so conv_proj.weight viewed as [D, C*P*P] is the GEMM weight. */
+int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P,
+                   void* stream);
+
+/* Token prologue rows that are not produced by the patch GEMM:
+ *   models/vit.py:230-236 (cat registers, cat class tokens) + models/vit.py:92 (+ pos_embedding),
+ *   models/residualvit.py:566-568,345 (append learnable_budget_token_1 * budget, no pos-embedding).
+ * tokens: fp32 [B,S_total,D].  Writes rows [0,n_special) = special[r] + pos[r] and, when
+ * budget_token != NULL, row S_total-1 = budget_token * budget.  special: [n_special,D] (class tokens
+ * then registers), pos: [>=n_special, D]. */
+int pv_token_prologue(float* tokens, const float* special, const float* pos, const float* budget_token,
+                      float budget, int64_t B, int64_t S_total, int64_t D, int64_t n_special, void* stream);
+
+/* LayerNorm over the last dim, fp32 in -> bf16 out (the GEMM operand):
+ *   nn.LayerNorm call sites models/vit.py:48,53 (eps 1e-5), models/residualvit.py:252,258 (eps 1e-6,
+ *   followed by `mask *`: row_scale, may be NULL).  x: [rows, D] with row stride ldx; out: [rows, D]
+ * contiguous.  D % 4 == 0, D <= 4096. */
+int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* row_scale,
+                      uint16_t* out, int64_t rows, int64_t D, float eps, void* stream);
+
+/* Epilogues of pv_gemm_bf16 (what is fused behind the MFMA accumulator). */
+#define PV_EPI_BIAS_BF16 0      /* out bf16 = (acc + bias[n]) * (n < qcols ? qscale : 1)   [QKV in-proj]      */
+#define PV_EPI_BIAS_GELU_BF16 1 /* out bf16 = gelu_erf(acc + bias[n])                       [MLP fc1]          */
+#define PV_EPI_BIAS_RES_F32 2   /* out f32  = res[m,n] + row_scale[m]*(acc + bias[n])       [out-proj, fc2]    */
+#define PV_EPI_BIAS_POS_F32 3   /* out f32 row (m/rpi)*rpo+row_off+(m%rpi) = acc+bias[n]+pos[(row_off+m%rpi),n] [patch embed] */
+
+typedef struct pv_gemm_args {
+    const uint16_t* A;       /* bf16 [M,K], row stride lda            (activations)                    */
+    const uint16_t* W;       /* bf16 [N,K], row stride ldw            (nn.Linear weight layout (out,in)) */
+    const float* bias;       /* fp32 [N] or NULL                                                        */
+    void* out;               /* bf16 or fp32 [*, N], row stride ldo                                     */
+    const float* res;        /* fp32 residual [M, *], row stride ldr  (PV_EPI_BIAS_RES_F32; may alias out) */
+    const float* row_scale;  /* fp32 [M] or NULL                      (PV_EPI_BIAS_RES_F32)              */
+    const float* pos;        /* fp32 [rows_per_img_out, N]            (PV_EPI_BIAS_POS_F32)              */
+    int64_t M, N, K;
+    int64_t lda, ldw, ldo, ldr;
+    int64_t rows_per_img_in;   /* rpi: Np                              (PV_EPI_BIAS_POS_F32)             */
+    int64_t rows_per_img_out;  /* rpo: S_total                                                          */
+    int64_t row_off;           /* first patch row inside an image's token block (= n_special)           */
+    int64_t qcols;             /* PV_EPI_BIAS_BF16: columns [0,qcols) are multiplied by qscale          */
+    float qscale;
+    int32_t epilogue;          /* PV_EPI_*                                                              */
+} pv_gemm_args;
+
+/* out = epilogue(A . W^T): bf16 MFMA operands, fp32 accumulation.  Replaces the addmm/mm behind
+ *   nn.MultiheadAttention in-proj / out-proj   models/blocks.py:91,94
+ *   MLP fc1 / fc2 (+ F.gelu)                   models/blocks.py:81-83
+ *   conv_proj as a GEMM over pv_im2col_bf16    models/vit.py:212
+ *   residual adds                              models/vit.py:51,55
+ * Requires K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0, ldo % 4 == 0; any M, N. */
+int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
+
+/* Fused multi-head self-attention core, softmax(q k^T) v per head, no mask, q already scaled:
+ *   torch F.multi_head_attention_forward as called by models/blocks.py:94 (the head-averaged weights it
+ *   also returns are discarded there and are not computed here).
+ * qkv: bf16 [B,S,3*H*dh] packed q|k|v (nn.MultiheadAttention in_proj layout), out: bf16 [B,S,H*dh].
+ * dh in {32,48,64}, S <= 416. */
+int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
+
+/* Final LayerNorm on the class-token rows only + sum over class tokens:
+ *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.
+ * x: fp32 [B,S,D]; pooled: fp32 [B,D] = sum_{c<num_cls} LN(x[b,c]). */
+int pv_cls_pool(const float* x, const float* gamma, const float* beta, float* pooled, int64_t B, int64_t S,
+                int64_t D, int64_t num_cls, float eps, void* stream);
+
+/* Classification head in fp32: models/vit.py:246 `self.head(x)`.  logits[B,C] = pooled[B,D] . w[C,D]^T + b. */
+int pv_head_f32(const float* pooled, const float* w, const float* b, float* logits, int64_t B, int64_t D,
+                int64_t C, void* stream);
+
+/* Token magnitudes: models/rankvit.py:63 `torch.norm(input, dim=-1)` on rows [1,S) of x fp32 [B,S,D]
+ * -> norms fp32 [B,S-1]. */
+int pv_token_norm(const float* x, float* norms, int64_t B, int64_t S, int64_t D, void* stream);
+
+/* Descending rank + top-k: models/rankvit.py:67,74-75 argsort(descending)[:, :k].
+ * norms fp32 [B,N] -> keep int32 [B,k] in sorted (descending) order; ties: lowest index first
+ * (the reference sort is unstable).  N <= 4096. */
+int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_t k, void* stream);
+
+/* Compaction gather: models/rankvit.py:71,75-77 gather + slice + cat class token.
+ * x fp32 [B,S_in,D], keep int32 [B,k] (indices into rows 1..S_in-1, i.e. 0-based among non-CLS tokens)
+ * -> out fp32 [B,1+k,D] with out[b,0]=x[b,0], out[b,1+j]=x[b,1+keep[b,j]].  D % 4 == 0. */
+int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B, int64_t S_in, int64_t k,
+                     int64_t D, void* stream);
+
+/* Residual gate + token masking: models/residualvit.py:197-235 (eval, sigmoid gate, learnable budget
+ * token) with models/residualvit.py:47-74 and models/blocks.py:62-69:
+ *   thr[b]    = sigmoid(x[b,S-1] . wb + bb)                               (budget_token_gate, :212)
+ *   mask[b,i] = relu(sigmoid((x[b,1+i] . wg + bg)/temp + sbias) - thr[b])   i < S-2            (:217)
+ *   x_out[b]  = [x[b,0] | mask[b,i] * x[b,1+i] | x[b,S-1]]                  (:220-227, masked_input)
+ * x_in: fp32 [B,S,D] (layout [cls | N | budget], one special token); x_out: same shape, may alias x_in;
+ * mask_out: fp32 [B,S-2] (block.mask); row_scale: fp32 [B,S] = [1, mask, 1] (:230-235 fwd_mask) for the
+ * LN / out-proj epilogues. */
+int pv_residual_gate(const float* x_in, float* x_out, const float* wg, const float* bg, const float* wb,
+                     const float* bb, float temp, float sigmoid_bias, float* mask_out, float* row_scale,
+                     int64_t B, int64_t S, int64_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEEKVIT_HIP_H */

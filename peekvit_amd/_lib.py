@@ -1,0 +1,82 @@
+"""ctypes binding of libpeekvit_hip.so (the C ABI declared in include/peekvit_hip.h).
+
+The library is built in-tree by `peekvit_amd._build.build()` (hipcc, gfx950).  There is NO fallback:
+if the shared object is missing or a symbol is absent, loading raises - the HIP path must be the
+path that runs on a GPU box.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from ._build import LIB
+
+_i64, _f32, _p, _i32 = C.c_int64, C.c_float, C.c_void_p, C.c_int32
+
+PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_BIAS_POS_F32 = 0, 1, 2, 3
+
+
+class GemmArgs(C.Structure):
+    """Mirror of `pv_gemm_args` (include/peekvit_hip.h)."""
+    _fields_ = [("A", _p), ("W", _p), ("bias", _p), ("out", _p), ("res", _p), ("row_scale", _p), ("pos", _p),
+                ("M", _i64), ("N", _i64), ("K", _i64), ("lda", _i64), ("ldw", _i64), ("ldo", _i64), ("ldr", _i64),
+                ("rows_per_img_in", _i64), ("rows_per_img_out", _i64), ("row_off", _i64), ("qcols", _i64),
+                ("qscale", _f32), ("epilogue", _i32)]
+
+
+# name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
+SIGNATURES = {
+    "pv_version": (C.c_int, []),
+    "pv_arch": (C.c_char_p, []),
+    "pv_error_string": (C.c_char_p, [C.c_int]),
+    "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
+    "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
+    "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
+    "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
+    "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_cls_pool": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
+    "pv_head_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "pv_token_norm": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "pv_rank_topk": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "pv_gather_tokens": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_residual_gate": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _i64, _i64, _i64, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class PeekvitHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return LIB
+
+
+def load():
+    """Load the shared library (once) and attach the declared signatures.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB):
+            raise PeekvitHipError(
+                f"{LIB} not found: the MI355X kernels are not built. Run `python -m peekvit_amd._build` "
+                "(or __graft_entry__.build()); there is no fallback path.")
+        lib = C.CDLL(LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().pv_error_string(code).decode()
+        raise PeekvitHipError(f"{what}: {msg} (code {code})" if what else f"{msg} (code {code})")

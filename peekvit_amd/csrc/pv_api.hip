@@ -1,0 +1,14 @@
+// ABI identification and error strings of libpeekvit_hip.so.
+#include "pv_common.h"
+
+extern "C" int pv_version(void) { return 1; }
+extern "C" const char* pv_arch(void) { return "gfx950"; }
+extern "C" const char* pv_error_string(int code) {
+    switch (code) {
+        case PV_OK: return "ok";
+        case PV_ERR_INVALID_ARG: return "invalid argument (null pointer, bad size, misaligned pointer or leading dimension)";
+        case PV_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        case PV_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown error";
+    }
+}

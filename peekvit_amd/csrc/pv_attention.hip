@@ -1,0 +1,181 @@
+// Fused multi-head self-attention core for ViT-length sequences (S <= 416) on gfx950.
+//   out[b,s,h*dh:(h+1)*dh] = softmax(q k^T) v          q pre-scaled by dh^-0.5 in the in-proj epilogue
+// One workgroup (4 waves) per (image, head).  The whole K and V of the head live in LDS (<= 53 KiB each), so
+// softmax is single pass: no online rescale.  Per 16-query tile a wave computes
+//   S^T = K . Q^T   (MFMA 16x16x32, A = K rows from LDS, B = Q rows straight from global)
+// "swapped", so a lane holds 4 consecutive KEYS of ONE query per accumulator tile: the row max / sum are
+// in-lane reductions plus two cross-lane steps, and the bf16-packed P^T registers are directly the B operand of
+//   O^T = V^T . P^T (A = V^T via ds_read_b64_tr_b16 transposed LDS reads of the row-major V image)
+// in a permuted-but-consistent k order (key slot j of lane group g: j<4 -> key 32t+4g+j, j>=4 -> key 32t+16+4g+j-4).
+// LDS images are XOR-swizzled per 128-byte line (chunk ^ (line & 7)): conflict-free for both read kinds.
+#include "pv_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <int CPR>   // 16-byte chunks per row (DHP / 8)
+__device__ __forceinline__ int pv_swz(int row, int chunk) {
+    const int L = row * CPR + chunk, line = L >> 3, pos = L & 7;
+    return ((line << 3) + (pos ^ (line & 7))) << 4;
+}
+
+template <int DH, int NKT32>
+__global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int CPR = DHP / 8;
+    constexpr int KS = DHP / 32;        // k-steps of the QK^T product
+    constexpr int NKT = NKT32 * 2;      // 16-key tiles
+    constexpr int SP = NKT32 * 32;      // padded key count
+    constexpr int NDT = DH / 16;        // 16-wide output d tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + SP * DHP * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
+
+    // ---- stage K and V (register staged, zero padded) --------------------------------------------------------
+    for (int L = tid; L < SP * CPR; L += 256) {
+        const int row = L / CPR, c = L - row * CPR;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (row < S && c * 8 < DH) {
+            const uint16_t* src = qb + (int64_t)row * ld + c * 8;
+            kv = *reinterpret_cast<const u32x4*>(src + D);
+            vv = *reinterpret_cast<const u32x4*>(src + 2 * D);
+        }
+        const int line = L >> 3, pos = L & 7;
+        const int dst = ((line << 3) + (pos ^ (line & 7))) << 4;
+        *reinterpret_cast<u32x4*>(Ks + dst) = kv;
+        *reinterpret_cast<u32x4*>(Vs + dst) = vv;
+    }
+    __syncthreads();
+
+    const int nqt = (S + 15) >> 4;
+    for (int qt = wid; qt < nqt; qt += 4) {
+        const int q0 = qt << 4;
+        // ---- Q^T fragments (B operand): lane (g,i16) holds Q[q0+i16][ks*32 + 8g .. +8] -----------------------
+        bf16x8 qf[KS];
+        {
+            int qr = q0 + i16; qr = qr < S ? qr : S - 1;
+            const uint16_t* qp = qb + (int64_t)qr * ld;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int dcol = ks * 32 + 8 * g;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (dcol < DH) v = *reinterpret_cast<const u32x4*>(qp + dcol);
+                qf[ks] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+        // ---- S^T tiles: sc[kt][r] = score(query q0+i16, key kt*16 + 4g + r) -----------------------------------
+        f32x4 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + pv_swz<CPR>(kt * 16 + i16, ks * 4 + g));
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);
+            }
+            sc[kt] = a;
+        }
+        // mask padded keys (only the last tiles can contain them)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if ((kt + 1) * 16 > S) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
+            }
+        }
+        // ---- softmax numerator: in-lane over 4*NKT keys, then across the 4 lane groups ------------------------
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __expf(sc[kt][r] - m);
+                sc[kt][r] = pe;
+                l += pe;
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        // ---- O^T = V^T . P^T ---------------------------------------------------------------------------------
+        f32x4 o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int tq = i16 >> 2, tp = i16 & 3;
+#pragma unroll
+        for (int t = 0; t < NKT32; ++t) {
+            u32x4 pw = {pv_pack_bf16x2(sc[2 * t][0], sc[2 * t][1]), pv_pack_bf16x2(sc[2 * t][2], sc[2 * t][3]),
+                        pv_pack_bf16x2(sc[2 * t + 1][0], sc[2 * t + 1][1]), pv_pack_bf16x2(sc[2 * t + 1][2], sc[2 * t + 1][3])};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+            const int r0 = 32 * t + 4 * g + tq;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int c = dt * 2 + (tp >> 1), sub = (tp & 1) << 3;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + pv_swz<CPR>(r0, c) + sub));
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Vs + pv_swz<CPR>(r0 + 16, c) + sub));
+                const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+        // ---- normalise and store: lane holds out[q0+i16][h*DH + dt*16 + 4g + 0..3] -----------------------------
+        if (q0 + i16 < S) {
+            const float inv = 1.0f / l;
+            uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                u32x2 ov = {pv_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pv_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+                *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+            }
+        }
+    }
+}
+
+template <int DH, int NKT32>
+static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int lds = 2 * NKT32 * 32 * DHP * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pv_attn_kernel<DH, NKT32>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    return pv_check_launch();
+}
+
+template <int DH>
+static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    switch ((S + 31) / 32) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, stream);
+        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
+    if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return PV_ERR_INVALID_ARG;
+    if (S > 416 || B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, s);
+        case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, s);
+        case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}

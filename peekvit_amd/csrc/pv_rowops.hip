@@ -1,0 +1,438 @@
+// HBM-bound row kernels of the ViT encoder hot path (gfx950): cast, im2col, token prologue, LayerNorm,
+// CLS pooling, fp32 head, token norms, rank/top-k, compaction gather, residual gate.
+// One wave (64 lanes) owns one token row; 16-byte vector accesses; grid-stride over rows.
+#include "pv_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    int64_t nvec = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const float4* s = reinterpret_cast<const float4*>(src) + i * 2;
+        float4 a = s[0], b = s[1];
+        u32x4 o = {pv_pack_bf16x2(a.x, a.y), pv_pack_bf16x2(a.z, a.w), pv_pack_bf16x2(b.x, b.y), pv_pack_bf16x2(b.z, b.w)};
+        reinterpret_cast<u32x4*>(dst)[i] = o;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 256) dst[i] = pv_f2bf(src[i]);
+    }
+}
+
+extern "C" int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return PV_ERR_INVALID_ARG;
+    if (n == 0) return PV_OK;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return PV_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pv_cast_kernel, dim3(pv_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for the stride-P / kernel-P patch convolution (models/vit.py:212)
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict__ x, uint16_t* __restrict__ cols, int64_t B, int C,
+                                                        int H, int W, int P) {
+    const int Hp = H / P, Wp = W / P, Np = Hp * Wp, K = C * P * P;
+    if (VEC) {
+        const int K8 = K >> 3;
+        const int64_t total = B * (int64_t)Np * K8;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            int64_t m = idx / K8;
+            int k = (int)(idx - m * K8) << 3;
+            int c = k / (P * P), kh = (k / P) % P, kw = k % P;
+            int64_t b = m / Np;
+            int pi = (int)(m - b * Np), ph = pi / Wp, pw = pi - ph * Wp;
+            const float* s = x + ((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw;
+            float4 a = reinterpret_cast<const float4*>(s)[0], d = reinterpret_cast<const float4*>(s)[1];
+            u32x4 o = {pv_pack_bf16x2(a.x, a.y), pv_pack_bf16x2(a.z, a.w), pv_pack_bf16x2(d.x, d.y), pv_pack_bf16x2(d.z, d.w)};
+            reinterpret_cast<u32x4*>(cols)[idx] = o;
+        }
+    } else {
+        const int64_t total = B * (int64_t)Np * K;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            int64_t m = idx / K;
+            int k = (int)(idx - m * K);
+            int c = k / (P * P), kh = (k / P) % P, kw = k % P;
+            int64_t b = m / Np;
+            int pi = (int)(m - b * Np), ph = pi / Wp, pw = pi - ph * Wp;
+            cols[idx] = pv_f2bf(x[((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw]);
+        }
+    }
+}
+
+extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream) {
+    if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0) return PV_ERR_INVALID_ARG;
+    if (H % P || W % P) return PV_ERR_INVALID_ARG;
+    const bool vec = (P % 8 == 0) && (W % 4 == 0) && !((uintptr_t)x & 15) && !((uintptr_t)cols & 15);
+    const int64_t K = C * P * P, work = B * (H / P) * (W / P) * (vec ? K / 8 : K);
+    dim3 grid(pv_stream_grid(work, 256));
+    if (vec)
+        hipLaunchKernelGGL(pv_im2col_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+    else
+        hipLaunchKernelGGL(pv_im2col_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// token prologue: special rows (+pos) and the optional budget token row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_token_prologue_kernel(float* __restrict__ tokens, const float* __restrict__ special,
+                                                                const float* __restrict__ pos, const float* __restrict__ btok, float budget,
+                                                                int64_t B, int64_t S, int D, int n_special) {
+    const int rows_per_img = n_special + (btok ? 1 : 0);
+    const int64_t total = B * rows_per_img * (int64_t)D;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int d = (int)(idx % D);
+        int64_t r = idx / D;
+        int64_t b = r / rows_per_img;
+        int j = (int)(r - b * rows_per_img);
+        if (j < n_special)
+            tokens[(b * S + j) * D + d] = special[(int64_t)j * D + d] + pos[(int64_t)j * D + d];
+        else
+            tokens[(b * S + (S - 1)) * D + d] = btok[d] * budget;
+    }
+}
+
+extern "C" int pv_token_prologue(float* tokens, const float* special, const float* pos, const float* budget_token, float budget,
+                                 int64_t B, int64_t S_total, int64_t D, int64_t n_special, void* stream) {
+    if (!tokens || !special || !pos || B <= 0 || S_total <= 0 || D <= 0 || n_special < 0 || n_special > S_total) return PV_ERR_INVALID_ARG;
+    const int64_t work = B * (n_special + (budget_token ? 1 : 0)) * D;
+    if (work == 0) return PV_OK;
+    hipLaunchKernelGGL(pv_token_prologue_kernel, dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, tokens, special, pos,
+                       budget_token, budget, B, S_total, (int)D, (int)n_special);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (one wave per row; the row stays in registers: two-pass mean / variance in fp32)
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+struct RowRegs {
+    float4 v[NCH];
+};
+
+template <int NCH>
+__device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __restrict__ xr, int nvec, int lane) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int idx = lane + 64 * j;
+        r.v[j] = idx < nvec ? reinterpret_cast<const float4*>(xr)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros)
+template <int NCH>
+__device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restrict__ gamma, const float* __restrict__ beta, int D,
+                                          int nvec, int lane, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
+    const float mean = pv_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (lane + 64 * j < nvec) {
+            float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(pv_wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int idx = lane + 64 * j;
+        if (idx < nvec) {
+            float4 g = reinterpret_cast<const float4*>(gamma)[idx], b = reinterpret_cast<const float4*>(beta)[idx];
+            r.v[j].x = (r.v[j].x - mean) * rstd * g.x + b.x;
+            r.v[j].y = (r.v[j].y - mean) * rstd * g.y + b.y;
+            r.v[j].z = (r.v[j].z - mean) * rstd * g.z + b.z;
+            r.v[j].w = (r.v[j].w - mean) * rstd * g.w + b.w;
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ row_scale,
+                                                           uint16_t* __restrict__ out, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        RowRegs<NCH> r;
+        pv_load_row<NCH>(r, x + row * ldx, nvec, lane);
+        pv_ln_row<NCH>(r, gamma, beta, D, nvec, lane, eps);
+        const float sc = row_scale ? row_scale[row] : 1.0f;
+        u32x2* o = reinterpret_cast<u32x2*>(out + row * (int64_t)D);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < nvec) {
+                u32x2 p = {pv_pack_bf16x2(r.v[j].x * sc, r.v[j].y * sc), pv_pack_bf16x2(r.v[j].z * sc, r.v[j].w * sc)};
+                o[idx] = p;
+            }
+        }
+    }
+}
+
+#define PV_DISPATCH_NCH(D, MACRO)          \
+    do {                                   \
+        int nch_ = (int)(((D) / 4 + 63) / 64); \
+        if (nch_ <= 1) { MACRO(1); }       \
+        else if (nch_ == 2) { MACRO(2); }  \
+        else if (nch_ == 3) { MACRO(3); }  \
+        else if (nch_ == 4) { MACRO(4); }  \
+        else if (nch_ <= 8) { MACRO(8); }  \
+        else { MACRO(16); }                \
+    } while (0)
+
+extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* row_scale, uint16_t* out,
+                                 int64_t rows, int64_t D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
+    if (ldx % 4 || ldx < D || ((uintptr_t)x & 15) || ((uintptr_t)out & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return PV_ERR_INVALID_ARG;
+    dim3 grid(pv_stream_grid(rows, 4));
+#define LN_LAUNCH(N) hipLaunchKernelGGL(pv_layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
+    PV_DISPATCH_NCH(D, LN_LAUNCH);
+#undef LN_LAUNCH
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// final LayerNorm on class-token rows + sum over class tokens (models/vit.py:95,242-243)
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_cls_pool_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ pooled, int64_t B, int64_t S, int D, int num_cls, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+        RowRegs<NCH> acc;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) acc.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < num_cls; ++c) {
+            RowRegs<NCH> r;
+            pv_load_row<NCH>(r, x + (b * S + c) * (int64_t)D, nvec, lane);
+            pv_ln_row<NCH>(r, gamma, beta, D, nvec, lane, eps);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                acc.v[j].x += r.v[j].x; acc.v[j].y += r.v[j].y; acc.v[j].z += r.v[j].z; acc.v[j].w += r.v[j].w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < nvec) reinterpret_cast<float4*>(pooled + b * (int64_t)D)[idx] = acc.v[j];
+        }
+    }
+}
+
+extern "C" int pv_cls_pool(const float* x, const float* gamma, const float* beta, float* pooled, int64_t B, int64_t S, int64_t D,
+                           int64_t num_cls, float eps, void* stream) {
+    if (!x || !gamma || !beta || !pooled || B <= 0 || S <= 0 || D <= 0 || num_cls <= 0 || num_cls > S) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
+    dim3 grid(pv_stream_grid(B, 4));
+#define CP_LAUNCH(N) hipLaunchKernelGGL(pv_cls_pool_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, pooled, B, S, (int)D, (int)num_cls, eps)
+    PV_DISPATCH_NCH(D, CP_LAUNCH);
+#undef CP_LAUNCH
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 classification head: logits[B,C] = pooled[B,D] . w[C,D]^T + bias   (LDS-tiled, 64x64 tile)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_head_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int B, int D, int C) {
+    __shared__ float As[16][65];
+    __shared__ float Ws[16][65];
+    const int t = threadIdx.x, tm = t >> 4, tn = t & 15;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    const int lr = t >> 2, lk = (t & 3) << 2;   // loader: row lr (0..63), k offset lk (0,4,8,12)
+    for (int k0 = 0; k0 < D; k0 += 16) {
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+        if (m0 + lr < B && k0 + lk < D) av = *reinterpret_cast<const float4*>(a + (int64_t)(m0 + lr) * D + k0 + lk);
+        if (n0 + lr < C && k0 + lk < D) wv = *reinterpret_cast<const float4*>(w + (int64_t)(n0 + lr) * D + k0 + lk);
+        As[lk + 0][lr] = av.x; As[lk + 1][lr] = av.y; As[lk + 2][lr] = av.z; As[lk + 3][lr] = av.w;
+        Ws[lk + 0][lr] = wv.x; Ws[lk + 1][lr] = wv.y; Ws[lk + 2][lr] = wv.z; Ws[lk + 3][lr] = wv.w;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float ar[4], wr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ar[i] = As[k][tm + 16 * i]; wr[i] = Ws[k][tn + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ar[i], wr[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + tm + 16 * i;
+        if (m >= B) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + tn + 16 * j;
+            if (n < C) out[(int64_t)m * C + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+
+extern "C" int pv_head_f32(const float* pooled, const float* w, const float* b, float* logits, int64_t B, int64_t D, int64_t C, void* stream) {
+    if (!pooled || !w || !logits || B <= 0 || D <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || ((uintptr_t)pooled & 15) || ((uintptr_t)w & 15)) return PV_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((B + 63) / 64));
+    hipLaunchKernelGGL(pv_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, pooled, w, b, logits, (int)B, (int)D, (int)C);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RankViT: token norms, rank / top-k, compaction gather  (models/rankvit.py:55-77)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_token_norm_kernel(const float* __restrict__ x, float* __restrict__ norms, int64_t B, int64_t S, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    const int64_t N = S - 1, rows = B * N;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        int64_t b = r / N, i = r - b * N;
+        const float4* xr = reinterpret_cast<const float4*>(x + (b * S + 1 + i) * (int64_t)D);
+        float s = 0.f;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float4 v = xr[idx];
+            s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        s = pv_wave_sum(s);
+        if (lane == 0) norms[r] = sqrtf(s);
+    }
+}
+
+extern "C" int pv_token_norm(const float* x, float* norms, int64_t B, int64_t S, int64_t D, void* stream) {
+    if (!x || !norms || B <= 0 || S < 1 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || ((uintptr_t)x & 15)) return PV_ERR_UNSUPPORTED;
+    if (S == 1) return PV_OK;
+    hipLaunchKernelGGL(pv_token_norm_kernel, dim3(pv_stream_grid(B * (S - 1), 4)), dim3(256), 0, (hipStream_t)stream, x, norms, B, S, (int)D);
+    return pv_check_launch();
+}
+
+// sortable key: larger float (NaN above +inf, like torch's descending argsort) <=> larger uint32
+__device__ __forceinline__ uint32_t pv_sort_key(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// one workgroup per image: keys in LDS, rank_i = #{j : key_j > key_i or (key_j == key_i and j < i)} (stable descending)
+__global__ __launch_bounds__(256) void pv_rank_topk_kernel(const float* __restrict__ norms, int32_t* __restrict__ keep, int N, int k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+    const int64_t b = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += 256) keys[i] = pv_sort_key(norms[b * N + i]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const uint32_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) {
+            uint32_t kj = keys[j];
+            rank += (kj > ki) || (kj == ki && j < i);
+        }
+        if (rank < k) keep[b * k + rank] = i;
+    }
+}
+
+extern "C" int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_t k, void* stream) {
+    if (!norms || !keep || B <= 0 || N <= 0 || k < 0 || k > N) return PV_ERR_INVALID_ARG;
+    if (N > 4096) return PV_ERR_UNSUPPORTED;
+    if (k == 0) return PV_OK;
+    hipLaunchKernelGGL(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)N * 4, (hipStream_t)stream, norms, keep, (int)N, (int)k);
+    return pv_check_launch();
+}
+
+__global__ __launch_bounds__(256) void pv_gather_tokens_kernel(const float* __restrict__ x, const int32_t* __restrict__ keep, float* __restrict__ out,
+                                                               int64_t B, int64_t S_in, int64_t k, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    const int64_t So = k + 1, rows = B * So;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        int64_t b = r / So, j = r - b * So;
+        int64_t srow = j == 0 ? 0 : 1 + (int64_t)keep[b * k + (j - 1)];
+        const float4* s = reinterpret_cast<const float4*>(x + (b * S_in + srow) * (int64_t)D);
+        float4* d = reinterpret_cast<float4*>(out + r * (int64_t)D);
+        for (int idx = lane; idx < nvec; idx += 64) d[idx] = s[idx];
+    }
+}
+
+extern "C" int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B, int64_t S_in, int64_t k, int64_t D, void* stream) {
+    if (!x || !out || B <= 0 || S_in < 1 || k < 0 || k > S_in - 1 || D <= 0 || (k > 0 && !keep)) return PV_ERR_INVALID_ARG;
+    if (D % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pv_gather_tokens_kernel, dim3(pv_stream_grid(B * (k + 1), 4)), dim3(256), 0, (hipStream_t)stream, x, keep, out, B, S_in, k, (int)D);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ResidualViT gate + in-place masking (models/residualvit.py:197-235, eval, sigmoid gate, learnable budget token)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pv_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, float* xo, const float* __restrict__ wg, const float* __restrict__ bg,
+                                                               const float* __restrict__ wb, const float* __restrict__ bb, float temp, float sbias,
+                                                               float* __restrict__ mask_out, float* __restrict__ row_scale, int64_t S, int D) {
+    __shared__ float thr_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    const int64_t b = blockIdx.x, N = S - 2;
+    if (wave == 0) {   // threshold from the budget token (last row), models/residualvit.py:212
+        const float4* xr = reinterpret_cast<const float4*>(x + (b * S + S - 1) * (int64_t)D);
+        float s = 0.f;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float4 v = xr[idx], w = reinterpret_cast<const float4*>(wb)[idx];
+            s += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+        }
+        s = pv_wave_sum(s);
+        if (lane == 0) {
+            thr_s = pv_sigmoid(s + bb[0]);
+            row_scale[b * S] = 1.0f;
+            row_scale[b * S + S - 1] = 1.0f;
+        }
+    }
+    if (xo != x && wave >= 2) {   // pass the class token and the budget token through unchanged
+        const int64_t r = wave == 2 ? 0 : S - 1;
+        const float4* s4 = reinterpret_cast<const float4*>(x + (b * S + r) * (int64_t)D);
+        float4* d4 = reinterpret_cast<float4*>(xo + (b * S + r) * (int64_t)D);
+        for (int idx = lane; idx < nvec; idx += 64) d4[idx] = s4[idx];
+    }
+    __syncthreads();
+    const float thr = thr_s;
+    for (int64_t i = wave; i < N; i += 4) {
+        const float* xr = x + (b * S + 1 + i) * (int64_t)D;
+        float* xw = xo + (b * S + 1 + i) * (int64_t)D;
+        RowRegs<NCH> r;
+        pv_load_row<NCH>(r, xr, nvec, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < nvec) {
+                float4 w = reinterpret_cast<const float4*>(wg)[idx];
+                s += (r.v[j].x * w.x + r.v[j].y * w.y) + (r.v[j].z * w.z + r.v[j].w * w.w);
+            }
+        }
+        s = pv_wave_sum(s) + bg[0];
+        const float m = fmaxf(pv_sigmoid(s / temp + sbias) - thr, 0.f);   // blocks.py:69, residualvit.py:66
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < nvec) reinterpret_cast<float4*>(xw)[idx] = make_float4(r.v[j].x * m, r.v[j].y * m, r.v[j].z * m, r.v[j].w * m);
+        }
+        if (lane == 0) {
+            mask_out[b * N + i] = m;
+            row_scale[b * S + 1 + i] = m;
+        }
+    }
+}
+
+extern "C" int pv_residual_gate(const float* x, float* xo, const float* wg, const float* bg, const float* wb, const float* bb, float temp,
+                                float sigmoid_bias, float* mask_out, float* row_scale, int64_t B, int64_t S, int64_t D, void* stream) {
+    if (!x || !xo || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)xo & 15) || ((uintptr_t)wg & 15) || ((uintptr_t)wb & 15)) return PV_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)B);
+#define RG_LAUNCH(N) hipLaunchKernelGGL(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, S, (int)D)
+    PV_DISPATCH_NCH(D, RG_LAUNCH);
+#undef RG_LAUNCH
+    return pv_check_launch();
+}

@@ -1,0 +1,180 @@
+"""Host-side executor of the MI355X forward path: sequences the C-ABI kernels for one encoder block,
+the patch embedding and the classification head.  Pure plumbing: buffers come from PyTorch's caching
+allocator, launches go to torch's current stream, arithmetic happens in libpeekvit_hip.so only.
+
+HBM data layout:
+  residual stream   fp32 [B, S, D]        (token-major, one 4*D-byte row per token)
+  GEMM operands     bf16 [B*S, D|M]       (LayerNorm / attention / GELU outputs, K-contiguous)
+  packed q|k|v      bf16 [B, S, 3D]       (nn.MultiheadAttention in_proj order; heads are 2*dh-byte column slices)
+  weights           bf16 [N, K]           (nn.Linear (out,in) layout, cast once per parameter version)
+"""
+from __future__ import annotations
+
+import math
+import os
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_POS_F32, PV_EPI_BIAS_RES_F32, PeekvitHipError
+
+
+def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> str:
+    """'hip' for GPU tensors outside autograd, else 'torch' (stock-op composite used on CPU tensors and
+    while autograd is recording - backward kernels are a later row of SURVEY.md section 8).
+    PEEKVIT_AMD_BACKEND=hip makes every non-eligible call raise instead of taking the composite path."""
+    forced = os.environ.get("PEEKVIT_AMD_BACKEND", "")
+    eligible = x.is_cuda and not torch.is_grad_enabled() and not (module.training and dropout_p > 0.0)
+    if forced == "torch":
+        return "torch"
+    if forced == "hip" and not eligible:
+        raise PeekvitHipError("PEEKVIT_AMD_BACKEND=hip but the call is not eligible for the HIP path "
+                              "(needs a GPU tensor, torch.no_grad(), and inactive dropout)")
+    return "hip" if eligible else "torch"
+
+
+# ------------------------------------------------------------------------------------------------
+# workspace arena: named scratch buffers per device, grown on demand, reused across blocks/calls
+# ------------------------------------------------------------------------------------------------
+class _Workspace:
+    def __init__(self):
+        self._bufs: Dict[Tuple[str, torch.device], torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        key = (name, device)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf[:nbytes].view(dtype).view(*shape)
+
+    def clear(self):
+        self._bufs.clear()
+
+
+workspace = _Workspace()
+
+# ------------------------------------------------------------------------------------------------
+# bf16 weight cache: one cast per (parameter storage, version)
+# ------------------------------------------------------------------------------------------------
+_wcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
+
+
+def bf16_weight(p: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes."""
+    key = id(p)
+    ent = _wcache.get(key)
+    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+        return ent[3]
+    src = p.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    w = ops.cast_bf16(src.view(src.shape[0], -1))
+    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), p._version, p.data_ptr(), w)
+    return w
+
+
+def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if p is None:
+        return None
+    d = p.detach()
+    return d if d.is_contiguous() else d.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# one pre-LN encoder block (reference models/vit.py:45-55; masked form models/residualvit.py:249-260)
+# ------------------------------------------------------------------------------------------------
+def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
+
+    7 launches: LN1 -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual)
+                -> LN2 -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias, +residual).
+    row_scale [B,S] (ResidualViT fwd_mask) multiplies LN1 out, the attention branch and LN2 out.
+    """
+    if x.dtype != torch.float32:
+        x = x.float()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, S, D = x.shape
+    mha = blk.self_attention.self_attention
+    H = mha.num_heads
+    dh = D // H
+    M = blk.mlp.fc1.out_features
+    dev = x.device
+    R = B * S
+
+    h = workspace.get("h", (R, D), torch.bfloat16, dev)
+    qkv = workspace.get("qkv", (R, 3 * D), torch.bfloat16, dev)
+    att = workspace.get("att", (R, D), torch.bfloat16, dev)
+    g = workspace.get("g", (R, M), torch.bfloat16, dev)
+    x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
+    out = torch.empty_like(x)
+
+    ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
+    ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
+             qcols=D, qscale=float(dh) ** -0.5)
+    ops.attention(qkv, att, B, S, H, dh)
+    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
+             res=x.view(R, D), row_scale=row_scale)
+    ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h, row_scale)
+    ops.gemm(h, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
+    ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
+             res=x1.view(R, D))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding + special tokens + positional embedding (reference models/vit.py:203-236, :92)
+# ------------------------------------------------------------------------------------------------
+def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[torch.Tensor] = None,
+                 budget: float = 0.0) -> torch.Tensor:
+    """img fp32 [B,3,R,R] -> tokens fp32 [B,S_total,D] = [cls | registers | patches] + pos_embedding
+    (+ one trailing budget-token row without positional embedding for ResidualViT)."""
+    if img.dtype != torch.float32:
+        img = img.float()
+    if not img.is_contiguous():
+        img = img.contiguous()
+    B = img.shape[0]
+    P, D = model.patch_size, model.hidden_dim
+    Np = (img.shape[2] // P) * (img.shape[3] // P)
+    n_special = model.num_class_tokens + model.num_registers
+    S = n_special + Np + (1 if budget_token is not None else 0)
+    K = img.shape[1] * P * P
+    dev = img.device
+
+    cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
+    ops.im2col(img, P, cols)
+    tokens = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+    pos = _f32(model.encoder.pos_embedding).view(-1, D)
+    ops.gemm(cols, bf16_weight(model.conv_proj.weight), _f32(model.conv_proj.bias), tokens.view(B * S, D),
+             PV_EPI_BIAS_POS_F32, M=B * Np, pos=pos, rows_per_img_in=Np, rows_per_img_out=S, row_off=n_special)
+    special = _f32(model.class_tokens).view(-1, D)
+    if model.num_registers > 0:
+        special = torch.cat([special, _f32(model.register_tokens).view(-1, D)], dim=0)
+    ops.token_prologue(tokens, special, pos, _f32(budget_token), budget, n_special)
+    return tokens
+
+
+def pool_and_head(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
+    """Final LayerNorm on the class-token rows, sum over class tokens, fp32 head (models/vit.py:95,242-246)."""
+    ln = model.encoder.ln
+    pooled = ops.cls_pool(tokens, _f32(ln.weight), _f32(ln.bias), ln.eps, model.num_class_tokens)
+    return ops.head(pooled, _f32(model.head.weight), _f32(model.head.bias))
+
+
+def sort_and_drop(x: torch.Tensor, budget: float):
+    """RankViT token ranking + compaction (models/rankvit.py:55-77).  Returns (tokens [B,1+k,D], keep int32 [B,k])."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    N = x.shape[1] - 1
+    k = math.ceil(N * budget)
+    norms = ops.token_norm(x)
+    keep = ops.rank_topk(norms, k)
+    return ops.gather_tokens(x, keep), keep

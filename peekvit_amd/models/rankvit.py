@@ -1,0 +1,105 @@
+"""Token-ranking ViT behind the reference's interface (reference models/rankvit.py).
+
+Blocks listed in `rankvit_layers` rank their non-class tokens by L2 norm and keep the top
+ceil(N * budget) - in descending-norm order - before running the ordinary pre-LN block
+(models/rankvit.py:55-97).  On the MI355X path the ranking is three HIP kernels (row norms, per-image
+rank/top-k in LDS, coalesced row compaction); ties rank lowest-index-first (the reference's argsort is
+unstable there).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Union
+
+import torch
+from torch import nn
+
+from .. import engine
+from .vit import ViTBlock, _ViTBase, _make_layers
+
+
+class RankViTBlock(ViTBlock):
+    """ViTBlock preceded by sort_and_drop when its budget is not 1 (reference models/rankvit.py:24-101)."""
+
+    def __init__(self, num_heads: int, hidden_dim: int, mlp_dim: int, dropout: float, attention_dropout: float):
+        super().__init__(num_heads, hidden_dim, mlp_dim, dropout, attention_dropout)
+        self.sort = False
+        self.current_budget = 1.0
+        self.last_keep = None      # int32 [B,k] indices kept by the most recent HIP sort_and_drop (introspection/tests)
+
+    def sort_and_drop(self, input: torch.Tensor):
+        torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        if engine.backend_for(input, self, self._p_drop) == "hip":
+            out, self.last_keep = engine.sort_and_drop(input, self.current_budget)
+            return out
+        cls_tok, rest = input[:, :1], input[:, 1:]
+        order = torch.argsort(torch.norm(rest, dim=-1), dim=-1, descending=True, stable=True)
+        keep = order[:, :math.ceil(rest.shape[1] * self.current_budget)]
+        self.last_keep = keep
+        kept = torch.gather(rest, 1, keep.unsqueeze(-1).expand(-1, -1, rest.shape[-1]))
+        return torch.cat([cls_tok, kept], dim=1)
+
+    def forward(self, input: torch.Tensor):
+        torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        if self.current_budget != 1:
+            input = self.sort_and_drop(input)
+        return super().forward(input)
+
+    def set_budget(self, budget: float):
+        self.current_budget = budget
+
+
+class RankViTEncoder(nn.Module):
+    """Encoder whose blocks at `rankvit_layers` are RankViTBlocks (reference models/rankvit.py:105-152).
+    Like the reference, `rankvit_layers=None` raises TypeError (`i in None`)."""
+
+    def __init__(self, seq_length: int, num_layers: int, num_heads: int, hidden_dim: int, mlp_dim: int, dropout: float,
+                 attention_dropout: float, rankvit_layers: Optional[List[Union[int, float]]] = None):
+        super().__init__()
+        self.pos_embedding = nn.Parameter(torch.empty(1, seq_length, hidden_dim).normal_(std=0.02))
+        self.dropout = nn.Dropout(dropout)
+        self.layers = _make_layers(
+            lambda i: (RankViTBlock if i in rankvit_layers else ViTBlock)(num_heads, hidden_dim, mlp_dim, dropout,
+                                                                         attention_dropout), num_layers)
+        self.ln = nn.LayerNorm(hidden_dim)
+
+    def forward(self, input: torch.Tensor, _pos_added: bool = False):
+        torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        if _pos_added:
+            return self.layers(input)
+        return self.ln(self.layers(self.dropout(input + self.pos_embedding)))
+
+
+class RankVisionTransformer(_ViTBase):
+    """reference models/rankvit.py:156-339."""
+
+    def __init__(self, image_size: int, patch_size: int, num_layers: int, num_heads: int, hidden_dim: int,
+                 mlp_dim: int, dropout: float = 0.0, attention_dropout: float = 0.0, num_classes: int = 1000,
+                 representation_size: Optional[int] = None, num_registers: int = 0, num_class_tokens: int = 1,
+                 torch_pretrained_weights: Optional[str] = None, timm_pretrained_weights: Optional[str] = None,
+                 rankvit_layers: Optional[List[Union[int, float]]] = None):
+        super().__init__()
+        seq_length = self._init_stem(image_size, patch_size, hidden_dim, mlp_dim, dropout, attention_dropout,
+                                     num_classes, representation_size, num_heads, num_registers, num_class_tokens)
+        self.rankvit_layers = rankvit_layers
+        if num_registers > 0:
+            raise ValueError("Registers are not supported yet for this model.")
+        self.encoder = RankViTEncoder(seq_length, num_layers, num_heads, hidden_dim, mlp_dim, dropout,
+                                      attention_dropout, rankvit_layers)
+        self.seq_length = seq_length
+        self._init_head()
+        self.load_weights(torch_pretrained_weights, timm_pretrained_weights)
+
+    def forward(self, x: torch.Tensor):
+        self._check_image(x)
+        if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
+            tokens = self.encoder(engine.embed_tokens(self, x), _pos_added=True)
+            return engine.pool_and_head(self, tokens)
+        return self._composite_head(self.encoder(self._composite_tokens(x)))
+
+    def set_budget(self, budget: float):
+        """Only the blocks in rankvit_layers receive it; a list is indexed by LAYER index
+        (reference models/rankvit.py:283-288)."""
+        self.current_budget = budget
+        for i in self.rankvit_layers:
+            self.encoder.layers[i].set_budget(budget[i] if isinstance(budget, list) else budget)

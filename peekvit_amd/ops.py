@@ -1,0 +1,155 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/peekvit_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every FLOP of the hot path is done by
+libpeekvit_hip.so.  All wrappers launch on torch's CURRENT stream and never synchronise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+# launch counter: tests assert that the HIP path (not some silent eager path) produced the result
+launch_count = 0
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.PeekvitHipError(f"{name}: expected a GPU tensor, got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.PeekvitHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.PeekvitHipError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _count():
+    global launch_count
+    launch_count += 1
+
+
+def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(src, torch.float32, "src")
+    if out is None:
+        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(_lib.load().pv_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "pv_cast_f32_bf16")
+    _count()
+    return out
+
+
+def im2col(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    B, Cc, H, W = x.shape
+    check(_lib.load().pv_im2col_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _stream(x)), "pv_im2col_bf16")
+    _count()
+    return out
+
+
+def token_prologue(tokens, special, pos, budget_token, budget: float, n_special: int):
+    B, S, D = tokens.shape
+    check(_lib.load().pv_token_prologue(_ptr(tokens), _ptr(special), _ptr(pos), _ptr(budget_token), float(budget),
+                                        B, S, D, n_special, _stream(tokens)), "pv_token_prologue")
+    _count()
+
+
+def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, row_scale=None):
+    """x: fp32 [..., D] contiguous -> out bf16 same shape."""
+    D = x.shape[-1]
+    rows = x.numel() // D
+    check(_lib.load().pv_layernorm_bf16(_ptr(x), D, _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(out), rows, D,
+                                        float(eps), _stream(x)), "pv_layernorm_bf16")
+    _count()
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0):
+    """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1])."""
+    K = a.shape[-1]
+    if M is None:
+        M = a.numel() // K
+    N = w.shape[0]
+    args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr() if bias is not None else 0,
+                    out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
+                    row_scale=row_scale.data_ptr() if row_scale is not None else 0,
+                    pos=pos.data_ptr() if pos is not None else 0,
+                    M=M, N=N, K=K, lda=K, ldw=w.shape[-1], ldo=out.shape[-1],
+                    ldr=res.shape[-1] if res is not None else 0,
+                    rows_per_img_in=rows_per_img_in, rows_per_img_out=rows_per_img_out, row_off=row_off,
+                    qcols=qcols, qscale=float(qscale), epilogue=epilogue)
+    check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
+    _count()
+    return out
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
+    check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_bf16")
+    _count()
+    return out
+
+
+def cls_pool(x: torch.Tensor, gamma, beta, eps: float, num_cls: int) -> torch.Tensor:
+    B, S, D = x.shape
+    pooled = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    check(_lib.load().pv_cls_pool(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(pooled), B, S, D, num_cls, float(eps),
+                                  _stream(x)), "pv_cls_pool")
+    _count()
+    return pooled
+
+
+def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
+    B, D = pooled.shape
+    Cn = w.shape[0]
+    logits = torch.empty((B, Cn), dtype=torch.float32, device=pooled.device)
+    check(_lib.load().pv_head_f32(_ptr(pooled), _ptr(w), _ptr(b), _ptr(logits), B, D, Cn, _stream(pooled)), "pv_head_f32")
+    _count()
+    return logits
+
+
+def token_norm(x: torch.Tensor) -> torch.Tensor:
+    B, S, D = x.shape
+    norms = torch.empty((B, S - 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().pv_token_norm(_ptr(x), _ptr(norms), B, S, D, _stream(x)), "pv_token_norm")
+    _count()
+    return norms
+
+
+def rank_topk(norms: torch.Tensor, k: int) -> torch.Tensor:
+    B, N = norms.shape
+    keep = torch.empty((B, k), dtype=torch.int32, device=norms.device)
+    check(_lib.load().pv_rank_topk(_ptr(norms), _ptr(keep), B, N, k, _stream(norms)), "pv_rank_topk")
+    _count()
+    return keep
+
+
+def gather_tokens(x: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    B, S, D = x.shape
+    k = keep.shape[1]
+    out = torch.empty((B, k + 1, D), dtype=torch.float32, device=x.device)
+    check(_lib.load().pv_gather_tokens(_ptr(x), _ptr(keep), _ptr(out), B, S, k, D, _stream(x)), "pv_gather_tokens")
+    _count()
+    return out
+
+
+def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float):
+    """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]."""
+    B, S, D = x.shape
+    mask = torch.empty((B, S - 2, 1), dtype=torch.float32, device=x.device)
+    row_scale = torch.empty((B, S), dtype=torch.float32, device=x.device)
+    check(_lib.load().pv_residual_gate(_ptr(x), _ptr(x_out), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp),
+                                       float(sigmoid_bias), _ptr(mask), _ptr(row_scale), B, S, D, _stream(x)),
+          "pv_residual_gate")
+    _count()
+    return mask, row_scale

@@ -1,0 +1,171 @@
+"""GPU parity, model level: the nn.Module surface on the HIP path against
+  (a) the oracle in bf16 'same-rounding-points' mode (tight), and
+  (b) golden logits captured from the REAL fp32 reference (looser: bf16 operand rounding),
+plus size-independent properties at BASELINE's full batch (batch invariance, permutation equivariance)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import vit_oracle as O
+from peekvit_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# tolerances (relative L2 of logits).  TOL_SAME: HIP vs oracle with identical rounding points - residual
+# differences are fp32 summation order / exp ulps amplified by bf16 re-rounding.  TOL_FP32: HIP (bf16 MFMA
+# operands, fp32 accumulate, fp32 residual stream) vs the fp32 reference; the survey measured 3.6e-3..4.8e-3
+# for this arithmetic at random init, BASELINE's 1e-3 needs split-precision operands.
+TOL_SAME = 2e-3
+TOL_FP32 = 1.2e-2
+
+
+def _model(kind, name, **extra):
+    from peekvit_amd.models.vit import VisionTransformer
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    cfg = synth.MODEL_CONFIGS[name]
+    cls = dict(vit=VisionTransformer, rank=RankVisionTransformer, res=ResidualVisionTransformer)[kind]
+    m = cls(**cfg, **extra)
+    synth.load_synth_weights(m, dict(cfg, **extra), "residualvit" if kind == "res" else "vit", seed=0)
+    return cfg, m.eval().to(DEV)
+
+
+def _x(cfg, b=2):
+    return torch.from_numpy(synth.synth_images(b, cfg["image_size"], seed=0))
+
+
+@pytest.mark.parametrize("name", ["vit_micro", "vit_tiny", "vit_small", "vit_b_16"])
+def test_vit_forward_parity(golden, name):
+    from peekvit_amd import ops
+    cfg, m = _model("vit", name)
+    x = _x(cfg)
+    n0 = ops.launch_count
+    with torch.no_grad():
+        logits = m(x.to(DEV)).cpu().numpy()
+    assert ops.launch_count - n0 >= 4 + 7 * cfg["num_layers"], "the HIP kernels did not run"
+    sd = synth.synth_state_dict(cfg)
+    same = O.vit_forward(x, sd, cfg, "bf16").numpy()
+    assert rel_l2(logits, same) < TOL_SAME
+    assert rel_l2(logits, golden(name)["logits"]) < TOL_FP32
+
+
+def test_vit_micro_per_block_activations(golden):
+    g = golden("vit_micro")
+    cfg, m = _model("vit", "vit_micro")
+    outs = []
+    hooks = [blk.register_forward_hook(lambda mod, i, o: outs.append(o.float().cpu())) for blk in m.encoder.layers]
+    with torch.no_grad():
+        m(_x(cfg).to(DEV))
+    for h in hooks:
+        h.remove()
+    for i, o in enumerate(outs):
+        assert rel_l2(o.numpy(), g["block_out"][i]) < 6e-3
+
+
+def test_block_level_standalone_and_surgery():
+    """A block called on its own (as add_noise / remove_layers surgery relies on) runs the HIP path."""
+    cfg, m = _model("vit", "vit_micro")
+    x = torch.from_numpy(synth.tensor("blk/x", (2, 17, 128), "normal", seed=3, bf16=False))
+    with torch.no_grad():
+        y = m.encoder.layers[0](x.to(DEV)).cpu()
+    ref = O.vit_block(x, synth.synth_state_dict(cfg), "encoder.layers.0.", cfg["num_heads"], 1e-5, "bf16")
+    assert rel_l2(y.numpy(), ref.numpy()) < 1e-3
+    m.remove_layers([1])
+    assert len(m.encoder.layers) == 1
+    with torch.no_grad():
+        assert m(_x(cfg).to(DEV)).shape == (2, cfg["num_classes"])
+
+
+@pytest.mark.parametrize("name,layers,b", [("vit_micro", [0, 1], 0.5), ("vit_micro", [0, 1], 0.25), ("vit_tiny", [1, 2, 3], 0.5),
+                                           ("vit_b_16", [3, 6, 9], 0.5)])
+def test_rankvit_parity(golden, name, layers, b):
+    g = golden("rankvit")
+    cfg, m = _model("rank", name, rankvit_layers=layers)
+    x = _x(cfg)
+    m.set_budget(b)
+    ins = {}
+    hooks = [m.encoder.layers[li].register_forward_pre_hook(lambda mod, i, li=li: ins.__setitem__(li, i[0].cpu()))
+             for li in layers]
+    seqs = []
+    hooks += [blk.register_forward_hook(lambda mod, i, o: seqs.append(o.shape[1])) for blk in m.encoder.layers]
+    with torch.no_grad():
+        logits = m(x.to(DEV)).cpu().numpy()
+    for h in hooks:
+        h.remove()
+    assert seqs == list(g[f"{name}_b{b}_seq"])                       # per-layer sequence lengths = reference
+    # keep-indices: bit-exact against the oracle's ranking of the SAME block input
+    for li in layers:
+        _, keep = O.sort_and_drop(ins[li], b)
+        assert np.array_equal(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), keep.numpy())
+    assert rel_l2(logits, g[f"{name}_b{b}_logits"]) < 2.5e-2          # e2e indices may legitimately differ after bf16 layers
+    m.set_budget(1.0)
+    with torch.no_grad():
+        full = m(x.to(DEV)).cpu().numpy()
+    assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("tag,name,gb", [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_micro", 0), ("vit_b_16", "vit_b_16", 10)])
+def test_residualvit_parity(golden, tag, name, gb):
+    g = golden("residualvit")
+    extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=gb, add_budget_token="learnable", gate_threshold=0.5)
+    cfg, m = _model("res", name, **extra)
+    x = _x(cfg)
+    sd = synth.synth_state_dict(dict(cfg, **extra), "residualvit")
+    for b in (0.2, 0.5, 1.0):
+        m.set_budget(b)
+        with torch.no_grad():
+            logits = m(x.to(DEV)).cpu().numpy()
+        masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
+        tr = {}
+        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "bf16", trace=tr).numpy()
+        assert rel_l2(logits, same) < 3e-3
+        assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
+        assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
+        assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_FP32 * 2
+
+
+def test_error_contract_matches_reference():
+    import json, os
+    from conftest import GOLDEN
+    from peekvit_amd.models.vit import VisionTransformer
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    err = json.load(open(os.path.join(GOLDEN, "meta.json")))["errors"]
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    m = VisionTransformer(**cfg).eval().to(DEV)
+    cases = {
+        "wrong_height": lambda: m(torch.zeros(1, 3, 40, 32, device=DEV)),
+        "wrong_width": lambda: m(torch.zeros(1, 3, 32, 40, device=DEV)),
+        "block_rank": lambda: m.encoder.layers[0](torch.zeros(4, 4, device=DEV)),
+        "rank_registers": lambda: RankVisionTransformer(**cfg, num_registers=2, rankvit_layers=[0]),
+        "rank_none_layers": lambda: RankVisionTransformer(**cfg),
+        "residual_no_budget_eval": lambda: ResidualVisionTransformer(**cfg, gate_type="sigmoid", add_budget_token="learnable").eval().to(DEV)(
+            torch.zeros(1, 3, 32, 32, device=DEV)),
+    }
+    for key, fn in cases.items():
+        with torch.no_grad(), pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == err[key]["type"] and str(ei.value) == err[key]["message"], key
+
+
+def test_full_batch_properties_vit_b_16():
+    """BASELINE config 3 size (B=2048, 224x224): batch invariance + permutation equivariance, bit-exact."""
+    cfg, m = _model("vit", "vit_b_16")
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    small = torch.randn(4, 3, 224, 224, generator=gen).to(torch.bfloat16).float()
+    B = 2048
+    big = torch.randn(B, 3, 224, 224, generator=gen).to(torch.bfloat16).float()
+    pos = [0, 777, 1500, 2047]
+    for p, s in zip(pos, small):
+        big[p] = s
+    with torch.no_grad():
+        ls = m(small.to(DEV)).cpu()
+        lb = m(big.to(DEV)).cpu()
+    assert torch.isfinite(lb).all()
+    assert torch.equal(lb[pos], ls)                                    # an image's logits do not depend on its batch
+    perm = torch.randperm(B, generator=gen)
+    with torch.no_grad():
+        lp = m(big[perm].to(DEV)).cpu()
+    assert torch.equal(lp, lb[perm])                                   # permuting images permutes logits

@@ -1,0 +1,210 @@
+"""GPU parity, op level: every C-ABI kernel against the CPU oracle on the same seeded inputs.
+Inputs are bf16-representable, so bf16-operand kernels differ from the oracle's bf16 mode only by fp32
+summation order (and by 1-ulp bf16 rounding flips on bf16 outputs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import vit_oracle as O
+from peekvit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from peekvit_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return _ops
+
+
+def T(name, shape, kind="normal", scale=1.0, shift=0.0, bf16=True):
+    return torch.from_numpy(synth.tensor("t/" + name, shape, kind, scale, shift, seed=1, bf16=bf16))
+
+
+def bf(x):   # fp32 tensor holding bf16-representable values -> bf16 GPU tensor
+    return x.to(torch.bfloat16).to(DEV)
+
+
+def test_cast_and_im2col_bit_exact(ops):
+    x = T("img", (3, 3, 32, 48))
+    cols = torch.empty((3 * 4 * 6, 3 * 64), dtype=torch.bfloat16, device=DEV)
+    ops.im2col(x.to(DEV), 8, cols)
+    ref = torch.nn.functional.unfold(x, kernel_size=8, stride=8).transpose(1, 2).reshape(-1, 192)
+    assert torch.equal(cols.float().cpu(), ref)
+    # non-vector path (P not a multiple of 8)
+    x2 = T("img2", (2, 3, 12, 12))
+    cols2 = torch.empty((2 * 4, 3 * 36), dtype=torch.bfloat16, device=DEV)
+    ops.im2col(x2.to(DEV), 6, cols2)
+    ref2 = torch.nn.functional.unfold(x2, kernel_size=6, stride=6).transpose(1, 2).reshape(-1, 108)
+    assert torch.equal(cols2.float().cpu(), ref2)
+    v = T("cast", (1037,), bf16=False)
+    assert torch.equal(ops.cast_bf16(v.to(DEV)).cpu(), v.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("rows,D", [(7, 64), (197 * 3, 768), (50, 256), (33, 384), (5, 1024), (3, 2048)])
+def test_layernorm(ops, rows, D):
+    x = T(f"ln{D}", (rows, D), scale=2.0, shift=0.3, bf16=False)
+    g, b = T(f"lng{D}", (D,), "uniform", 0.2, 1.0), T(f"lnb{D}", (D,), "uniform", 0.1)
+    rs = T(f"lnrs{D}", (rows,), "uniform", 0.5, 0.5, bf16=False)
+    for eps, scale in ((1e-5, None), (1e-6, rs)):
+        out = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+        ops.layernorm_bf16(x.to(DEV), g.to(DEV), b.to(DEV), eps, out, None if scale is None else scale.to(DEV))
+        ref = O.layer_norm(x, g, b, eps)
+        if scale is not None:
+            ref = ref * scale[:, None]
+        got = out.float().cpu()
+        assert rel_l2(got, ref) < 3e-3                      # bf16 output rounding
+        assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
+GEMM_SHAPES = [(100, 128, 64), (256, 256, 128), (300, 384, 192), (197 * 2, 2304, 768), (130, 768, 3072), (77, 1000, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_epilogues(ops, M, N, K):
+    from peekvit_amd._lib import PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32
+    a, w = T(f"ga{M}{K}", (M, K)), T(f"gw{N}{K}", (N, K), "uniform", 1.0 / math.sqrt(K))
+    bias = T(f"gb{N}", (N,), "uniform", 0.1, bf16=False)
+    res = T(f"gr{M}{N}", (M, N), bf16=False)
+    rs = T(f"gs{M}", (M,), "uniform", 0.5, 0.5, bf16=False)
+    ref = a.double() @ w.double().t() + bias.double()
+    A, W, Bv = bf(a), bf(w), bias.to(DEV)
+    # bias (+ q scaling on the first qcols columns), bf16 out
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    qcols = (N // 3) // 4 * 4
+    ops.gemm(A, W, Bv, out, PV_EPI_BIAS_BF16, qcols=qcols, qscale=0.125)
+    r = ref.clone()
+    r[:, :qcols] *= 0.125
+    assert rel_l2(out.float().cpu(), r) < 3e-3
+    # bias + exact GELU, bf16 out
+    ops.gemm(A, W, Bv, out, PV_EPI_BIAS_GELU_BF16)
+    assert rel_l2(out.float().cpu(), torch.nn.functional.gelu(ref)) < 3e-3
+    # bias + residual (+ row scale), fp32 out
+    o32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, W, Bv, o32, PV_EPI_BIAS_RES_F32, res=res.to(DEV))
+    assert rel_l2(o32.cpu(), ref + res.double()) < 2e-6
+    ops.gemm(A, W, Bv, o32, PV_EPI_BIAS_RES_F32, res=res.to(DEV), row_scale=rs.to(DEV))
+    assert rel_l2(o32.cpu(), rs.double()[:, None] * ref + res.double()) < 2e-6
+    # in-place residual (out aliases res)
+    inpl = res.to(DEV).clone()
+    ops.gemm(A, W, Bv, inpl, PV_EPI_BIAS_RES_F32, res=inpl)
+    assert rel_l2(inpl.cpu(), ref + res.double()) < 2e-6
+
+
+def test_gemm_patch_embed_epilogue(ops):
+    from peekvit_amd._lib import PV_EPI_BIAS_POS_F32
+    B, Np, S, D, K, off = 3, 16, 19, 128, 192, 2
+    a, w = T("pa", (B * Np, K)), T("pw", (D, K), "uniform", 0.07)
+    bias, pos = T("pb", (D,), "uniform", 0.1), T("pp", (S, D), scale=0.02)
+    out = torch.full((B, S, D), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(bf(a), bf(w), bias.to(DEV), out.view(B * S, D), PV_EPI_BIAS_POS_F32, pos=pos.to(DEV),
+             rows_per_img_in=Np, rows_per_img_out=S, row_off=off)
+    ref = (a.double() @ w.double().t() + bias.double()).view(B, Np, D) + pos.double()[off:off + Np]
+    got = out.cpu()
+    assert rel_l2(got[:, off:off + Np], ref) < 2e-6
+    assert torch.all(got[:, :off] == 7.0) and torch.all(got[:, off + Np:] == 7.0)   # untouched rows
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from peekvit_amd._lib import PV_EPI_BIAS_BF16, PeekvitHipError
+    a, w = bf(T("ba", (8, 96))), bf(T("bw", (16, 96)))
+    with pytest.raises(PeekvitHipError):
+        ops.gemm(a, w, None, torch.empty((8, 16), dtype=torch.bfloat16, device=DEV), PV_EPI_BIAS_BF16)   # K % 64 != 0
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 197, 12, 64), (3, 17, 2, 64), (2, 401, 8, 32), (2, 197, 8, 48), (2, 99, 3, 64),
+                                      (1, 50, 4, 64), (2, 26, 12, 64), (1, 5, 2, 32), (1, 1, 1, 64), (2, 64, 2, 32)])
+def test_attention(ops, B, S, H, dh):
+    D = H * dh
+    qkv = T(f"qkv{S}{H}{dh}", (B, S, 3 * D), scale=1.0)
+    qkv[..., :D] *= dh ** -0.5            # q arrives pre-scaled from the in-proj epilogue
+    qkv = qkv.to(torch.bfloat16).float()
+    out = torch.empty((B, S, D), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(torch.bfloat16).to(DEV), out, B, S, H, dh)
+    q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    ref = O.attention_core(q, k, v, "bf16").transpose(1, 2).reshape(B, S, D)
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    exact = torch.softmax(q.double() @ k.double().transpose(-1, -2), -1) @ v.double()
+    assert rel_l2(out.float().cpu(), exact.transpose(1, 2).reshape(B, S, D)) < 6e-3
+
+
+def test_attention_spiked_scores(ops):
+    """One key dominates a query row (softmax ~ one-hot) and one row has huge negative scores."""
+    B, S, H, dh = 1, 197, 1, 64
+    qkv = T("spk", (B, S, 3 * dh), scale=0.5)
+    qkv[0, 3, :dh] = 6.0
+    qkv[0, 100, dh:2 * dh] = 6.0
+    qkv[0, 7, :dh] = -6.0
+    qkv = qkv.to(torch.bfloat16).float()
+    out = torch.empty((B, S, dh), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(torch.bfloat16).to(DEV), out, B, S, H, dh)
+    q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2) for t in qkv.split(dh, dim=-1))
+    ref = O.attention_core(q, k, v, "bf16").transpose(1, 2).reshape(B, S, dh)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+
+
+def test_cls_pool_and_head(ops):
+    B, S, D, C = 5, 9, 256, 1000
+    x = T("cp", (B, S, D), scale=1.5, bf16=False)
+    g, b = T("cpg", (D,), "uniform", 0.2, 1.0), T("cpb", (D,), "uniform", 0.1)
+    for nc in (1, 3):
+        pooled = ops.cls_pool(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, nc)
+        ref = O.layer_norm(x[:, :nc], g, b, 1e-5).sum(1)
+        assert rel_l2(pooled.cpu(), ref) < 1e-6
+    w, hb = T("hw", (C, D), scale=0.02), T("hb", (C,), "uniform", 0.02)
+    logits = ops.head(pooled, w.to(DEV), hb.to(DEV))
+    assert rel_l2(logits.cpu(), pooled.cpu().double() @ w.double().t() + hb.double()) < 1e-6
+    assert logits.shape == (B, C)
+
+
+def test_rank_path_bit_exact_vs_reference_golden(ops, golden):
+    """token_norm -> rank_topk -> gather against indices/outputs the REAL reference produced."""
+    from oracle.make_golden import sorted_gap_tokens
+    g = golden("sort_and_drop")
+    for N in (196, 400):
+        x = torch.from_numpy(sorted_gap_tokens(2, N, 64, seed=0))
+        xd = x.to(DEV)
+        norms = ops.token_norm(xd)
+        assert rel_l2(norms.cpu(), torch.norm(x[:, 1:], dim=-1)) < 1e-6
+        for b in (0.1, 0.25, 0.5, 0.75, 0.99):
+            k = math.ceil(N * b)
+            keep = ops.rank_topk(norms, k)
+            assert np.array_equal(keep.cpu().numpy().astype(np.int64), g[f"N{N}_b{b}_idx"])      # bit-exact indices
+            out = ops.gather_tokens(xd, keep)
+            assert np.array_equal(out.cpu().numpy(), g[f"N{N}_b{b}_out"])                        # bit-exact rows
+
+
+def test_rank_ties_lowest_index_first_and_edges(ops):
+    norms = torch.tensor([[1.0, 3.0, 3.0, 0.5, 3.0, 2.0], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]], device=DEV)
+    keep = ops.rank_topk(norms, 6).cpu()
+    assert keep[0].tolist() == [1, 2, 4, 5, 0, 3] and keep[1].tolist() == [0, 1, 2, 3, 4, 5]
+    assert ops.rank_topk(norms, 1).cpu()[:, 0].tolist() == [1, 0]
+    x = T("g1", (2, 7, 64), bf16=False).to(DEV)
+    out = ops.gather_tokens(x, keep[:, :1].to(DEV).contiguous())       # k = 1
+    assert torch.equal(out[:, 0], x[:, 0]) and torch.equal(out[0, 1], x[0, 2]) and torch.equal(out[1, 1], x[1, 1])
+
+
+def test_residual_gate(ops):
+    B, S, D = 3, 19, 128
+    x = T("rg", (B, S, D), bf16=False)
+    wg, bg = T("rgw", (1, D), "uniform", 0.3), T("rgb", (1,), "uniform", 0.1)
+    wb, bb = T("rbw", (1, D), "uniform", 0.1), T("rbb", (1,), "uniform", 0.1)
+    for sbias in (10.0, 0.0):
+        xo = torch.empty_like(x, device=DEV)
+        mask, rs = ops.residual_gate(x.to(DEV), xo, wg.to(DEV), bg.to(DEV), wb.to(DEV), bb.to(DEV), 1.0, sbias)
+        thr = torch.sigmoid(torch.nn.functional.linear(x[:, -1:], wb, bb))
+        ref = O.residual_gate(x[:, 1:-1], wg, bg, 1.0, sbias, thr)
+        assert (mask.cpu() - ref).abs().max() < 1e-6
+        if sbias == 0.0:
+            assert (ref == 0).any() and torch.equal(mask.cpu() == 0, ref == 0)
+        m = mask.cpu()
+        exp = torch.cat([x[:, :1], m * x[:, 1:-1], x[:, -1:]], dim=1)
+        assert torch.equal(xo.cpu(), exp)
+        assert torch.equal(rs.cpu(), torch.cat([torch.ones(B, 1), m[..., 0], torch.ones(B, 1)], dim=1))
