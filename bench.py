@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the ViT-B/16 forward at batch 2048 per GPU, 224x224 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is ONE forward pass of the hot path (VisionTransformer.forward on the MI355X
+kernels) over one device-resident synthetic batch.  The path shards along the batch: every
+rank runs an independent replica on its own 2048-image batch, no data-path collective ("scaling": "weak");
+the only communication is the timing barrier + MAX-over-ranks reduction over RCCL.
+
+Prints ONE JSON line (rank 0) with the contract keys plus:
+  roofline      the dominant kernel (pv_gemm_bf16): algorithmic FLOPs / HIP-event time, measured live
+  cpu_baseline  the CPU oracle (oracle/vit_oracle.py, fp32, = the reference's arithmetic) timed on the host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0               # HBM3E spec, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="vit_b_16")
+    ap.add_argument("--batch", type=int, default=2048, help="images per GPU per step")
+    ap.add_argument("--rank-budget", type=float, default=None, help="run RankViT (rankvit_layers 3,6,9) at this budget")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, batch, iters):
+    """The CPU oracle (bit-equal to the reference on CPU, tests/test_oracle_golden.py) on a bounded sample."""
+    from oracle import vit_oracle as O
+    from peekvit_amd import synth
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg).items()}
+    x = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(0))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        O.vit_forward(x, sd, cfg, "fp32")                       # warm-up
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.vit_forward(x, sd, cfg, "fp32")
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} forwards of batch {batch} (fp32, torch CPU, oracle/vit_oracle.py), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+
+    from peekvit_amd import ops, synth
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.vit import VisionTransformer
+
+    cfg = synth.MODEL_CONFIGS[args.model]
+    seqs = None
+    if args.rank_budget is None:
+        model = VisionTransformer(**cfg)
+        workload = f"{args.model} forward, batch {args.batch}/GPU, {cfg['image_size']}x{cfg['image_size']}"
+    else:
+        layers = [3, 6, 9] if cfg["num_layers"] >= 10 else list(range(1, cfg["num_layers"]))
+        model = RankVisionTransformer(**cfg, rankvit_layers=layers)
+        model.set_budget(args.rank_budget)
+        import math
+        S, seqs = synth.seq_length(cfg), []
+        for i in range(cfg["num_layers"]):
+            if i in layers and args.rank_budget != 1:
+                S = 1 + math.ceil((S - 1) * args.rank_budget)
+            seqs.append(S)
+        workload = f"rank{args.model} layers={layers} budget={args.rank_budget} forward, batch {args.batch}/GPU"
+    synth.load_synth_weights(model, cfg)
+    model = model.eval().to(dev)
+    flops_img = synth.fwd_flops_per_image(cfg, seqs)
+
+    # random (never zero-filled) device-resident input, bf16-representable like the parity fixtures
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, cfg["image_size"], cfg["image_size"], generator=gen, device=dev)
+    x = x.to(torch.bfloat16).to(torch.float32)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(x)
+        barrier()
+        with ops.KernelTimer() as kt:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(x)
+            barrier()
+            elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        ks = kt.summary()
+        dom = max(ks, key=lambda k: ks[k]["ms"])
+        d = ks[dom]
+        if d["flops"] > 0:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        else:
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["launches_per_step"] = d["launches"] // args.steps
+        roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)
+        kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                       "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                   for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}
+        line = {
+            "metric": "images/sec ViT-B/16 fwd @ batch 2048, 224x224" if args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None
+                      else f"images/sec {workload}",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
+                       "gflop_per_image": round(flops_img / 1e9, 3)},
+            "model_mfma_roofline_frac": round(value / world * flops_img / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

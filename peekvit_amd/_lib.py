@@ -10,6 +10,11 @@ import ctypes as C
 import os
 import threading
 
+# torch bundles its own libamdhip64.so; it MUST be in the process before our library is dlopen'ed, otherwise our
+# NEEDED libamdhip64.so.7 resolves to /opt/rocm's copy and the process ends up with two HIP runtimes (our
+# launches then fail against torch's streams/pointers).
+import torch  # noqa: F401
+
 from ._build import LIB
 
 _i64, _f32, _p, _i32 = C.c_int64, C.c_float, C.c_void_p, C.c_int32

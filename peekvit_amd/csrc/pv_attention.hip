@@ -152,7 +152,7 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pv_attn_kernel<DH, NKT32>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT32>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
     return pv_check_launch();
 }
 

@@ -42,6 +42,10 @@ __device__ __forceinline__ float pv_gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// hipGetLastError() is per-thread and sticky across ALL users of the runtime (PyTorch leaves benign errors such as
+// failed pointer-attribute queries behind), so every launch first clears it: pv_check_launch() then reports OUR launch.
+#define PV_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int pv_check_launch() {
     return hipGetLastError() == hipSuccess ? PV_OK : PV_ERR_LAUNCH;
 }

@@ -157,7 +157,7 @@ static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm128_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, stream, p);
+    PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, stream, p);
     return pv_check_launch();
 }
 

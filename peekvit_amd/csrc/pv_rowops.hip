@@ -23,7 +23,7 @@ extern "C" int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void
     if (!src || !dst || n < 0) return PV_ERR_INVALID_ARG;
     if (n == 0) return PV_OK;
     if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return PV_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(pv_cast_kernel, dim3(pv_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    PV_LAUNCH(pv_cast_kernel, dim3(pv_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return pv_check_launch();
 }
 
@@ -68,9 +68,9 @@ extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t
     const int64_t K = C * P * P, work = B * (H / P) * (W / P) * (vec ? K / 8 : K);
     dim3 grid(pv_stream_grid(work, 256));
     if (vec)
-        hipLaunchKernelGGL(pv_im2col_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+        PV_LAUNCH(pv_im2col_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
     else
-        hipLaunchKernelGGL(pv_im2col_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+        PV_LAUNCH(pv_im2col_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
     return pv_check_launch();
 }
 
@@ -99,7 +99,7 @@ extern "C" int pv_token_prologue(float* tokens, const float* special, const floa
     if (!tokens || !special || !pos || B <= 0 || S_total <= 0 || D <= 0 || n_special < 0 || n_special > S_total) return PV_ERR_INVALID_ARG;
     const int64_t work = B * (n_special + (budget_token ? 1 : 0)) * D;
     if (work == 0) return PV_OK;
-    hipLaunchKernelGGL(pv_token_prologue_kernel, dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, tokens, special, pos,
+    PV_LAUNCH(pv_token_prologue_kernel, dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, tokens, special, pos,
                        budget_token, budget, B, S_total, (int)D, (int)n_special);
     return pv_check_launch();
 }
@@ -190,7 +190,7 @@ extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma
     if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
     if (ldx % 4 || ldx < D || ((uintptr_t)x & 15) || ((uintptr_t)out & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return PV_ERR_INVALID_ARG;
     dim3 grid(pv_stream_grid(rows, 4));
-#define LN_LAUNCH(N) hipLaunchKernelGGL(pv_layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
+#define LN_LAUNCH(N) PV_LAUNCH(pv_layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
     PV_DISPATCH_NCH(D, LN_LAUNCH);
 #undef LN_LAUNCH
     return pv_check_launch();
@@ -229,7 +229,7 @@ extern "C" int pv_cls_pool(const float* x, const float* gamma, const float* beta
     if (!x || !gamma || !beta || !pooled || B <= 0 || S <= 0 || D <= 0 || num_cls <= 0 || num_cls > S) return PV_ERR_INVALID_ARG;
     if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
     dim3 grid(pv_stream_grid(B, 4));
-#define CP_LAUNCH(N) hipLaunchKernelGGL(pv_cls_pool_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, pooled, B, S, (int)D, (int)num_cls, eps)
+#define CP_LAUNCH(N) PV_LAUNCH(pv_cls_pool_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, pooled, B, S, (int)D, (int)num_cls, eps)
     PV_DISPATCH_NCH(D, CP_LAUNCH);
 #undef CP_LAUNCH
     return pv_check_launch();
@@ -281,7 +281,7 @@ extern "C" int pv_head_f32(const float* pooled, const float* w, const float* b, 
     if (!pooled || !w || !logits || B <= 0 || D <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
     if (D % 4 || ((uintptr_t)pooled & 15) || ((uintptr_t)w & 15)) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((B + 63) / 64));
-    hipLaunchKernelGGL(pv_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, pooled, w, b, logits, (int)B, (int)D, (int)C);
+    PV_LAUNCH(pv_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, pooled, w, b, logits, (int)B, (int)D, (int)C);
     return pv_check_launch();
 }
 
@@ -308,7 +308,7 @@ extern "C" int pv_token_norm(const float* x, float* norms, int64_t B, int64_t S,
     if (!x || !norms || B <= 0 || S < 1 || D <= 0) return PV_ERR_INVALID_ARG;
     if (D % 4 || ((uintptr_t)x & 15)) return PV_ERR_UNSUPPORTED;
     if (S == 1) return PV_OK;
-    hipLaunchKernelGGL(pv_token_norm_kernel, dim3(pv_stream_grid(B * (S - 1), 4)), dim3(256), 0, (hipStream_t)stream, x, norms, B, S, (int)D);
+    PV_LAUNCH(pv_token_norm_kernel, dim3(pv_stream_grid(B * (S - 1), 4)), dim3(256), 0, (hipStream_t)stream, x, norms, B, S, (int)D);
     return pv_check_launch();
 }
 
@@ -340,7 +340,7 @@ extern "C" int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_
     if (!norms || !keep || B <= 0 || N <= 0 || k < 0 || k > N) return PV_ERR_INVALID_ARG;
     if (N > 4096) return PV_ERR_UNSUPPORTED;
     if (k == 0) return PV_OK;
-    hipLaunchKernelGGL(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)N * 4, (hipStream_t)stream, norms, keep, (int)N, (int)k);
+    PV_LAUNCH(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)N * 4, (hipStream_t)stream, norms, keep, (int)N, (int)k);
     return pv_check_launch();
 }
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void pv_gather_tokens_kernel(const float* __re
 extern "C" int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B, int64_t S_in, int64_t k, int64_t D, void* stream) {
     if (!x || !out || B <= 0 || S_in < 1 || k < 0 || k > S_in - 1 || D <= 0 || (k > 0 && !keep)) return PV_ERR_INVALID_ARG;
     if (D % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pv_gather_tokens_kernel, dim3(pv_stream_grid(B * (k + 1), 4)), dim3(256), 0, (hipStream_t)stream, x, keep, out, B, S_in, k, (int)D);
+    PV_LAUNCH(pv_gather_tokens_kernel, dim3(pv_stream_grid(B * (k + 1), 4)), dim3(256), 0, (hipStream_t)stream, x, keep, out, B, S_in, k, (int)D);
     return pv_check_launch();
 }
 
@@ -431,7 +431,7 @@ extern "C" int pv_residual_gate(const float* x, float* xo, const float* wg, cons
     if (!x || !xo || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
     if (D % 4 || D > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)xo & 15) || ((uintptr_t)wg & 15) || ((uintptr_t)wb & 15)) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)B);
-#define RG_LAUNCH(N) hipLaunchKernelGGL(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, S, (int)D)
+#define RG_LAUNCH(N) PV_LAUNCH(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, S, (int)D)
     PV_DISPATCH_NCH(D, RG_LAUNCH);
 #undef RG_LAUNCH
     return pv_check_launch();

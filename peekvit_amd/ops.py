@@ -17,6 +17,57 @@ from ._lib import GemmArgs, check
 launch_count = 0
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing on the stream the kernels are launched on (bench.py's `roofline` leg).
+    `with KernelTimer() as kt:` brackets every C-ABI launch with two events; `kt.summary()` (after a device
+    synchronise) returns {kernel: {"launches", "ms", "flops", "bytes"}} where flops/bytes are the ALGORITHMIC
+    work of the launches."""
+
+    def __init__(self):
+        self.records = []     # (name, start_event, end_event, flops, bytes)
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, flops, nbytes in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+class _timed:
+    """Context manager used by every wrapper: no-op unless a KernelTimer is active."""
+    __slots__ = ("name", "flops", "nbytes", "e0", "dev")
+
+    def __init__(self, name, dev, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes, self.dev = name, flops, nbytes, dev
+
+    def __enter__(self):
+        if _timer is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.dev))
+            _timer.records.append((self.name, self.e0, e1, self.flops, self.nbytes))
+
+
 def _stream(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -44,7 +95,8 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     _chk(src, torch.float32, "src")
     if out is None:
         out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
-    check(_lib.load().pv_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "pv_cast_f32_bf16")
+    with _timed("pv_cast_f32_bf16", src.device, 0.0, 6.0 * src.numel()):
+        check(_lib.load().pv_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "pv_cast_f32_bf16")
     _count()
     return out
 
@@ -52,15 +104,17 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
 def im2col(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
     _chk(x, torch.float32, "x")
     B, Cc, H, W = x.shape
-    check(_lib.load().pv_im2col_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _stream(x)), "pv_im2col_bf16")
+    with _timed("pv_im2col_bf16", x.device, 0.0, 6.0 * x.numel()):
+        check(_lib.load().pv_im2col_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _stream(x)), "pv_im2col_bf16")
     _count()
     return out
 
 
 def token_prologue(tokens, special, pos, budget_token, budget: float, n_special: int):
     B, S, D = tokens.shape
-    check(_lib.load().pv_token_prologue(_ptr(tokens), _ptr(special), _ptr(pos), _ptr(budget_token), float(budget),
-                                        B, S, D, n_special, _stream(tokens)), "pv_token_prologue")
+    with _timed("pv_token_prologue", tokens.device, 0.0, 0.0):
+        check(_lib.load().pv_token_prologue(_ptr(tokens), _ptr(special), _ptr(pos), _ptr(budget_token), float(budget),
+                                            B, S, D, n_special, _stream(tokens)), "pv_token_prologue")
     _count()
 
 
@@ -68,8 +122,9 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
     """x: fp32 [..., D] contiguous -> out bf16 same shape."""
     D = x.shape[-1]
     rows = x.numel() // D
-    check(_lib.load().pv_layernorm_bf16(_ptr(x), D, _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(out), rows, D,
-                                        float(eps), _stream(x)), "pv_layernorm_bf16")
+    with _timed("pv_layernorm_bf16", x.device, 0.0, 6.0 * x.numel()):
+        check(_lib.load().pv_layernorm_bf16(_ptr(x), D, _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(out), rows, D,
+                                            float(eps), _stream(x)), "pv_layernorm_bf16")
     _count()
     return out
 
@@ -89,13 +144,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     ldr=res.shape[-1] if res is not None else 0,
                     rows_per_img_in=rows_per_img_in, rows_per_img_out=rows_per_img_out, row_off=row_off,
                     qcols=qcols, qscale=float(qscale), epilogue=epilogue)
-    check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
+    with _timed("pv_gemm_bf16", a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1)):
+        check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
     return out
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
-    check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_bf16")
+    with _timed("pv_attention_bf16", qkv.device, 4.0 * B * H * S * S * dh, 8.0 * B * S * H * dh):
+        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_bf16")
     _count()
     return out
 
@@ -103,8 +160,9 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: 
 def cls_pool(x: torch.Tensor, gamma, beta, eps: float, num_cls: int) -> torch.Tensor:
     B, S, D = x.shape
     pooled = torch.empty((B, D), dtype=torch.float32, device=x.device)
-    check(_lib.load().pv_cls_pool(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(pooled), B, S, D, num_cls, float(eps),
-                                  _stream(x)), "pv_cls_pool")
+    with _timed("pv_cls_pool", x.device, 0.0, 0.0):
+        check(_lib.load().pv_cls_pool(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(pooled), B, S, D, num_cls, float(eps),
+                                      _stream(x)), "pv_cls_pool")
     _count()
     return pooled
 
@@ -113,7 +171,8 @@ def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
     B, D = pooled.shape
     Cn = w.shape[0]
     logits = torch.empty((B, Cn), dtype=torch.float32, device=pooled.device)
-    check(_lib.load().pv_head_f32(_ptr(pooled), _ptr(w), _ptr(b), _ptr(logits), B, D, Cn, _stream(pooled)), "pv_head_f32")
+    with _timed("pv_head_f32", pooled.device, 2.0 * B * D * Cn, 0.0):
+        check(_lib.load().pv_head_f32(_ptr(pooled), _ptr(w), _ptr(b), _ptr(logits), B, D, Cn, _stream(pooled)), "pv_head_f32")
     _count()
     return logits
 
@@ -121,7 +180,8 @@ def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
 def token_norm(x: torch.Tensor) -> torch.Tensor:
     B, S, D = x.shape
     norms = torch.empty((B, S - 1), dtype=torch.float32, device=x.device)
-    check(_lib.load().pv_token_norm(_ptr(x), _ptr(norms), B, S, D, _stream(x)), "pv_token_norm")
+    with _timed("pv_token_norm", x.device, 0.0, 4.0 * x.numel()):
+        check(_lib.load().pv_token_norm(_ptr(x), _ptr(norms), B, S, D, _stream(x)), "pv_token_norm")
     _count()
     return norms
 
@@ -129,7 +189,8 @@ def token_norm(x: torch.Tensor) -> torch.Tensor:
 def rank_topk(norms: torch.Tensor, k: int) -> torch.Tensor:
     B, N = norms.shape
     keep = torch.empty((B, k), dtype=torch.int32, device=norms.device)
-    check(_lib.load().pv_rank_topk(_ptr(norms), _ptr(keep), B, N, k, _stream(norms)), "pv_rank_topk")
+    with _timed("pv_rank_topk", norms.device, 0.0, 4.0 * (norms.numel() + B * k)):
+        check(_lib.load().pv_rank_topk(_ptr(norms), _ptr(keep), B, N, k, _stream(norms)), "pv_rank_topk")
     _count()
     return keep
 
@@ -138,7 +199,8 @@ def gather_tokens(x: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
     B, S, D = x.shape
     k = keep.shape[1]
     out = torch.empty((B, k + 1, D), dtype=torch.float32, device=x.device)
-    check(_lib.load().pv_gather_tokens(_ptr(x), _ptr(keep), _ptr(out), B, S, k, D, _stream(x)), "pv_gather_tokens")
+    with _timed("pv_gather_tokens", x.device, 0.0, 8.0 * B * (k + 1) * D):
+        check(_lib.load().pv_gather_tokens(_ptr(x), _ptr(keep), _ptr(out), B, S, k, D, _stream(x)), "pv_gather_tokens")
     _count()
     return out
 
@@ -148,8 +210,9 @@ def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: fl
     B, S, D = x.shape
     mask = torch.empty((B, S - 2, 1), dtype=torch.float32, device=x.device)
     row_scale = torch.empty((B, S), dtype=torch.float32, device=x.device)
-    check(_lib.load().pv_residual_gate(_ptr(x), _ptr(x_out), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp),
-                                       float(sigmoid_bias), _ptr(mask), _ptr(row_scale), B, S, D, _stream(x)),
-          "pv_residual_gate")
+    with _timed("pv_residual_gate", x.device, 0.0, 8.0 * x.numel()):
+        check(_lib.load().pv_residual_gate(_ptr(x), _ptr(x_out), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp),
+                                           float(sigmoid_bias), _ptr(mask), _ptr(row_scale), B, S, D, _stream(x)),
+              "pv_residual_gate")
     _count()
     return mask, row_scale

@@ -13,12 +13,17 @@ from peekvit_amd import synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# tolerances (relative L2 of logits).  TOL_SAME: HIP vs oracle with identical rounding points - residual
-# differences are fp32 summation order / exp ulps amplified by bf16 re-rounding.  TOL_FP32: HIP (bf16 MFMA
-# operands, fp32 accumulate, fp32 residual stream) vs the fp32 reference; the survey measured 3.6e-3..4.8e-3
-# for this arithmetic at random init, BASELINE's 1e-3 needs split-precision operands.
-TOL_SAME = 2e-3
-TOL_FP32 = 1.2e-2
+# Tolerances (relative L2).
+# TOL_BLOCK: ONE block on IDENTICAL inputs, HIP vs the oracle's same-rounding-points mode: only fp32 summation
+#   order / exp ulps differ, re-rounded to bf16 a few times (measured 4e-5..7e-5 over all rows).
+# TOL_E2E: whole-model logits.  bf16 MFMA operands + fp32 accumulate + fp32 residual stream is measured at
+#   4.3e-3 (ViT-B/16) .. 7e-3 (vit_tiny) against the fp32 reference at random init - the same as the CPU
+#   oracle's bf16 mode (4.1e-3 .. 7e-3, SURVEY 7 H1 predicted 3.6e-3..4.8e-3).  Logits depend on the CLS row only,
+#   whose norm is ~15x smaller than patch rows, so bf16 rounding noise decorrelates between two bf16
+#   implementations: HIP-vs-oracle(bf16) is no tighter than HIP-vs-fp32.  BASELINE's 1e-3 needs split-precision
+#   operands.
+TOL_BLOCK = 3e-4
+TOL_E2E = 1.2e-2
 
 
 def _model(kind, name, **extra):
@@ -47,8 +52,8 @@ def test_vit_forward_parity(golden, name):
     assert ops.launch_count - n0 >= 4 + 7 * cfg["num_layers"], "the HIP kernels did not run"
     sd = synth.synth_state_dict(cfg)
     same = O.vit_forward(x, sd, cfg, "bf16").numpy()
-    assert rel_l2(logits, same) < TOL_SAME
-    assert rel_l2(logits, golden(name)["logits"]) < TOL_FP32
+    assert rel_l2(logits, same) < TOL_E2E
+    assert rel_l2(logits, golden(name)["logits"]) < TOL_E2E          # vs the REAL reference's fp32 logits
 
 
 def test_vit_micro_per_block_activations(golden):
@@ -71,7 +76,7 @@ def test_block_level_standalone_and_surgery():
     with torch.no_grad():
         y = m.encoder.layers[0](x.to(DEV)).cpu()
     ref = O.vit_block(x, synth.synth_state_dict(cfg), "encoder.layers.0.", cfg["num_heads"], 1e-5, "bf16")
-    assert rel_l2(y.numpy(), ref.numpy()) < 1e-3
+    assert rel_l2(y.numpy(), ref.numpy()) < TOL_BLOCK
     m.remove_layers([1])
     assert len(m.encoder.layers) == 1
     with torch.no_grad():
@@ -103,7 +108,7 @@ def test_rankvit_parity(golden, name, layers, b):
     m.set_budget(1.0)
     with torch.no_grad():
         full = m(x.to(DEV)).cpu().numpy()
-    assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_FP32
+    assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_E2E
 
 
 @pytest.mark.parametrize("tag,name,gb", [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_micro", 0), ("vit_b_16", "vit_b_16", 10)])
@@ -120,10 +125,10 @@ def test_residualvit_parity(golden, tag, name, gb):
         masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
         tr = {}
         same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "bf16", trace=tr).numpy()
-        assert rel_l2(logits, same) < 3e-3
+        assert rel_l2(logits, same) < TOL_E2E
         assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
         assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
-        assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_FP32 * 2
+        assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_E2E
 
 
 def test_error_contract_matches_reference():
@@ -169,3 +174,21 @@ def test_full_batch_properties_vit_b_16():
     with torch.no_grad():
         lp = m(big[perm].to(DEV)).cpu()
     assert torch.equal(lp, lb[perm])                                   # permuting images permutes logits
+
+
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_small", "vit_b_16"])
+def test_every_block_on_identical_inputs(name):
+    """Each encoder block of the real configs, fed the ORACLE's input, against the oracle's same-rounding-points
+    output: isolates kernel correctness from the chaotic e2e accumulation (all rows, and the CLS row alone)."""
+    cfg, m = _model("vit", name)
+    sd = synth.synth_state_dict(cfg)
+    x = _x(cfg)
+    t = O.embed_tokens(x, sd, cfg, "bf16") + torch.from_numpy(sd["encoder.pos_embedding"])
+    with torch.no_grad():
+        from peekvit_amd import engine
+        assert rel_l2(engine.embed_tokens(m, x.to(DEV)).cpu().numpy(), t.numpy()) < 1e-6
+        for i, blk in enumerate(m.encoder.layers):
+            ref = O.vit_block(t, sd, f"encoder.layers.{i}.", cfg["num_heads"], 1e-5, "bf16")
+            got = blk(t.to(DEV)).cpu()
+            assert rel_l2(got.numpy(), ref.numpy()) < TOL_BLOCK, i
+            t = ref
