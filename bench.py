@@ -51,7 +51,12 @@ def cpu_baseline(cfg, batch, iters):
     from peekvit_amd import synth
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg).items()}
     x = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(0))
-    cores = os.cpu_count() or 1
+    # the GPU box gives one-GPU jobs a 16-CPU share of a 256-thread host: size the pool to the share, not the host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("PV_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     with torch.no_grad():
         O.vit_forward(x, sd, cfg, "fp32")                       # warm-up

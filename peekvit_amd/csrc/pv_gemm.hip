@@ -7,6 +7,8 @@
 // accumulator registers are four CONSECUTIVE output columns of one output row: the epilogue then loads
 // bias/residual and stores the result with 8-byte (bf16) / 16-byte (fp32) vector accesses.
 #include "pv_common.h"
+#include <type_traits>
+#include <cstdlib>
 
 struct GemmDev {
     const uint16_t* A;
@@ -35,10 +37,9 @@ __device__ __forceinline__ int pv_xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int EPI>
-__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc) {
-    if (m >= p.M || n >= p.N) return;
-    float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+template <int EPI, bool GUARD = true>
+__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc, float4 b) {
+    if (GUARD && (m >= p.M || n >= p.N)) return;
     float v0 = acc[0] + b.x, v1 = acc[1] + b.y, v2 = acc[2] + b.z, v3 = acc[3] + b.w;
     if (EPI == PV_EPI_BIAS_BF16) {
         const float s = n < p.qcols ? p.qscale : 1.0f;
@@ -143,10 +144,21 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p) {
     // ---- epilogue: lane holds out[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3] ---------------------------------
     const int em = m0 + wm * 64 + (lane & 15);
     const int en = n0 + wn * 64 + ((lane >> 4) << 2);
+    float4 bias4[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int nt = 0; nt < 4; ++nt)
+        bias4[nt] = (p.bias && en + nt * 16 < p.N) ? *reinterpret_cast<const float4*>(p.bias + en + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + G1_BM <= p.M && n0 + G1_BN <= p.N) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI>(p, em + mt * 16, en + nt * 16, acc[nt][mt]);
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+    }
 }
 
 template <int EPI>
@@ -158,6 +170,205 @@ static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
         attr_set = true;
     }
     PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, stream, p);
+    return pv_check_launch();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 M x 4 N, 128 x 64 outputs per wave = 128 accumulator VGPRs), 128 KiB LDS,
+// one workgroup per CU.  Deep pipeline in plain HIP: LDS-DMA stays in flight ACROSS raw s_barriers behind a
+// counted s_waitcnt vmcnt (never 0 in the loop); the two wave groups (waves 0-3 / 4-7 = the two waves of every
+// SIMD) run staggered by one barrier, so in every barrier interval one wave per SIMD issues its 16 MFMAs while its
+// partner issues the next phase's ds_reads and LDS-DMA.
+//
+// LDS: 2 buffers (K-tile parity) x 4 half-tile slots {A0, A1, B0, B1} of 128 rows x 64 k (16 KiB, swizzled as
+// above).  Per K-tile t (buffer t&1) a wave runs 4 phases, each = [load interval | barrier | MFMA interval | barrier]:
+//   P1: read A(m0) 8x b128 + B(n0) 4x   MFMA (m0,n0)     stage B0(t+1)
+//   P2: read A(m1) 8x                   MFMA (m1,n0)     stage B1(t+1)
+//   P3: read B(n1) 4x                   MFMA (m1,n1)     stage A0(t+2)      (A slots: last read in P2)
+//   P4: -                               MFMA (m0,n1)     stage A1(t+2), s_waitcnt vmcnt(4)
+// Hazards (q = phase index, group g in {0,1} loads in interval 2q+g, every wave drains lgkmcnt BEFORE the barrier
+// that ends its load interval):
+//   WAR  a slot last read in phase q is free from interval 2q+2 on -> restaging in phase q+1 is safe for both groups;
+//   RAW  vmcnt(4) in P4 retires everything but the two youngest half-tiles (A0/A1 of t+2): all of tile t+1 has
+//        landed for THIS thread; after one more barrier pair it has for every thread -> first read in P1 of t+1.
+// ------------------------------------------------------------------------------------------------
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
+constexpr int G2_HALF = 128 * G2_BK * 2;     // 16 KiB half-tile slot
+constexpr int G2_BUF = 4 * G2_HALF;          // 64 KiB per K-tile buffer
+constexpr int G2_LDS = 2 * G2_BUF;           // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+    // ---- LDS-DMA sources: per half-tile two 1-KiB pieces per wave (rows j*64 + wid*8 + lane/8), swizzled chunk ----
+    const int srow = wid * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((lane >> 3) & 7);
+    // block-uniform bases (SGPR pairs) + per-lane 32-bit byte offsets: keeps the 8 DMA sources in 8 VGPRs
+    const char* const a_blk = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
+    const char* const w_blk = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    uint32_t oa[2][2], ow[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ra = h * 128 + j * 64 + srow; ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            int rw = h * 128 + j * 64 + srow; rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+            oa[h][j] = (uint32_t)(ra * (int)p.lda + schunk * 8) * 2u;
+            ow[h][j] = (uint32_t)(rw * (int)p.ldw + schunk * 8) * 2u;
+        }
+    char* const lds_piece = smem + wid * 1024;       // + slot + j * 8192
+    auto stage_a = [&](int buf, int h, int kt) {
+        const char* src = a_blk + kt * (G2_BK * 2);
+        pv_glds16(src + oa[h][0], lds_piece + buf * G2_BUF + h * G2_HALF);
+        pv_glds16(src + oa[h][1], lds_piece + buf * G2_BUF + h * G2_HALF + 8192);
+    };
+    auto stage_b = [&](int buf, int h, int kt) {
+        const char* src = w_blk + kt * (G2_BK * 2);
+        pv_glds16(src + ow[h][0], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF);
+        pv_glds16(src + ow[h][1], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF + 8192);
+    };
+
+    // ---- fragment read addresses: one LDS-address-space base per (buffer, k-step), every read = base + immediate ----
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    const int frow = (lane & 15) * 128;
+    const int fx0 = ((lane >> 4) ^ (lane & 7)) << 4;
+    lds_cc* const lds0 = (lds_cc*)smem;
+    lds_cc* a_rd[2][2];   // [buf][ks]
+    lds_cc* b_rd[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_rd[b][ks] = lds0 + b * G2_BUF + wr * G2_HALF + frow + (fx0 ^ (ks << 6));
+            b_rd[b][ks] = lds0 + b * G2_BUF + (2 + (wc >> 1)) * G2_HALF + (wc & 1) * 8192 + frow + (fx0 ^ (ks << 6));
+            asm volatile("" : "+v"(a_rd[b][ks]));   // opaque: keep these 8 bases in VGPRs, never re-derive per read
+            asm volatile("" : "+v"(b_rd[b][ks]));
+        }
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][4][2];   // [m half][mt][ks]
+    bf16x8 bfr[2][2];     // [nt][ks] of the CURRENT n half (n0 lives P1-P2, n1 lives P3-P4: one register set)
+
+#define G2_READ_A(BUF, MH)                                                                                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)  \
+        af[MH][t_][ks_] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a_rd[BUF][ks_] + ((MH) * 4 + t_) * 2048);
+#define G2_READ_B(BUF, NH)                                                                                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)  \
+        bfr[t_][ks_] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(b_rd[BUF][ks_] + ((NH) * 2 + t_) * 2048);
+#define G2_SYNC_LOADS()                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);
+#define G2_MFMA(MH, NH)                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)            \
+        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                            \
+            acc[(NH) * 2 + n_][(MH) * 4 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+                bfr[n_][ks_], af[MH][m_][ks_], acc[(NH) * 2 + n_][(MH) * 4 + m_], 0, 0, 0);                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one K-tile.  SB: stage the B halves of tile kt+1 (P1,P2).  SA: stage the A halves of tile kt+2 (P3,P4); without
+    // SA the youngest loads in flight are B(kt+1) themselves, so P4 must drain (vmcnt(0)) instead of vmcnt(4).
+    auto ktile = [&](auto buf_c, auto sb_c, auto sa_c, int kt) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool SB = decltype(sb_c)::value, SA = decltype(sa_c)::value;
+        // P1
+        G2_READ_B(BUF, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        G2_READ_A(BUF, 0)
+        if (SB) stage_b(BUF ^ 1, 0, kt + 1);
+        G2_SYNC_LOADS()
+        G2_MFMA(0, 0)
+        // P2
+        G2_READ_A(BUF, 1)
+        if (SB) stage_b(BUF ^ 1, 1, kt + 1);
+        G2_SYNC_LOADS()
+        G2_MFMA(1, 0)
+        // P3
+        G2_READ_B(BUF, 1)
+        if (SA) stage_a(BUF, 0, kt + 2);
+        G2_SYNC_LOADS()
+        G2_MFMA(1, 1)
+        // P4
+        if (SA) {
+            stage_a(BUF, 1, kt + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G2_SYNC_LOADS()
+        G2_MFMA(0, 1)
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
+    const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
+    stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
+    stage_a(1, 0, 1); stage_a(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier interval behind group 0
+
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 2) {              // tiles with kt+2 < nk: full staging
+        ktile(B0{}, T{}, T{}, kt);
+        ktile(B1{}, T{}, T{}, kt + 1);
+    }
+    ktile(B0{}, T{}, F{}, kt);                   // tile nk-2: only B(nk-1) left to stage, then drain
+    ktile(B1{}, F{}, F{}, kt + 1);               // tile nk-1
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
+#undef G2_READ_A
+#undef G2_READ_B
+#undef G2_SYNC_LOADS
+#undef G2_MFMA
+
+    const int em = m0 + wr * 128 + (lane & 15);
+    const int en = n0 + wc * 64 + ((lane >> 4) << 2);
+    float4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        bias4[nt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + en + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);   // N % 256 == 0 here
+    if (m0 + G2_BM <= p.M) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+    }
+}
+
+template <int EPI>
+static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), G2_LDS, stream, p);
     return pv_check_launch();
 }
 
@@ -173,19 +384,23 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
     p.rpi = (int)a->rows_per_img_in; p.rpo = (int)a->rows_per_img_out; p.row_off = (int)a->row_off;
     p.qcols = (int)a->qcols; p.qscale = a->qscale;
-    p.tiles_m = (p.M + G1_BM - 1) / G1_BM; p.tiles_n = (p.N + G1_BN - 1) / G1_BN;
-    if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (a->epilogue == PV_EPI_BIAS_RES_F32 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15))) return PV_ERR_INVALID_ARG;
+    if (a->epilogue == PV_EPI_BIAS_POS_F32 &&
+        (!a->pos || a->rows_per_img_in <= 0 || a->rows_per_img_out < a->rows_per_img_in + a->row_off || a->row_off < 0 || ((uintptr_t)a->pos & 15)))
+        return PV_ERR_INVALID_ARG;
+    // kernel choice: the deep-pipelined 256^2 tile for the big token GEMMs, the 128^2 tile for everything else
+    static const int force = [] { const char* e = getenv("PV_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const bool big = force == 256 || (force != 128 && p.N % G2_BN == 0 && p.K % (2 * G2_BK) == 0 && p.M >= 2048);
+    if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+    const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
+    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
+    if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     switch (a->epilogue) {
-        case PV_EPI_BIAS_BF16: return pv_launch_gemm128<PV_EPI_BIAS_BF16>(p, s);
-        case PV_EPI_BIAS_GELU_BF16: return pv_launch_gemm128<PV_EPI_BIAS_GELU_BF16>(p, s);
-        case PV_EPI_BIAS_RES_F32:
-            if (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15)) return PV_ERR_INVALID_ARG;
-            return pv_launch_gemm128<PV_EPI_BIAS_RES_F32>(p, s);
-        case PV_EPI_BIAS_POS_F32:
-            if (!a->pos || a->rows_per_img_in <= 0 || a->rows_per_img_out < a->rows_per_img_in + a->row_off || a->row_off < 0 || ((uintptr_t)a->pos & 15))
-                return PV_ERR_INVALID_ARG;
-            return pv_launch_gemm128<PV_EPI_BIAS_POS_F32>(p, s);
+        case PV_EPI_BIAS_BF16: return big ? pv_launch_gemm256<PV_EPI_BIAS_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_BF16>(p, s);
+        case PV_EPI_BIAS_GELU_BF16: return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_BF16>(p, s);
+        case PV_EPI_BIAS_RES_F32: return big ? pv_launch_gemm256<PV_EPI_BIAS_RES_F32>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_RES_F32>(p, s);
+        case PV_EPI_BIAS_POS_F32: return big ? pv_launch_gemm256<PV_EPI_BIAS_POS_F32>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_POS_F32>(p, s);
         default: return PV_ERR_INVALID_ARG;
     }
 }

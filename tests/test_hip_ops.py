@@ -63,7 +63,9 @@ def test_layernorm(ops, rows, D):
         assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
 
 
-GEMM_SHAPES = [(100, 128, 64), (256, 256, 128), (300, 384, 192), (197 * 2, 2304, 768), (130, 768, 3072), (77, 1000, 256)]
+# the last four shapes (M >= 2048, N % 256 == 0, K % 128 == 0) run the 256x256 deep-pipelined kernel, incl. a ragged M edge
+GEMM_SHAPES = [(100, 128, 64), (256, 256, 128), (300, 384, 192), (197 * 2, 2304, 768), (130, 768, 3072), (77, 1000, 256),
+               (2048, 256, 128), (2304 + 37, 768, 768), (2048, 2304, 256), (2100, 768, 3072)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
