@@ -23,7 +23,25 @@ struct GemmDev {
     int rpi, rpo, row_off, qcols;
     float qscale;
     int tiles_m, tiles_n;
+#ifdef PV_STAMPS
+    unsigned long long* dbg;   // diagnostic build only: per-block s_memtime stamps (never read by any kernel)
+#endif
 };
+
+#ifdef PV_STAMPS
+static unsigned long long* g_pv_dbg = nullptr;
+extern "C" void pv_debug_set_stamp_buffer(void* p) { g_pv_dbg = (unsigned long long*)p; }
+#define PV_STAMP(i)                                                                                  \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        unsigned long long t_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 8 + (i)] = t_;                    \
+    } while (0)
+#else
+#define PV_STAMP(i)
+#endif
 
 __device__ __forceinline__ void pv_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -37,21 +55,23 @@ __device__ __forceinline__ int pv_xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+// Per-lane epilogue of the 128^2 kernel.  `acc` already contains the bias (accumulators are INITIALISED with it, in both
+// kernels, so that an output element is rounded identically whichever kernel/tile computes it: batch invariance).
 template <int EPI, bool GUARD = true>
-__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc, float4 b) {
+__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
-    float v0 = acc[0] + b.x, v1 = acc[1] + b.y, v2 = acc[2] + b.z, v3 = acc[3] + b.w;
+    const float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
     if (EPI == PV_EPI_BIAS_BF16) {
         const float s = n < p.qcols ? p.qscale : 1.0f;
         u32x2 o = {pv_pack_bf16x2(v0 * s, v1 * s), pv_pack_bf16x2(v2 * s, v3 * s)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_GELU_BF16) {
-        u32x2 o = {pv_pack_bf16x2(pv_gelu_erf(v0), pv_gelu_erf(v1)), pv_pack_bf16x2(pv_gelu_erf(v2), pv_gelu_erf(v3))};
+        u32x2 o = {pv_pack_bf16x2(pv_gelu_fast(v0), pv_gelu_fast(v1)), pv_pack_bf16x2(pv_gelu_fast(v2), pv_gelu_fast(v3))};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
         const float s = p.row_scale ? p.row_scale[m] : 1.0f;
         float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.ldr + n);
-        float4 o = make_float4(r.x + s * v0, r.y + s * v1, r.z + s * v2, r.w + s * v3);
+        float4 o = make_float4(fmaf(s, v0, r.x), fmaf(s, v1, r.y), fmaf(s, v2, r.z), fmaf(s, v3, r.w));
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else {   // PV_EPI_BIAS_POS_F32
         const int img = m / p.rpi, pi = m - img * p.rpi;
@@ -107,11 +127,15 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p) {
     const int a_off = (wm * 64 + frow) * 128;                    // activation rows of this wave
     const int w_off = (wn * 64 + frow) * 128;                    // weight rows of this wave
 
-    f32x4 acc[4][4];   // [nt][mt]
+    const int en = n0 + wn * 64 + ((lane >> 4) << 2);
+    f32x4 acc[4][4];   // [nt][mt], initialised with the bias of the lane's 4 columns
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && en + i * 16 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + en + i * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = b4;
+    }
 
     const int nk = p.K / G1_BK;
     stage(0, 0);
@@ -143,21 +167,16 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p) {
 
     // ---- epilogue: lane holds out[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3] ---------------------------------
     const int em = m0 + wm * 64 + (lane & 15);
-    const int en = n0 + wn * 64 + ((lane >> 4) << 2);
-    float4 bias4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-        bias4[nt] = (p.bias && en + nt * 16 < p.N) ? *reinterpret_cast<const float4*>(p.bias + en + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (m0 + G1_BM <= p.M && n0 + G1_BN <= p.N) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt]);
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt]);
     }
 }
 
@@ -172,7 +191,6 @@ static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
     PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, stream, p);
     return pv_check_launch();
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves (2 M x 4 N, 128 x 64 outputs per wave = 128 accumulator VGPRs), 128 KiB LDS,
@@ -221,7 +239,11 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int ra = h * 128 + j * 64 + srow; ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
-            int rw = h * 128 + j * 64 + srow; rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+            // LDS row q of every aligned 32-row block holds W row perm(q) = ((q&15)>>2)*8 + (q>>4)*4 + (q&3): with the
+            // MFMA C layout (row = 4*(lane>>4)+reg) a lane then owns 8 CONSECUTIVE output columns per tile pair.
+            const int q = j * 64 + srow;
+            int rw = h * 128 + (q & ~31) + (((q & 15) >> 2) << 3) + (((q >> 4) & 1) << 2) + (q & 3);
+            rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
             oa[h][j] = (uint32_t)(ra * (int)p.lda + schunk * 8) * 2u;
             ow[h][j] = (uint32_t)(rw * (int)p.ldw + schunk * 8) * 2u;
         }
@@ -254,11 +276,16 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
             asm volatile("" : "+v"(b_rd[b][ks]));
         }
 
+    // accumulators start from the bias: lane (g = lane>>4) owns columns en0 + (nt>>1)*32 + g*8 + (nt&1)*4 + 0..3 of tile nt
+    const int en0 = n0 + wc * 64 + ((lane >> 4) << 3);
     f32x4 acc[4][8];   // [nt][mt]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + en0 + (i >> 1) * 32 + (i & 1) * 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) acc[i][j] = b4;
+    }
     bf16x8 af[2][4][2];   // [m half][mt][ks]
     bf16x8 bfr[2][2];     // [nt][ks] of the CURRENT n half (n0 lives P1-P2, n1 lives P3-P4: one register set)
 
@@ -322,11 +349,13 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
 
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
+    PV_STAMP(0);
     stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
     stage_a(1, 0, 1); stage_a(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PV_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier interval behind group 0
 
     int kt = 0;
@@ -337,28 +366,100 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
     ktile(B0{}, T{}, F{}, kt);                   // tile nk-2: only B(nk-1) left to stage, then drain
     ktile(B1{}, F{}, F{}, kt + 1);               // tile nk-1
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
+    PV_STAMP(2);
 #undef G2_READ_A
 #undef G2_READ_B
 #undef G2_SYNC_LOADS
 #undef G2_MFMA
 
-    const int em = m0 + wr * 128 + (lane & 15);
-    const int en = n0 + wc * 64 + ((lane >> 4) << 2);
-    float4 bias4[4];
+    // ---- epilogue: transpose the C tile through LDS (the staging buffers are free now) so that every global access is a
+    // whole contiguous row segment: one wave-instruction = 1 KiB of one (fp32) or two (bf16) output rows ------------
+    typedef __attribute__((address_space(3))) char lds_c;
+    lds_c* const cimg = (lds_c*)smem;
+    const int g = lane >> 4, i16 = lane & 15;
+    if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) {
+        // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7)
+        const float qs = (EPI == PV_EPI_BIAS_BF16 && n0 < p.qcols) ? p.qscale : 1.0f;     // tile-uniform (qcols % 256 == 0 checked on host)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-        bias4[nt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + en + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);   // N % 256 == 0 here
-    if (m0 + G2_BM <= p.M) {
+        for (int mt = 0; mt < 8; ++mt) {
+            const int row = wr * 128 + mt * 16 + i16;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+            for (int u = 0; u < 2; ++u) {
+                f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
+                u32x4 pk;
+                if (EPI == PV_EPI_BIAS_GELU_BF16) {
+                    pk = (u32x4){pv_pack_bf16x2(pv_gelu_fast(lo[0]), pv_gelu_fast(lo[1])), pv_pack_bf16x2(pv_gelu_fast(lo[2]), pv_gelu_fast(lo[3])),
+                                 pv_pack_bf16x2(pv_gelu_fast(hi[0]), pv_gelu_fast(hi[1])), pv_pack_bf16x2(pv_gelu_fast(hi[2]), pv_gelu_fast(hi[3]))};
+                } else {
+                    pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
+                                 pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
+                }
+                const int c = wc * 8 + u * 4 + g;
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+        for (int j = 0; j < 16; ++j) {
+            const int row = wid * 32 + 2 * j + (lane >> 5);
+            const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
+            if (m0 + row < p.M) *reinterpret_cast<u32x4*>(ob + (int64_t)(m0 + row) * p.ldo) = v;
+        }
     } else {
+        // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int ps = 0; ps < 2; ++ps) {
+            // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
+            f32x4 rr[16];
+            int64_t orow[16];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], bias4[nt]);
+            for (int j = 0; j < 16; ++j) {
+                int m = m0 + ps * 128 + wid * 16 + j;
+                m = m < p.M ? m : p.M - 1;
+                if (EPI == PV_EPI_BIAS_RES_F32) {
+                    orow[j] = m;
+                    rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n0 + lane * 4);
+                } else {
+                    const int img = m / p.rpi, pi = m - img * p.rpi;
+                    orow[j] = (int64_t)img * p.rpo + p.row_off + pi;
+                    rr[j] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + n0 + lane * 4);
+                }
+            }
+            if (ps == 1) __builtin_amdgcn_s_barrier();      // pass 0's image has been consumed by every wave
+            if (wr == ps) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int row = mt * 16 + i16;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = wc * 16 + (nt >> 1) * 8 + g * 2 + (nt & 1);
+                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = wid * 16 + j;
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((lane ^ (row & 7)) << 4));
+                float sc = 1.0f;
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) sc = p.row_scale[orow[j]];
+                f32x4 o;
+                if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
+                else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
+                if (m0 + ps * 128 + row < p.M)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + n0 + lane * 4) = o;
+            }
+        }
     }
+    PV_STAMP(3);
+#ifdef PV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PV_STAMP(4);
+#endif
 }
 
 template <int EPI>
@@ -384,6 +485,9 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
     p.rpi = (int)a->rows_per_img_in; p.rpo = (int)a->rows_per_img_out; p.row_off = (int)a->row_off;
     p.qcols = (int)a->qcols; p.qscale = a->qscale;
+#ifdef PV_STAMPS
+    p.dbg = g_pv_dbg;
+#endif
     hipStream_t s = (hipStream_t)stream;
     if (a->epilogue == PV_EPI_BIAS_RES_F32 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15))) return PV_ERR_INVALID_ARG;
     if (a->epilogue == PV_EPI_BIAS_POS_F32 &&
@@ -391,8 +495,10 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
         return PV_ERR_INVALID_ARG;
     // kernel choice: the deep-pipelined 256^2 tile for the big token GEMMs, the 128^2 tile for everything else
     static const int force = [] { const char* e = getenv("PV_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    const bool big = force == 256 || (force != 128 && p.N % G2_BN == 0 && p.K % (2 * G2_BK) == 0 && p.M >= 2048);
+    const bool big = force == 256 || (force != 128 && p.N % G2_BN == 0 && p.K % (2 * G2_BK) == 0 && p.M >= 2048 &&
+                                      !(a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN));
     if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+    if (big && a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN) return PV_ERR_UNSUPPORTED;   // q-scale is tile-uniform there
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;

@@ -1,0 +1,36 @@
+"""Diagnostic: build a -DPV_STAMPS copy of the GEMM and print where a tile's cycles go (prologue / K-loop / epilogue issue / store drain)."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from peekvit_amd._lib import GemmArgs
+so = os.path.join(ROOT, "gpurun_out", "libpv_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPV_STAMPS",
+                       os.path.join(ROOT, "peekvit_amd/csrc/pv_gemm.hip"), "-o", so])
+lib = C.CDLL(so)
+lib.pv_gemm_bf16.argtypes = [C.POINTER(GemmArgs), C.c_void_p]; lib.pv_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+dev = "cuda:0"; M = int(os.environ.get("M", 403456))
+g = torch.Generator(device=dev).manual_seed(0)
+for name, N, K, epi in [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]:
+    a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device=dev)
+    out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev) if epi == 2 else None
+    nblk = ((M + 255) // 256) * (N // 256)
+    dbg = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+    lib.pv_debug_set_stamp_buffer(dbg.data_ptr())
+    args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
+                    row_scale=0, pos=0, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, rows_per_img_in=0, rows_per_img_out=0, row_off=0,
+                    qcols=0, qscale=1.0, epilogue=epi)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        assert lib.pv_gemm_bf16(C.byref(args), st) == 0
+    torch.cuda.synchronize()
+    d = dbg.view(nblk, 8).cpu().double()
+    seg = lambda i, j: (d[:, j] - d[:, i])
+    tot = seg(0, 4)
+    print(f"{name}: blocks {nblk}  (s_memtime ticks, median per block) prologue {seg(0,1).median():.0f}  kloop {seg(1,2).median():.0f} "
+          f"({seg(1,2).median() / (K // 64):.0f}/ktile)  epilogue-issue {seg(2,3).median():.0f}  store-drain {seg(3,4).median():.0f}  total {tot.median():.0f}"
+          f"   span first-start..last-end {(d[:,4].max() - d[:,0].min()):.0f}")
