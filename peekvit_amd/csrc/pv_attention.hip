@@ -26,49 +26,64 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     constexpr int NKT = NKT32 * 2;      // 16-key tiles
     constexpr int SP = NKT32 * 32;      // padded key count
     constexpr int NDT = DH / 16;        // 16-wide output d tiles
+    constexpr int NCH = SP * CPR;       // 16-byte chunks per K (or V) image
+    constexpr int NIT = (NCH + 255) / 256;
+    constexpr int MAXQT = (NKT + 3) / 4;   // q tiles per wave (4 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + SP * DHP * 2;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * DH;
     const int64_t ld = 3 * (int64_t)D;
     const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
 
-    // ---- stage K and V (register staged, zero padded) --------------------------------------------------------
-    for (int L = tid; L < SP * CPR; L += 256) {
-        const int row = L / CPR, c = L - row * CPR;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (row < S && c * 8 < DH) {
+    // ---- stage K and V by LDS-DMA, every piece issued up front (one wait for the whole head) ----------------------
+    // physical chunk P (lane-linear LDS destination) holds logical chunk L = swizzle(P); rows >= S duplicate row S-1:
+    // their scores are masked to -inf below and P = 0 multiplies the (finite) duplicate V rows.
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int P = it * 256 + tid;
+        if (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) {
+            const int L = (P & ~7) | ((P & 7) ^ ((P >> 3) & 7));
+            int row = L / CPR, c = L - row * CPR;
+            row = row < S ? row : S - 1;
+            if (c * 8 >= DH) c = 0;        // DH = 48: the pad chunks only ever meet zero Q columns / unused d tiles
             const uint16_t* src = qb + (int64_t)row * ld + c * 8;
-            kv = *reinterpret_cast<const u32x4*>(src + D);
-            vv = *reinterpret_cast<const u32x4*>(src + 2 * D);
+            char* dst = (it * 256 + wid * 64) * 16 + (char*)nullptr;   // wave-uniform byte offset
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + D),
+                                             (__attribute__((address_space(3))) void*)(Ks + (size_t)dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * D),
+                                             (__attribute__((address_space(3))) void*)(Vs + (size_t)dst), 16, 0, 0);
         }
-        const int line = L >> 3, pos = L & 7;
-        const int dst = ((line << 3) + (pos ^ (line & 7))) << 4;
-        *reinterpret_cast<u32x4*>(Ks + dst) = kv;
-        *reinterpret_cast<u32x4*>(Vs + dst) = vv;
     }
+    // ---- Q^T fragments of every q tile of this wave (B operand): lane (g,i16) holds Q[q0+i16][ks*32 + 8g .. +8] -------
+    const int nqt = (S + 15) >> 4;
+    bf16x8 qf[MAXQT][KS];
+#pragma unroll
+    for (int t = 0; t < MAXQT; ++t) {
+        int qr = (wid + 4 * t) * 16 + i16;
+        qr = qr < S ? qr : S - 1;
+        const uint16_t* qp = qb + (int64_t)qr * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dcol = ks * 32 + 8 * g;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (dcol < DH) v = *reinterpret_cast<const u32x4*>(qp + dcol);
+            qf[t][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nqt = (S + 15) >> 4;
-    for (int qt = wid; qt < nqt; qt += 4) {
-        const int q0 = qt << 4;
-        // ---- Q^T fragments (B operand): lane (g,i16) holds Q[q0+i16][ks*32 + 8g .. +8] -----------------------
-        bf16x8 qf[KS];
-        {
-            int qr = q0 + i16; qr = qr < S ? qr : S - 1;
-            const uint16_t* qp = qb + (int64_t)qr * ld;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int dcol = ks * 32 + 8 * g;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (dcol < DH) v = *reinterpret_cast<const u32x4*>(qp + dcol);
-                qf[ks] = __builtin_bit_cast(bf16x8, v);
-            }
-        }
+    for (int t = 0; t < MAXQT; ++t) {
+        const int qt = wid + 4 * t;
+        if (qt >= nqt) break;
+        const int q0 = qt << 4;
         // ---- S^T tiles: sc[kt][r] = score(query q0+i16, key kt*16 + 4g + r) -----------------------------------
         f32x4 sc[NKT];
 #pragma unroll
@@ -77,18 +92,16 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + pv_swz<CPR>(kt * 16 + i16, ks * 4 + g));
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], a, 0, 0, 0);
             }
             sc[kt] = a;
         }
-        // mask padded keys (only the last tiles can contain them)
+        // mask padded keys: SP - 32 < S <= SP, so only the last two 16-key tiles can hold them
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if ((kt + 1) * 16 > S) {
+        for (int kt = (NKT >= 2 ? NKT - 2 : 0); kt < NKT; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
-            }
+            for (int r = 0; r < 4; ++r)
+                if (kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
         }
         // ---- softmax numerator: in-lane over 4*NKT keys, then across the 4 lane groups ------------------------
         float m = -INFINITY;
@@ -114,11 +127,11 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int tq = i16 >> 2, tp = i16 & 3;
 #pragma unroll
-        for (int t = 0; t < NKT32; ++t) {
-            u32x4 pw = {pv_pack_bf16x2(sc[2 * t][0], sc[2 * t][1]), pv_pack_bf16x2(sc[2 * t][2], sc[2 * t][3]),
-                        pv_pack_bf16x2(sc[2 * t + 1][0], sc[2 * t + 1][1]), pv_pack_bf16x2(sc[2 * t + 1][2], sc[2 * t + 1][3])};
+        for (int tt = 0; tt < NKT32; ++tt) {
+            u32x4 pw = {pv_pack_bf16x2(sc[2 * tt][0], sc[2 * tt][1]), pv_pack_bf16x2(sc[2 * tt][2], sc[2 * tt][3]),
+                        pv_pack_bf16x2(sc[2 * tt + 1][0], sc[2 * tt + 1][1]), pv_pack_bf16x2(sc[2 * tt + 1][2], sc[2 * tt + 1][3])};
             const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-            const int r0 = 32 * t + 4 * g + tq;
+            const int r0 = 32 * tt + 4 * g + tq;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 const int c = dt * 2 + (tp >> 1), sub = (tp & 1) << 3;
