@@ -19,8 +19,12 @@ __device__ __forceinline__ uint16_t pv_f2bf(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float pv_f32x2_t;
+// two fp32 -> one dword of two bf16 (lo in bits 0-15): a vector convert lowers to ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
-    return (uint32_t)pv_f2bf(lo) | ((uint32_t)pv_f2bf(hi) << 16);
+    const pv_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float pv_bf2f(uint16_t b) {
     return __builtin_bit_cast(float, (uint32_t)b << 16);
@@ -58,8 +62,28 @@ __device__ __forceinline__ float pv_gelu_fast(float x) {
     poly = fmaf(t, poly, 1.421413741f);
     poly = fmaf(t, poly, -0.284496736f);
     poly = fmaf(t, poly, 0.254829592f);
-    const float h = 0.5f * (poly * t) * e;                          // 0.5 * erfc(|x|/sqrt2)
+    const float h = (poly * t) * 0.5f * e;                          // 0.5 * erfc(|x|/sqrt2)
     return x * (x < 0.f ? h : 1.0f - h);
+}
+
+// two GELUs at once on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 issue one instruction for two lanes-values): same
+// arithmetic per element as pv_gelu_fast, bit-identical results (packed ops round each half like their scalar forms).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 pv_gelu_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 d = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 u = x * 0.84932180028801904f;
+    const f32x2 nu2 = -(u * u);
+    const f32x2 e = {__builtin_amdgcn_exp2f(nu2[0]), __builtin_amdgcn_exp2f(nu2[1])};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 h = (poly * t) * 0.5f * e;
+    const f32x2 phi = {x[0] < 0.f ? h[0] : 1.0f - h[0], x[1] < 0.f ? h[1] : 1.0f - h[1]};
+    return x * phi;
 }
 
 static inline int pv_check_launch() {

@@ -388,8 +388,9 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
                 f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
                 u32x4 pk;
                 if (EPI == PV_EPI_BIAS_GELU_BF16) {
-                    pk = (u32x4){pv_pack_bf16x2(pv_gelu_fast(lo[0]), pv_gelu_fast(lo[1])), pv_pack_bf16x2(pv_gelu_fast(lo[2]), pv_gelu_fast(lo[3])),
-                                 pv_pack_bf16x2(pv_gelu_fast(hi[0]), pv_gelu_fast(hi[1])), pv_pack_bf16x2(pv_gelu_fast(hi[2]), pv_gelu_fast(hi[3]))};
+                    const f32x2 g0 = pv_gelu_fast2((f32x2){lo[0], lo[1]}), g1 = pv_gelu_fast2((f32x2){lo[2], lo[3]});
+                    const f32x2 g2 = pv_gelu_fast2((f32x2){hi[0], hi[1]}), g3 = pv_gelu_fast2((f32x2){hi[2], hi[3]});
+                    pk = (u32x4){pv_pack_bf16x2(g0[0], g0[1]), pv_pack_bf16x2(g1[0], g1[1]), pv_pack_bf16x2(g2[0], g2[1]), pv_pack_bf16x2(g3[0], g3[1])};
                 } else {
                     pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
                                  pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
