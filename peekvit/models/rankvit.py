@@ -1,0 +1,4 @@
+from peekvit_amd.models.rankvit import *  # noqa: F401,F403
+from peekvit_amd.models import rankvit as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

@@ -1,0 +1,80 @@
+"""Data-parallel plumbing for the hot path: one process per GPU, torch.distributed over
+RCCL ("nccl" backend on ROCm) - or gloo on CPU for tests.
+
+The forward shards along the batch with NO data-path collective (every image is independent: no BatchNorm, no
+cross-sample op in models/vit.py / rankvit.py / residualvit.py), so inference is "replicas only": rank r runs
+samples r::world of the global batch and, if the caller wants the global logits, one small all-gather
+([B/world, C] per rank) rebuilds them in the original order.
+
+Training has ONE real exchange step, the gradient all-reduce (the reference has no distributed code at all;
+train/train.py:118-122 does backward -> clip_grad_norm_ -> step on one device).  `allreduce_gradients` does it in
+~25 MB flat buckets (fewer, larger collectives: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so ring
+collectives are per-link bound and small messages are latency bound) and returns once every bucket is reduced, so
+the global-norm clip that follows sees fully reduced gradients.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as td
+
+
+def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    """Samples rank::world of a global batch (the partition SURVEY.md section 8e prescribes)."""
+    rank = td.get_rank() if rank is None else rank
+    world = td.get_world_size() if world is None else world
+    return x[rank::world].contiguous()
+
+
+def gather_logits(local: torch.Tensor, global_batch: int) -> torch.Tensor:
+    """All-gather per-rank logits [ceil-ish(B/world), C] back into global order [B, C] (inverse of shard_batch)."""
+    world, rank = td.get_world_size(), td.get_rank()
+    per = (global_batch + world - 1) // world
+    pad = local.new_zeros((per, local.shape[1]))
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    td.all_gather(parts, pad)
+    out = local.new_empty((global_batch, local.shape[1]))
+    for r, p in enumerate(parts):
+        n = len(range(r, global_batch, world))
+        out[r::world] = p[:n]
+    return out
+
+
+@torch.no_grad()
+def sharded_forward(model: torch.nn.Module, x_global: torch.Tensor, gather: bool = True) -> torch.Tensor:
+    """Batch-sharded inference: local forward on this rank's shard (+ optional logits all-gather)."""
+    local = model(shard_batch(x_global))
+    return gather_logits(local, x_global.shape[0]) if gather else local
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True) -> int:
+    """Bucketed gradient all-reduce (sum, then / world).  Buckets are filled in REVERSE parameter order - the order
+    in which backward produces gradients - launched asynchronously and awaited together.  Returns the bucket count."""
+    world = td.get_world_size()
+    grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
+    buckets: List[List[torch.Tensor]] = [[]]
+    size = 0
+    for g in grads:
+        nbytes = g.numel() * g.element_size()
+        if buckets[-1] and size + nbytes > bucket_bytes:
+            buckets.append([])
+            size = 0
+        buckets[-1].append(g)
+        size += nbytes
+    work = []
+    for b in buckets:
+        if not b:
+            continue
+        flat = torch.cat([g.reshape(-1) for g in b])
+        work.append((td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True), flat, b))
+    for handle, flat, b in work:
+        handle.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for g in b:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return len(work)

@@ -1,0 +1,163 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/peekvit_hip.h declares, the module
+surface keeps the reference's constructor / state-dict / error / attribute contract, the stock-op composite path
+(CPU tensors) reproduces the reference's golden logits bit-for-bit, and the YAML `_target_` strings resolve."""
+import importlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, rel_l2
+from peekvit_amd import synth
+
+
+def test_library_exports_every_declared_symbol():
+    from peekvit_amd import _lib
+    header = open(os.path.join(REPO, "include", "peekvit_hip.h")).read()
+    declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
+    assert lib.pv_version() == 1 and lib.pv_arch() == b"gfx950"
+    assert b"launch" in lib.pv_error_string(-3)
+
+
+def test_gemm_args_struct_matches_header_layout():
+    import ctypes as C
+    from peekvit_amd._lib import GemmArgs
+    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4
+    assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from peekvit_amd import ops
+    from peekvit_amd._lib import PeekvitHipError
+    with pytest.raises(PeekvitHipError):
+        ops.cast_bf16(torch.zeros(8))                   # CPU tensor: no silent fallback
+
+
+@pytest.mark.parametrize("target", ["peekvit.models.vit.VisionTransformer", "peekvit.models.rankvit.RankVisionTransformer",
+                                    "peekvit.models.residualvit.ResidualVisionTransformer"])
+def test_hydra_targets_resolve(target):
+    mod, cls = target.rsplit(".", 1)
+    assert hasattr(importlib.import_module(mod), cls)
+
+
+def _models():
+    from peekvit_amd.models.vit import VisionTransformer
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    return VisionTransformer, RankVisionTransformer, ResidualVisionTransformer
+
+
+def test_state_dict_contract_matches_reference():
+    VT, RVT, ResVT = _models()
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))["state_dict"]
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    shapes = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert shapes(VT(**cfg)) == meta["vit_micro"]
+    assert shapes(RVT(**cfg, rankvit_layers=[0, 1])) == meta["rankvit_micro"]
+    assert shapes(ResVT(**cfg, gate_type="sigmoid", add_budget_token="learnable")) == meta["residualvit_micro"]
+    # the synthetic generator covers exactly the same keys
+    assert set(synth.synth_state_dict(cfg)) == set(meta["vit_micro"])
+
+
+def test_error_contract_matches_reference_on_cpu():
+    VT, RVT, ResVT = _models()
+    err = json.load(open(os.path.join(GOLDEN, "meta.json")))["errors"]
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    m = VT(**cfg).eval()
+    cases = {
+        "wrong_height": lambda: m(torch.zeros(1, 3, 40, 32)),
+        "wrong_width": lambda: m(torch.zeros(1, 3, 32, 40)),
+        "indivisible": lambda: VT(**dict(cfg, image_size=30)),
+        "block_rank": lambda: m.encoder.layers[0](torch.zeros(4, 4)),
+        "rank_registers": lambda: RVT(**cfg, num_registers=2, rankvit_layers=[0]),
+        "rank_none_layers": lambda: RVT(**cfg),
+        "residual_gate_type": lambda: ResVT(**cfg, gate_type="nope"),
+        "residual_gumbel_threshold": lambda: ResVT(**cfg, gate_type="gumbel", gate_threshold=0.3),
+        "residual_set_budget_training": lambda: ResVT(**cfg, gate_type="sigmoid").train().set_budget(0.5),
+        "residual_no_budget_eval": lambda: ResVT(**cfg, gate_type="sigmoid", add_budget_token="learnable").eval()(torch.zeros(1, 3, 32, 32)),
+    }
+    for key, fn in cases.items():
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == err[key]["type"], key
+        assert str(ei.value) == err[key]["message"], key
+
+
+def test_composite_path_matches_reference_golden(golden):
+    """CPU tensors take the stock-op composite: it must reproduce the REAL reference's fp32 logits."""
+    VT, RVT, ResVT = _models()
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"]))
+    m = VT(**cfg).eval()
+    synth.load_synth_weights(m, cfg)
+    with torch.no_grad():
+        assert rel_l2(m(x).numpy(), golden("vit_micro")["logits"]) < 1e-6
+    r = RVT(**cfg, rankvit_layers=[0, 1]).eval()
+    synth.load_synth_weights(r, cfg)
+    for b in (0.5, 0.25, 1.0):
+        r.set_budget(b)
+        with torch.no_grad():
+            assert rel_l2(r(x).numpy(), golden("rankvit")[f"vit_micro_b{b}_logits"]) < 1e-6
+    assert r.current_budget == 1.0 and r.encoder.layers[0].current_budget == 1.0
+    extra = dict(gate_type="sigmoid", gate_bias=0, gate_temp=1, add_budget_token="learnable")
+    rs = ResVT(**cfg, **extra).eval()
+    synth.load_synth_weights(rs, dict(cfg, **extra), "residualvit")
+    for b in (0.2, 0.5):
+        rs.set_budget(b)
+        with torch.no_grad():
+            out = rs(x)
+        assert rel_l2(out.numpy(), golden("residualvit")[f"vit_micro_gb0_b{b}_logits"]) < 1e-5
+        masks = torch.stack([blk.mask for blk in rs.encoder.layers]).numpy()
+        assert np.abs(masks - golden("residualvit")[f"vit_micro_gb0_b{b}_masks"]).max() < 1e-6
+
+
+def test_attribute_surface_and_surgery():
+    VT, RVT, ResVT = _models()
+    from peekvit_amd.models.residualvit import ResidualModule
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    m = VT(**cfg, num_registers=2, num_class_tokens=2)
+    for attr in ("num_classes", "patch_size", "num_class_tokens", "num_registers", "hidden_dim", "seq_length"):
+        assert hasattr(m, attr)
+    assert m.seq_length == 16 + 2 + 2 and isinstance(m.encoder.layers, torch.nn.Sequential)
+    with torch.no_grad():
+        assert m.eval()(torch.zeros(1, 3, 32, 32)).shape == (1, 10)
+    m2 = VT(**cfg, remove_layers=[0])
+    assert len(m2.encoder.layers) == 1
+    rs = ResVT(**cfg, gate_type="sigmoid", add_budget_token="learnable")
+    assert all(isinstance(b, ResidualModule) for b in rs.encoder.layers) and rs.num_budget_tokens == 1
+    names = [n for n, _ in rs.named_parameters()]
+    assert any("gate" in n for n in names) and any("budget" in n for n in names) and any("class" in n for n in names)
+
+
+def test_adapters_rename_onto_reference_keys():
+    from peekvit_amd.models.adapters import adapt_timm_state_dict, adapt_torch_state_dict
+    VT, _, _ = _models()
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    ref = VT(**cfg).state_dict()
+    tv = {}
+    for k, v in ref.items():
+        k2 = k.replace("class_tokens", "class_token").replace("head.", "heads.head.")
+        k2 = re.sub(r"encoder\.layers\.(\d+)\.self_attention\.self_attention\.", r"encoder.layers.encoder_layer_\1.self_attention.", k2)
+        k2 = re.sub(r"encoder\.layers\.(\d+)\.mlp\.fc1\.", r"encoder.layers.encoder_layer_\1.mlp.linear_1.", k2)
+        k2 = re.sub(r"encoder\.layers\.(\d+)\.mlp\.fc2\.", r"encoder.layers.encoder_layer_\1.mlp.linear_2.", k2)
+        k2 = re.sub(r"encoder\.layers\.(\d+)\.ln_", r"encoder.layers.encoder_layer_\1.ln_", k2)
+        tv[k2] = v
+    assert set(adapt_torch_state_dict(tv, num_classes=10)) == set(ref)
+    assert "head.weight" not in adapt_torch_state_dict(tv, num_classes=1000)
+    timm = {"cls_token": ref["class_tokens"], "pos_embed": ref["encoder.pos_embedding"], "patch_embed.proj.weight": ref["conv_proj.weight"],
+            "blocks.0.attn.qkv.weight": ref["encoder.layers.0.self_attention.self_attention.in_proj_weight"],
+            "blocks.1.mlp.fc2.bias": ref["encoder.layers.1.mlp.fc2.bias"], "norm.weight": ref["encoder.ln.weight"]}
+    got = adapt_timm_state_dict(timm, num_classes=10)
+    assert set(got) <= set(ref) and len(got) == len(timm)
+
+
+def test_flop_model_matches_baseline_table():
+    f = lambda n, **kw: synth.fwd_flops_per_image(synth.MODEL_CONFIGS[n], **kw) / 1e9
+    assert abs(f("vit_tiny") - 2.800) < 2e-3 and abs(f("vit_small") - 6.171) < 2e-3 and abs(f("vit_b_16") - 35.128) < 2e-3
+    seqs = [197] * 3 + [99] * 3 + [50] * 3 + [26] * 3
+    assert abs(f("vit_b_16", seq_per_layer=seqs) - 16.508) < 5e-3
