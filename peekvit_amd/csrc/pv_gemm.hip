@@ -474,6 +474,7 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     return pv_check_launch();
 }
 
+
 extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->out || a->M <= 0 || a->N <= 0 || a->K <= 0) return PV_ERR_INVALID_ARG;
     if (a->K % 64 || a->N % 4) return PV_ERR_UNSUPPORTED;

@@ -65,7 +65,8 @@ def test_layernorm(ops, rows, D):
 
 # the last four shapes (M >= 2048, N % 256 == 0, K % 128 == 0) run the 256x256 deep-pipelined kernel, incl. a ragged M edge
 GEMM_SHAPES = [(100, 128, 64), (256, 256, 128), (300, 384, 192), (197 * 2, 2304, 768), (130, 768, 3072), (77, 1000, 256),
-               (2048, 256, 128), (2304 + 37, 768, 768), (2048, 2304, 256), (2100, 768, 3072)]
+               (2048, 256, 128), (2304 + 37, 768, 768), (2048, 2304, 256), (2100, 768, 3072),
+               (2048, 768, 768), (4096 + 128, 2304, 768), (2048 + 384, 768, 3072), (2560, 3072, 768), (66 * 128, 256, 1536)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -111,6 +112,42 @@ def test_gemm_patch_embed_epilogue(ops):
     got = out.cpu()
     assert rel_l2(got[:, off:off + Np], ref) < 2e-6
     assert torch.all(got[:, :off] == 7.0) and torch.all(got[:, off + Np:] == 7.0)   # untouched rows
+
+
+def test_gemm_patch_embed_epilogue_big_kernel(ops):
+    """Same epilogue at a shape the 256^2 kernel takes (M = B*Np >= 2048, K = 768), row remap across images."""
+    from peekvit_amd._lib import PV_EPI_BIAS_POS_F32
+    B, Np, S, D, K, off = 32, 196, 199, 256, 768, 2
+    a, w = T("ppa", (B * Np, K)), T("ppw", (D, K), "uniform", 0.04)
+    bias, pos = T("ppb", (D,), "uniform", 0.1), T("ppp", (S, D), scale=0.02)
+    out = torch.full((B, S, D), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(bf(a), bf(w), bias.to(DEV), out.view(B * S, D), PV_EPI_BIAS_POS_F32, pos=pos.to(DEV),
+             rows_per_img_in=Np, rows_per_img_out=S, row_off=off)
+    ref = (a.double() @ w.double().t() + bias.double()).view(B, Np, D) + pos.double()[off:off + Np]
+    got = out.cpu()
+    assert rel_l2(got[:, off:off + Np], ref) < 2e-6
+    assert torch.all(got[:, :off] == 7.0) and torch.all(got[:, off + Np:] == 7.0)
+
+
+def test_gemm_kernels_agree_bitwise(ops):
+    """An output element is rounded identically by the 128^2 and 256^2 kernels (batch invariance relies on it)."""
+    import os, subprocess, sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); from peekvit_amd import ops, synth\n"
+        "from peekvit_amd._lib import PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32\n"
+        "g = torch.Generator(device='cuda').manual_seed(5)\n"
+        "a = torch.randn(2048, 768, generator=g, device='cuda').bfloat16(); w = (torch.randn(768, 768, generator=g, device='cuda') / 28).bfloat16()\n"
+        "b = torch.randn(768, generator=g, device='cuda'); r = torch.randn(2048, 768, generator=g, device='cuda')\n"
+        "o1 = torch.empty(2048, 768, device='cuda'); ops.gemm(a, w, b, o1, PV_EPI_BIAS_RES_F32, res=r)\n"
+        "o2 = torch.empty(2048, 768, dtype=torch.bfloat16, device='cuda'); ops.gemm(a, w, b, o2, PV_EPI_BIAS_GELU_BF16)\n"
+        "torch.save((o1.cpu(), o2.cpu()), sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tile in ("128", "256"):
+        path = f"/tmp/pv_gemm_tile_{tile}.pt"
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, PV_GEMM_TILE=tile))
+        outs.append(torch.load(path))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
 def test_gemm_rejects_bad_shapes(ops):
