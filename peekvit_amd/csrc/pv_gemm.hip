@@ -7,8 +7,23 @@
 // accumulator registers are four CONSECUTIVE output columns of one output row: the epilogue then loads
 // bias/residual and stores the result with 8-byte (bf16) / 16-byte (fp32) vector accesses.
 #include "pv_common.h"
+#include "pv_gelu_table.h"
 #include <type_traits>
 #include <cstdlib>
+
+// exact-erf GELU by table: Phi(x) linearly interpolated from 4096 samples on [-8, 8) (pv_gelu_table.h; |error| <= 5e-7, the
+// same class as torch's fp32 F.gelu).  ~7 VALU + one 8-byte gather per value instead of ~20 issue slots for the erfc
+// polynomial (rcp + exp).  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2 kernel), so both
+// kernels round an element identically.
+template <typename TabPtr>
+__device__ __forceinline__ float pv_gelu_lut(float x, TabPtr tab) {
+    float t = fmaf(x, 256.0f, 2048.0f);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, 4095.9998f);
+    const int i = (int)t;
+    const float fr = t - (float)i;
+    const pv_f32x2_t e = tab[i];
+    return x * fmaf(fr, e[1], e[0]);
+}
 
 struct GemmDev {
     const uint16_t* A;
@@ -23,6 +38,7 @@ struct GemmDev {
     int rpi, rpo, row_off, qcols;
     float qscale;
     int tiles_m, tiles_n;
+    int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
 #ifdef PV_STAMPS
     unsigned long long* dbg;   // diagnostic build only: per-block s_memtime stamps (never read by any kernel)
 #endif
@@ -66,7 +82,8 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         u32x2 o = {pv_pack_bf16x2(v0 * s, v1 * s), pv_pack_bf16x2(v2 * s, v3 * s)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_GELU_BF16) {
-        u32x2 o = {pv_pack_bf16x2(pv_gelu_fast(v0), pv_gelu_fast(v1)), pv_pack_bf16x2(pv_gelu_fast(v2), pv_gelu_fast(v3))};
+        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        u32x2 o = {pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
         const float s = p.row_scale ? p.row_scale[m] : 1.0f;
@@ -223,8 +240,12 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
 
+    // tile order: every XCD walks a contiguous range of a list in which groups of `gm` M-blocks are swept with n as the slow
+    // index, so the ~32 co-running blocks of an XCD touch gm A panels and ~32/gm weight tiles at a time (L2 = 4 MiB per XCD)
     const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int grp = tile / (p.gm * p.tiles_n), rem = tile - grp * (p.gm * p.tiles_n);
+    const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
+    const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
     const int m0 = tm * G2_BM, n0 = tn * G2_BN;
 
     // ---- LDS-DMA sources: per half-tile two 1-KiB pieces per wave (rows j*64 + wid*8 + lane/8), swizzled chunk ----
@@ -350,6 +371,13 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
     PV_STAMP(0);
+    if (EPI == PV_EPI_BIAS_GELU_BF16) {
+        // GELU table (32 KiB) into the LDS above the staging buffers: the OLDEST operations of the kernel, so every later
+        // counted wait covers them and nothing else changes
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            pv_glds16(reinterpret_cast<const char*>(pv_gelu_tab) + (i * 512 + tid) * 16, smem + G2_LDS + (i * 512 + wid * 64) * 16);
+    }
     stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
     stage_a(1, 0, 1); stage_a(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -388,9 +416,9 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
                 f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
                 u32x4 pk;
                 if (EPI == PV_EPI_BIAS_GELU_BF16) {
-                    const f32x2 g0 = pv_gelu_fast2((f32x2){lo[0], lo[1]}), g1 = pv_gelu_fast2((f32x2){lo[2], lo[3]});
-                    const f32x2 g2 = pv_gelu_fast2((f32x2){hi[0], hi[1]}), g3 = pv_gelu_fast2((f32x2){hi[2], hi[3]});
-                    pk = (u32x4){pv_pack_bf16x2(g0[0], g0[1]), pv_pack_bf16x2(g1[0], g1[1]), pv_pack_bf16x2(g2[0], g2[1]), pv_pack_bf16x2(g3[0], g3[1])};
+                    const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+                    pk = (u32x4){pv_pack_bf16x2(pv_gelu_lut(lo[0], tab), pv_gelu_lut(lo[1], tab)), pv_pack_bf16x2(pv_gelu_lut(lo[2], tab), pv_gelu_lut(lo[3], tab)),
+                                 pv_pack_bf16x2(pv_gelu_lut(hi[0], tab), pv_gelu_lut(hi[1], tab)), pv_pack_bf16x2(pv_gelu_lut(hi[2], tab), pv_gelu_lut(hi[3], tab))};
                 } else {
                     pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
                                  pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
@@ -466,14 +494,14 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static bool attr_set = false;
+    constexpr int lds = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), G2_LDS, stream, p);
+    PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
     return pv_check_launch();
 }
-
 
 extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->out || a->M <= 0 || a->N <= 0 || a->K <= 0) return PV_ERR_INVALID_ARG;
@@ -501,6 +529,8 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
                                       !(a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN));
     if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
     if (big && a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN) return PV_ERR_UNSUPPORTED;   // q-scale is tile-uniform there
+    static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
+    p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
