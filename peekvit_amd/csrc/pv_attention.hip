@@ -18,13 +18,30 @@ __device__ __forceinline__ int pv_swz(int row, int chunk) {
     return ((line << 3) + (pos ^ (line & 7))) << 4;
 }
 
-template <int DH, int NKT32>
+#ifdef PV_STAMPS
+__device__ unsigned long long* d_pv_adbg;     // diagnostic build only: stamps go to a buffer no kernel reads
+extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_pv_adbg), &p, sizeof(p)); }
+#define PV_ASTAMP(i)                                                                                       \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        unsigned long long t_;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((threadIdx.x & 63) == 0 && d_pv_adbg) d_pv_adbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = t_;   \
+    } while (0)
+#else
+#define PV_ASTAMP(i)
+#endif
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
 __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
-    constexpr int NKT = NKT32 * 2;      // 16-key tiles
-    constexpr int SP = NKT32 * 32;      // padded key count
+    constexpr int NKT32 = NKT / 2;      // full 32-key steps of the PV product (an odd last tile uses the K=16 MFMA)
+    constexpr int SP = NKT * 16;        // padded key count: LDS holds exactly SP rows of K and of V
     constexpr int NDT = DH / 16;        // 16-wide output d tiles
     constexpr int NCH = SP * CPR;       // 16-byte chunks per K (or V) image
     constexpr int NIT = (NCH + 255) / 256;
@@ -37,30 +54,13 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    PV_ASTAMP(0);
     const int D = H * DH;
     const int64_t ld = 3 * (int64_t)D;
     const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
 
-    // ---- stage K and V by LDS-DMA, every piece issued up front (one wait for the whole head) ----------------------
-    // physical chunk P (lane-linear LDS destination) holds logical chunk L = swizzle(P); rows >= S duplicate row S-1:
-    // their scores are masked to -inf below and P = 0 multiplies the (finite) duplicate V rows.
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int P = it * 256 + tid;
-        if (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) {
-            const int L = (P & ~7) | ((P & 7) ^ ((P >> 3) & 7));
-            int row = L / CPR, c = L - row * CPR;
-            row = row < S ? row : S - 1;
-            if (c * 8 >= DH) c = 0;        // DH = 48: the pad chunks only ever meet zero Q columns / unused d tiles
-            const uint16_t* src = qb + (int64_t)row * ld + c * 8;
-            char* dst = (it * 256 + wid * 64) * 16 + (char*)nullptr;   // wave-uniform byte offset
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + D),
-                                             (__attribute__((address_space(3))) void*)(Ks + (size_t)dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * D),
-                                             (__attribute__((address_space(3))) void*)(Vs + (size_t)dst), 16, 0, 0);
-        }
-    }
-    // ---- Q^T fragments of every q tile of this wave (B operand): lane (g,i16) holds Q[q0+i16][ks*32 + 8g .. +8] -------
+    // ---- Q^T fragments of every q tile of this wave (B operand), issued FIRST (needed first):
+    // lane (g,i16) holds Q[q0+i16][ks*32 + 8g .. +8] ---------------------------------------------------------------------
     const int nqt = (S + 15) >> 4;
     bf16x8 qf[MAXQT][KS];
 #pragma unroll
@@ -76,8 +76,74 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
             qf[t][ks] = __builtin_bit_cast(bf16x8, v);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- stage K, then V, by LDS-DMA: every piece issued up front; K is waited for first so QK^T starts under V's flight ----
+    // physical chunk P = it*256 + tid; the swizzle permutes inside a 128-byte line only, so L>>3 = P>>3 and the lane's logical
+    // chunk-in-line (tid&7)^((tid>>3)&7) is the same for every iteration: row = it*(256/CPR) + lane term, c = lane term.
+    // Rows >= S duplicate row S-1: their scores are masked to -inf below and P = 0 multiplies the (finite) duplicate V rows.
+    const int lsw = (tid & 7) ^ ((tid >> 3) & 7);
+    const int r_lane = CPR == 8 ? (tid >> 3) : 2 * (tid >> 3) + (lsw >> 2);
+    int c_lane = CPR == 8 ? lsw : (lsw & 3);
+    if (c_lane * 8 >= DH) c_lane = 0;          // DH = 48: the pad chunks only ever meet zero Q columns / unused d tiles
+    const uint16_t* const kv_src = qb + D + c_lane * 8;
+#pragma unroll
+    for (int kv = 0; kv < 2; ++kv) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) {
+                int row = it * (256 / CPR) + r_lane;
+                row = row < S ? row : S - 1;
+                const uint16_t* src = kv_src + (int64_t)row * ld + kv * D;
+                const size_t dst = (size_t)(it * 256 + wid * 64) * 16;   // wave-uniform byte offset
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)((kv ? Vs : Ks) + dst), 16, 0, 0);
+            }
+        }
+    }
+    // number of V pieces THIS wave issued (the youngest operations): waiting until only they remain retires Q and K
+    int nv = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) nv += (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) ? 1 : 0;
+
+    // ---- LDS read bases: lane-constant swizzle terms hoisted, every read below is base + immediate ------------------------
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    lds_cc* kbase[KS];     // K fragment of key tile kt, k-step ks: kbase[ks] + kt * (16 rows)
+    lds_cc* vbase[NDT];    // V transposed read of key tile kt, d tile dt: vbase[dt] + kt * (16 rows)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kbase[ks] = (lds_cc*)Ks + pv_swz<CPR>(i16, ks * 4 + g);
+        asm volatile("" : "+v"(kbase[ks]));
+    }
+    {
+        const int tq_ = i16 >> 2, tp_ = i16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            vbase[dt] = (lds_cc*)Vs + pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+            asm volatile("" : "+v"(vbase[dt]));
+        }
+    }
+    PV_ASTAMP(1);
+    // K (and Q) landed: all but this wave's nv youngest pieces.  nv is NIT or NIT-1 (wave-uniform): two immediates.
+    if (nv == NIT) {
+        if (NIT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (NIT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (NIT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (NIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (NIT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (NIT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (NIT == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (NIT == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (NIT == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (NIT == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (NIT == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (NIT == 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (NIT == 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    PV_ASTAMP(2);
+    bool v_ready = false;
 
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
@@ -91,56 +157,69 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + pv_swz<CPR>(kt * 16 + i16, ks * 4 + g));
+                // rows kt*16 + i16: 16 rows = 16*DHP*2 bytes further, and (row & 7) / the line parity are unchanged
+                const bf16x8 kf = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kbase[ks] + kt * (16 * DHP * 2));
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], a, 0, 0, 0);
             }
             sc[kt] = a;
         }
-        // mask padded keys: SP - 32 < S <= SP, so only the last two 16-key tiles can hold them
+        // mask padded keys: SP - 16 < S <= SP, so only the last 16-key tile can hold them
 #pragma unroll
-        for (int kt = (NKT >= 2 ? NKT - 2 : 0); kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
-        }
+        for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
         // ---- softmax numerator: in-lane over 4*NKT keys, then across the 4 lane groups ------------------------
         float m = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        for (int kt = 0; kt < NKT; ++kt) {      // v_max3: two scores per instruction, no canonicalising v_max pairs
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(sc[kt][0]), "v"(sc[kt][1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(sc[kt][2]), "v"(sc[kt][3]));
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        // p = exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp per score
+        const float nm = -m * 1.44269504088896340736f;
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pe = __expf(sc[kt][r] - m);
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.44269504088896340736f, nm));
                 sc[kt][r] = pe;
                 l += pe;
             }
         }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        if (!v_ready) {            // first tile of the wave: V must have landed (for every wave) before the first PV product
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            v_ready = true;
+        }
         // ---- O^T = V^T . P^T ---------------------------------------------------------------------------------
         f32x4 o[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int tq = i16 >> 2, tp = i16 & 3;
 #pragma unroll
         for (int tt = 0; tt < NKT32; ++tt) {
             u32x4 pw = {pv_pack_bf16x2(sc[2 * tt][0], sc[2 * tt][1]), pv_pack_bf16x2(sc[2 * tt][2], sc[2 * tt][3]),
                         pv_pack_bf16x2(sc[2 * tt + 1][0], sc[2 * tt + 1][1]), pv_pack_bf16x2(sc[2 * tt + 1][2], sc[2 * tt + 1][3])};
             const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-            const int r0 = 32 * tt + 4 * g + tq;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                const int c = dt * 2 + (tp >> 1), sub = (tp & 1) << 3;
-                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vs + pv_swz<CPR>(r0, c) + sub));
-                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(Vs + pv_swz<CPR>(r0 + 16, c) + sub));
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + tt * (32 * DHP * 2)));
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + tt * (32 * DHP * 2) + 16 * DHP * 2));
                 const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (NKT & 1) {             // odd last 16-key tile: K = 16 MFMA, lane group g contributes keys 4g..4g+3 directly
+            constexpr int kt = NKT - 1;
+            u32x2 pw = {pv_pack_bf16x2(sc[kt][0], sc[kt][1]), pv_pack_bf16x2(sc[kt][2], sc[kt][3])};
+            const s16x4 pf = __builtin_bit_cast(s16x4, pw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + kt * (16 * DHP * 2)));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(v0, pf, o[dt], 0, 0, 0);
             }
         }
         // ---- normalise and store: lane holds out[q0+i16][h*DH + dt*16 + 4g + 0..3] -----------------------------
@@ -154,27 +233,34 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
             }
         }
     }
+    if (!v_ready) {                // a wave without any q tile still has to join the V barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    PV_ASTAMP(3);
 }
 
-template <int DH, int NKT32>
+template <int DH, int NKT>
 static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
-    constexpr int lds = 2 * NKT32 * 32 * DHP * 2;
+    constexpr int lds = 2 * NKT * 16 * DHP * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT32>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
     return pv_check_launch();
 }
 
 template <int DH>
 static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
-    switch ((S + 31) / 32) {
+    switch ((S + 15) / 16) {
 #define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, stream);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
-        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13) PV_ATTN_CASE(14)
+        PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20) PV_ATTN_CASE(21)
+        PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
         default: return PV_ERR_UNSUPPORTED;
     }
