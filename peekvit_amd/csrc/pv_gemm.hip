@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + en0 + (i >> 1) * 32 + (i & 1) * 4);
+        if (p.bias && en0 + (i >> 1) * 32 + (i & 1) * 4 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + en0 + (i >> 1) * 32 + (i & 1) * 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = b4;
     }
@@ -407,13 +407,14 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
     const int g = lane >> 4, i16 = lane & 15;
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) {
         // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7)
-        const float qs = (EPI == PV_EPI_BIAS_BF16 && n0 < p.qcols) ? p.qscale : 1.0f;     // tile-uniform (qcols % 256 == 0 checked on host)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int row = wr * 128 + mt * 16 + i16;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
+                // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
+                const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
                 u32x4 pk;
                 if (EPI == PV_EPI_BIAS_GELU_BF16) {
                     const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
         for (int j = 0; j < 16; ++j) {
             const int row = wid * 32 + 2 * j + (lane >> 5);
             const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
-            if (m0 + row < p.M) *reinterpret_cast<u32x4*>(ob + (int64_t)(m0 + row) * p.ldo) = v;
+            if (m0 + row < p.M && n0 + (lane & 31) * 8 < p.N) *reinterpret_cast<u32x4*>(ob + (int64_t)(m0 + row) * p.ldo) = v;
         }
     } else {
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
@@ -443,17 +444,19 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
             // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
             f32x4 rr[16];
             int64_t orow[16];
+            const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
+            const int ncol = col_ok ? n0 + lane * 4 : 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int m = m0 + ps * 128 + wid * 16 + j;
                 m = m < p.M ? m : p.M - 1;
                 if (EPI == PV_EPI_BIAS_RES_F32) {
                     orow[j] = m;
-                    rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n0 + lane * 4);
+                    rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
                 } else {
                     const int img = m / p.rpi, pi = m - img * p.rpi;
                     orow[j] = (int64_t)img * p.rpo + p.row_off + pi;
-                    rr[j] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + n0 + lane * 4);
+                    rr[j] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + ncol);
                 }
             }
             if (ps == 1) __builtin_amdgcn_s_barrier();      // pass 0's image has been consumed by every wave
@@ -479,8 +482,8 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
                 f32x4 o;
                 if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
                 else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
-                if (m0 + ps * 128 + row < p.M)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + n0 + lane * 4) = o;
+                if (m0 + ps * 128 + row < p.M && col_ok)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
             }
         }
     }
@@ -525,10 +528,15 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
         return PV_ERR_INVALID_ARG;
     // kernel choice: the deep-pipelined 256^2 tile for the big token GEMMs, the 128^2 tile for everything else
     static const int force = [] { const char* e = getenv("PV_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    const bool big = force == 256 || (force != 128 && p.N % G2_BN == 0 && p.K % (2 * G2_BK) == 0 && p.M >= 2048 &&
-                                      !(a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN));
+    // 256^2 tile: N a multiple of 128 (a ragged last column tile is clamped on load and guarded on store; worth it while
+    // it wastes <= 25 % of the tiles), K a multiple of 128, enough rows to fill the chip
+    const int tn256 = (p.N + G2_BN - 1) / G2_BN;
+    const bool n_ok = p.N % 128 == 0 && (int64_t)tn256 * G2_BN * 3 <= (int64_t)p.N * 4;
+    // (the 256^2 epilogue applies the q-scale per 8-column chunk, the 128^2 one per 4 columns)
+    const bool big = !(a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % 8) &&
+                     (force == 256 || (force != 128 && n_ok && p.K % (2 * G2_BK) == 0 && p.M >= 2048));
     if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
-    if (big && a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % G2_BN) return PV_ERR_UNSUPPORTED;   // q-scale is tile-uniform there
+    if (a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
     p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;

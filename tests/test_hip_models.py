@@ -192,3 +192,16 @@ def test_every_block_on_identical_inputs(name):
             got = blk(t.to(DEV)).cpu()
             assert rel_l2(got.numpy(), ref.numpy()) < TOL_BLOCK, i
             t = ref
+
+
+def test_hip_graph_replay_matches_eager():
+    """The forward is capturable into a hipGraph (stateless, allocation-free C ABI) and replays bit-identically."""
+    from peekvit_amd.graph import GraphedForward
+    cfg, m = _model("vit", "vit_tiny")
+    x = _x(cfg, 4).to(DEV)
+    with torch.no_grad():
+        eager = m(x).clone()
+    g = GraphedForward(m, x)
+    assert torch.equal(g(x), eager)
+    x2 = torch.flip(x, dims=[0])
+    assert torch.equal(g(x2), torch.flip(eager, dims=[0]))

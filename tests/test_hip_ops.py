@@ -66,7 +66,9 @@ def test_layernorm(ops, rows, D):
 # the last four shapes (M >= 2048, N % 256 == 0, K % 128 == 0) run the 256x256 deep-pipelined kernel, incl. a ragged M edge
 GEMM_SHAPES = [(100, 128, 64), (256, 256, 128), (300, 384, 192), (197 * 2, 2304, 768), (130, 768, 3072), (77, 1000, 256),
                (2048, 256, 128), (2304 + 37, 768, 768), (2048, 2304, 256), (2100, 768, 3072),
-               (2048, 768, 768), (4096 + 128, 2304, 768), (2048 + 384, 768, 3072), (2560, 3072, 768), (66 * 128, 256, 1536)]
+               (2048, 768, 768), (4096 + 128, 2304, 768), (2048 + 384, 768, 3072), (2560, 3072, 768), (66 * 128, 256, 1536),
+               # N % 256 == 128: ragged last column tile of the 256^2 kernel (vit_small: 384, 1152)
+               (2048 + 77, 384, 384), (2304, 1152, 384), (2048, 640, 256)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
