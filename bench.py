@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     return ap.parse_args()
 
 
@@ -76,11 +77,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = world > 1
+    if args.dist_backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)       # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group("gloo")
 
     from peekvit_amd import ops, synth
     from peekvit_amd.models.rankvit import RankVisionTransformer
@@ -128,7 +134,7 @@ def main():
             elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all()
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -82,6 +82,15 @@ typedef struct pv_gemm_args {
     int64_t qcols;             /* PV_EPI_BIAS_BF16: columns [0,qcols) are multiplied by qscale          */
     float qscale;
     int32_t epilogue;          /* PV_EPI_*                                                              */
+    /* optional fused LayerNorm of the finished output rows (PV_EPI_BIAS_RES_F32 only, ABI v2): when ln_out != NULL the
+     * kernel also writes ln_out[m,:] = bf16(LayerNorm(out[m,:]; ln_gamma, ln_beta, ln_eps) * ln_row_scale[m]) -
+     * bit-identical to pv_layernorm_bf16 on `out`.  Replaces models/vit.py:51+53 (residual, then ln_2) and
+     * models/vit.py:55 + the next block's :48.  Needs N % 256 == 0, N <= 4096, K % 128 == 0, ldo == N. */
+    const float* ln_gamma;     /* fp32 [N]                                                              */
+    const float* ln_beta;      /* fp32 [N]                                                              */
+    const float* ln_row_scale; /* fp32 [M] or NULL                                                      */
+    uint16_t* ln_out;          /* bf16 [M,N] contiguous, or NULL (no fused LayerNorm)                   */
+    float ln_eps;
 } pv_gemm_args;
 
 /* out = epilogue(A . W^T): bf16 MFMA operands, fp32 accumulation.  Replaces the addmm/mm behind

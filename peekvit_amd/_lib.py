@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", _p), ("W", _p), ("bias", _p), ("out", _p), ("res", _p), ("row_scale", _p), ("pos", _p),
                 ("M", _i64), ("N", _i64), ("K", _i64), ("lda", _i64), ("ldw", _i64), ("ldo", _i64), ("ldr", _i64),
                 ("rows_per_img_in", _i64), ("rows_per_img_out", _i64), ("row_off", _i64), ("qcols", _i64),
-                ("qscale", _f32), ("epilogue", _i32)]
+                ("qscale", _f32), ("epilogue", _i32),
+                ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32)]
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares

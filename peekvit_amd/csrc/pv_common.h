@@ -46,6 +46,52 @@ __device__ __forceinline__ float pv_gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// ---- LayerNorm row helpers (one wave per row, the row stays in registers; two-pass mean / variance in fp32).  Shared by the
+// standalone LN kernel and the GEMM-fused LN pass so both round identically. -------------------------------------------
+template <int NCH>
+struct RowRegs {
+    float4 v[NCH];
+};
+
+template <int NCH>
+__device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __restrict__ xr, int nvec, int lane) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int idx = lane + 64 * j;
+        r.v[j] = idx < nvec ? reinterpret_cast<const float4*>(xr)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros)
+template <int NCH>
+__device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restrict__ gamma, const float* __restrict__ beta, int D,
+                                          int nvec, int lane, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
+    const float mean = pv_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (lane + 64 * j < nvec) {
+            float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(pv_wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int idx = lane + 64 * j;
+        if (idx < nvec) {
+            float4 g = reinterpret_cast<const float4*>(gamma)[idx], b = reinterpret_cast<const float4*>(beta)[idx];
+            r.v[j].x = (r.v[j].x - mean) * rstd * g.x + b.x;
+            r.v[j].y = (r.v[j].y - mean) * rstd * g.y + b.y;
+            r.v[j].z = (r.v[j].z - mean) * rstd * g.z + b.z;
+            r.v[j].w = (r.v[j].w - mean) * rstd * g.w + b.w;
+        }
+    }
+}
+
 // hipGetLastError() is per-thread and sticky across ALL users of the runtime (PyTorch leaves benign errors such as
 // failed pointer-attribute queries behind), so every launch first clears it: pv_check_launch() then reports OUR launch.
 #define PV_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

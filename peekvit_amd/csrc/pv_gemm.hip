@@ -39,6 +39,11 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
+    const float* ln_gamma;     // fused LayerNorm of the finished output rows (row-block kernel): out rows -> ln_out bf16
+    const float* ln_beta;
+    const float* ln_row_scale;
+    uint16_t* ln_out;
+    float ln_eps;
 #ifdef PV_STAMPS
     unsigned long long* dbg;   // diagnostic build only: per-block s_memtime stamps (never read by any kernel)
 #endif
@@ -233,20 +238,12 @@ constexpr int G2_HALF = 128 * G2_BK * 2;     // 16 KiB half-tile slot
 constexpr int G2_BUF = 4 * G2_HALF;          // 64 KiB per K-tile buffer
 constexpr int G2_LDS = 2 * G2_BUF;           // 128 KiB
 
+// one 256 x 256 output tile at (m0, n0): prologue, pipelined K loop, transposed epilogue.  Uses smem[0, G2_LDS) (+ the GELU table).
 template <int EPI>
-__global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, const int m0, const int n0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-
-    // tile order: every XCD walks a contiguous range of a list in which groups of `gm` M-blocks are swept with n as the slow
-    // index, so the ~32 co-running blocks of an XCD touch gm A panels and ~32/gm weight tiles at a time (L2 = 4 MiB per XCD)
-    const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int grp = tile / (p.gm * p.tiles_n), rem = tile - grp * (p.gm * p.tiles_n);
-    const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
-    const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
-    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
 
     // ---- LDS-DMA sources: per half-tile two 1-KiB pieces per wave (rows j*64 + wid*8 + lane/8), swizzled chunk ----
     const int srow = wid * 8 + (lane >> 3);
@@ -495,6 +492,94 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
 }
 
 template <int EPI>
+__global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // tile order: every XCD walks a contiguous range of a list in which groups of `gm` M-blocks are swept with n as the slow
+    // index, so the ~32 co-running blocks of an XCD touch gm A panels and ~32/gm weight tiles at a time (L2 = 4 MiB per XCD)
+    const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int grp = tile / (p.gm * p.tiles_n), rem = tile - grp * (p.gm * p.tiles_n);
+    const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
+    const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
+    pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, tn * G2_BN);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-block kernel with FUSED LayerNorm: one workgroup computes ALL column tiles of its 256 output rows (N = hidden dim),
+// then normalises the rows it has just written - re-read from the XCD's L2 with L1-bypassing loads instead of from HBM by a
+// separate LayerNorm launch - and emits the bf16 operand of the next GEMM.  The per-row arithmetic is the standalone LN
+// kernel's (pv_ln_row), so the result is bit-identical to GEMM + pv_layernorm_bf16.
+//   replaces models/vit.py:51 + :53 (out-proj residual, then ln_2) and models/vit.py:55 + next block's :48 (fc2 residual, ln_1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pv_load16_l2(f32x4& dst, const void* ptr) {     // sc1: served by L2, never by a (possibly stale) L1 line
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
+template <int NCH>
+__device__ __forceinline__ void pv_fused_ln_rows(const GemmDev& p, const int m0) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int D = p.N, nvec = D >> 2;
+    const float* const xo = reinterpret_cast<const float*>(p.out);
+    constexpr int RB = NCH <= 4 ? 4 : 1;                     // rows in flight per wave (registers: RB * NCH * 4)
+    for (int r0 = 0; r0 < 32; r0 += RB) {
+        f32x4 raw[RB][NCH];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            int m = m0 + wid * 32 + r0 + rb;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < nvec) pv_load16_l2(raw[rb][j], xo + (int64_t)m * p.ldo + idx * 4);
+                else raw[rb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[rb][j])::"memory");
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int m = m0 + wid * 32 + r0 + rb;
+            if (m >= p.M) break;
+            RowRegs<NCH> r;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) r.v[j] = make_float4(raw[rb][j][0], raw[rb][j][1], raw[rb][j][2], raw[rb][j][3]);
+            pv_ln_row<NCH>(r, p.ln_gamma, p.ln_beta, D, nvec, lane, p.ln_eps);
+            const float sc = p.ln_row_scale ? p.ln_row_scale[m] : 1.0f;
+            u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * D);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < nvec) {
+                    u32x2 pk = {pv_pack_bf16x2(r.v[j].x * sc, r.v[j].y * sc), pv_pack_bf16x2(r.v[j].z * sc, r.v[j].w * sc)};
+                    o[idx] = pk;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m0 = pv_xcd_remap(blockIdx.x, p.tiles_m) * G2_BM;
+    for (int tn = 0; tn < p.tiles_n; ++tn) {
+        pv_gemm256_tile<EPI>(p, smem, m0, tn * G2_BN);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the epilogue's LDS reads are done before the next tile's DMA
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every row segment of this block has reached L2
+    __builtin_amdgcn_s_barrier();
+    const int nch = (p.N / 4 + 63) / 64;
+    if (nch <= 1) pv_fused_ln_rows<1>(p, m0);
+    else if (nch == 2) pv_fused_ln_rows<2>(p, m0);
+    else if (nch == 3) pv_fused_ln_rows<3>(p, m0);
+    else if (nch == 4) pv_fused_ln_rows<4>(p, m0);
+    else if (nch <= 8) pv_fused_ln_rows<8>(p, m0);
+    else pv_fused_ln_rows<16>(p, m0);
+}
+
+template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static bool attr_set = false;
     constexpr int lds = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
@@ -503,6 +588,17 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
         attr_set = true;
     }
     PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
+    return pv_check_launch();
+}
+
+template <int EPI>
+static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_rows_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    PV_LAUNCH(pv_gemm256_rows_kernel<EPI>, dim3((unsigned)p.tiles_m), dim3(512), G2_LDS, stream, p);
     return pv_check_launch();
 }
 
@@ -521,7 +617,14 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
 #ifdef PV_STAMPS
     p.dbg = g_pv_dbg;
 #endif
+    p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_row_scale = a->ln_row_scale; p.ln_out = a->ln_out; p.ln_eps = a->ln_eps;
     hipStream_t s = (hipStream_t)stream;
+    if (a->ln_out) {
+        // fused LayerNorm: whole rows per workgroup -> N is the hidden dim, a multiple of 256, K a multiple of 128
+        if (a->epilogue != PV_EPI_BIAS_RES_F32 || !a->ln_gamma || !a->ln_beta) return PV_ERR_INVALID_ARG;
+        if (a->N % G2_BN || a->N > 4096 || a->K % (2 * G2_BK) || a->ldo != a->N) return PV_ERR_UNSUPPORTED;
+        if (((uintptr_t)a->ln_out & 7) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return PV_ERR_INVALID_ARG;
+    }
     if (a->epilogue == PV_EPI_BIAS_RES_F32 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15))) return PV_ERR_INVALID_ARG;
     if (a->epilogue == PV_EPI_BIAS_POS_F32 &&
         (!a->pos || a->rows_per_img_in <= 0 || a->rows_per_img_out < a->rows_per_img_in + a->row_off || a->row_off < 0 || ((uintptr_t)a->pos & 15)))
@@ -542,6 +645,11 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    if (a->ln_out) {
+        p.gm = 1;
+        p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = p.N / G2_BN;
+        return pv_launch_gemm256_rows<PV_EPI_BIAS_RES_F32>(p, s);
+    }
     switch (a->epilogue) {
         case PV_EPI_BIAS_BF16: return big ? pv_launch_gemm256<PV_EPI_BIAS_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_BF16>(p, s);
         case PV_EPI_BIAS_GELU_BF16: return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_BF16>(p, s);

@@ -108,50 +108,6 @@ extern "C" int pv_token_prologue(float* tokens, const float* special, const floa
 // LayerNorm (one wave per row; the row stays in registers: two-pass mean / variance in fp32)
 // ------------------------------------------------------------------------------------------------
 template <int NCH>
-struct RowRegs {
-    float4 v[NCH];
-};
-
-template <int NCH>
-__device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __restrict__ xr, int nvec, int lane) {
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        int idx = lane + 64 * j;
-        r.v[j] = idx < nvec ? reinterpret_cast<const float4*>(xr)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros)
-template <int NCH>
-__device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restrict__ gamma, const float* __restrict__ beta, int D,
-                                          int nvec, int lane, float eps) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
-    const float mean = pv_wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        if (lane + 64 * j < nvec) {
-            float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(pv_wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        int idx = lane + 64 * j;
-        if (idx < nvec) {
-            float4 g = reinterpret_cast<const float4*>(gamma)[idx], b = reinterpret_cast<const float4*>(beta)[idx];
-            r.v[j].x = (r.v[j].x - mean) * rstd * g.x + b.x;
-            r.v[j].y = (r.v[j].y - mean) * rstd * g.y + b.y;
-            r.v[j].z = (r.v[j].z - mean) * rstd * g.z + b.z;
-            r.v[j].w = (r.v[j].w - mean) * rstd * g.w + b.w;
-        }
-    }
-}
-
-template <int NCH>
 __global__ __launch_bounds__(256) void pv_layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ row_scale,
                                                            uint16_t* __restrict__ out, int64_t rows, int D, float eps) {

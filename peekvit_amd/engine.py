@@ -91,17 +91,38 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 # ------------------------------------------------------------------------------------------------
 # one pre-LN encoder block (reference models/vit.py:45-55; masked form models/residualvit.py:249-260)
 # ------------------------------------------------------------------------------------------------
-def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+# Fused LayerNorm (row-block GEMM, pv_gemm_args.ln_out) is OPT-IN: measured on MI355X at B = 2048 it is bit-identical but
+# slower than GEMM + standalone LN (out-proj 1.34 vs 1.14 ms, fc2 2.81 vs 2.02 ms): one workgroup per 256-row block runs its
+# three column tiles one after the other, so the A panel is re-fetched through the fabric three times instead of being
+# shared in time by neighbouring CUs.
+_FUSE_LN = os.environ.get("PEEKVIT_AMD_FUSE_LN", "0") == "1"
+
+
+def _ln_fusable(D: int, K: int) -> bool:
+    """Shapes the row-block GEMM with fused LayerNorm accepts (include/peekvit_hip.h pv_gemm_args.ln_out)."""
+    return _FUSE_LN and D % 256 == 0 and D <= 4096 and K % 128 == 0
+
+
+def _ln_key(ln: nn.LayerNorm):
+    return (id(ln.weight), ln.weight._version, ln.bias._version, float(ln.eps))
+
+
+def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
+                  next_ln: Optional[nn.LayerNorm] = None) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
 
-    7 launches: LN1 -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual)
-                -> LN2 -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias, +residual).
+    Launches: [LN1] -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual, fused LN2)
+              -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias, +residual, fused next-block LN1).
+    LN1 is skipped when the producer of `x` (the previous block's fc2) already emitted it: that hand-off travels as the
+    private attribute `x._pv_ln = (h_bf16, key)` and is used only if `key` matches this block's ln_1 (same parameter
+    object, versions and eps).  `next_ln`: the LayerNorm the consumer of the output will apply first (encoder hint).
     row_scale [B,S] (ResidualViT fwd_mask) multiplies LN1 out, the attention branch and LN2 out.
     """
     if x.dtype != torch.float32:
         x = x.float()
+    handoff = getattr(x, "_pv_ln", None)
     if not x.is_contiguous():
-        x = x.contiguous()
+        x, handoff = x.contiguous(), None
     B, S, D = x.shape
     mha = blk.self_attention.self_attention
     H = mha.num_heads
@@ -110,24 +131,53 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     dev = x.device
     R = B * S
 
-    h = workspace.get("h", (R, D), torch.bfloat16, dev)
+    h2 = workspace.get("h2", (R, D), torch.bfloat16, dev)
     qkv = workspace.get("qkv", (R, 3 * D), torch.bfloat16, dev)
     att = workspace.get("att", (R, D), torch.bfloat16, dev)
     g = workspace.get("g", (R, M), torch.bfloat16, dev)
     x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
     out = torch.empty_like(x)
 
-    ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
+    if handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
+        h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue
+    else:
+        h = workspace.get("h", (R, D), torch.bfloat16, dev)
+        ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
     ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
              qcols=D, qscale=float(dh) ** -0.5)
     ops.attention(qkv, att, B, S, H, dh)
+    fuse2 = _ln_fusable(D, D)
     ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-             res=x.view(R, D), row_scale=row_scale)
-    ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h, row_scale)
-    ops.gemm(h, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
+             res=x.view(R, D), row_scale=row_scale,
+             ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale) if fuse2 else None)
+    if not fuse2:
+        ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
+    ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
+    fuse_next = next_ln is not None and _ln_fusable(D, M) and next_ln.normalized_shape == (D,)
+    hn = workspace.get("h", (R, D), torch.bfloat16, dev) if fuse_next else None      # "h" is dead once QKV has consumed it
     ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-             res=x1.view(R, D))
+             res=x1.view(R, D),
+             ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
+    if fuse_next:
+        out._pv_ln = (hn, _ln_key(next_ln))
     return out
+
+
+def run_layers(layers: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Run an encoder's `layers` on the MI355X path, telling every block which LayerNorm its consumer applies first so the
+    producer can fuse it (peephole over ADJACENT blocks only: `layers` stays an ordinary nn.Sequential).
+    A consumer that transforms its input before ln_1 (RankViT block with an active budget, ResidualViT gated block,
+    NoiseBlock, ...) gets no hint and simply normalises itself."""
+    mods = list(layers)
+    for i, layer in enumerate(mods):
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        hint = None
+        if nxt is not None and getattr(nxt, "_pv_plain_ln1", None) is not None and nxt._pv_plain_ln1():
+            hint = nxt.ln_1
+        if hasattr(layer, "_pv_next_ln"):
+            layer._pv_next_ln = hint
+        x = layer(x)
+    return x
 
 
 # ------------------------------------------------------------------------------------------------

@@ -48,6 +48,9 @@ class RankViTBlock(ViTBlock):
     def set_budget(self, budget: float):
         self.current_budget = budget
 
+    def _pv_plain_ln1(self) -> bool:
+        return self.current_budget == 1      # with an active budget the tokens are ranked / dropped before ln_1
+
 
 class RankViTEncoder(nn.Module):
     """Encoder whose blocks at `rankvit_layers` are RankViTBlocks (reference models/rankvit.py:105-152).
@@ -66,7 +69,7 @@ class RankViTEncoder(nn.Module):
     def forward(self, input: torch.Tensor, _pos_added: bool = False):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
-            return self.layers(input)
+            return engine.run_layers(self.layers, input)
         return self.ln(self.layers(self.dropout(input + self.pos_embedding)))
 
 

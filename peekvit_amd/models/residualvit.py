@@ -196,7 +196,7 @@ class ResidualViTEncoder(nn.Module):
     def forward(self, input: torch.Tensor, _pos_added: bool = False):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
-            return self.layers(input)
+            return engine.run_layers(self.layers, input)      # gated blocks publish no _pv_plain_ln1: they normalise themselves
         if self.budget_token:
             body, btok = input[:, :-self.num_budget_tokens], input[:, -self.num_budget_tokens:]
             input = torch.cat([body + self.pos_embedding, btok], dim=1)

@@ -33,6 +33,11 @@ class ViTBlock(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.ln_2 = nn.LayerNorm(hidden_dim, eps=self.LN_EPS)
         self.mlp = MLP(hidden_dim=hidden_dim, mlp_dim=mlp_dim)
+        self._pv_next_ln = None     # engine hint: the LayerNorm the next block applies first (fused into fc2's epilogue)
+
+    def _pv_plain_ln1(self) -> bool:
+        """True when this block applies ln_1 directly to its input (so a producer may pre-compute it)."""
+        return True
 
     def _composite(self, tokens: torch.Tensor) -> torch.Tensor:
         attn = self.dropout(self.self_attention(self.ln_1(tokens)))
@@ -42,7 +47,7 @@ class ViTBlock(nn.Module):
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if engine.backend_for(input, self, self._p_drop) == "hip":
-            return engine.block_forward(self, input, self.ln_1.eps)
+            return engine.block_forward(self, input, self.ln_1.eps, next_ln=self._pv_next_ln)
         return self._composite(input)
 
 
@@ -68,7 +73,7 @@ class ViTEncoder(nn.Module):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
             # MI355X path: the final LayerNorm is applied to the class-token rows only, by pool_and_head
-            return self.layers(input)
+            return engine.run_layers(self.layers, input)
         return self.ln(self.layers(self.dropout(input + self.pos_embedding)))
 
 

@@ -130,8 +130,9 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0):
-    """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1])."""
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None):
+    """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
+    ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
     K = a.shape[-1]
     if M is None:
         M = a.numel() // K
@@ -143,8 +144,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     M=M, N=N, K=K, lda=K, ldw=w.shape[-1], ldo=out.shape[-1],
                     ldr=res.shape[-1] if res is not None else 0,
                     rows_per_img_in=rows_per_img_in, rows_per_img_out=rows_per_img_out, row_off=row_off,
-                    qcols=qcols, qscale=float(qscale), epilogue=epilogue)
-    with _timed("pv_gemm_bf16", a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1)):
+                    qcols=qcols, qscale=float(qscale), epilogue=epilogue,
+                    ln_gamma=ln[0].data_ptr() if ln else 0, ln_beta=ln[1].data_ptr() if ln else 0,
+                    ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
+                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0)
+    with _timed("pv_gemm_bf16", a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
         check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
     return out

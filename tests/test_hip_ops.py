@@ -152,6 +152,26 @@ def test_gemm_kernels_agree_bitwise(ops):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048 + 77, 768, 768), (1000, 768, 3072), (520, 1024, 256)])
+def test_gemm_fused_layernorm_bit_identical_to_separate_kernels(ops, M, N, K):
+    """Row-block GEMM with fused LayerNorm == plain GEMM followed by pv_layernorm_bf16, bit for bit (with and without row scale)."""
+    from peekvit_amd._lib import PV_EPI_BIAS_RES_F32
+    a, w = bf(T(f"fa{M}{K}", (M, K))), bf(T(f"fw{N}{K}", (N, K), "uniform", 1.0 / math.sqrt(K)))
+    bias, res = T(f"fb{N}", (N,), "uniform", 0.1).to(DEV), T(f"fr{M}{N}", (M, N), bf16=False).to(DEV)
+    g, b = T(f"fg{N}", (N,), "uniform", 0.2, 1.0).to(DEV), T(f"fbeta{N}", (N,), "uniform", 0.1).to(DEV)
+    rs = T(f"frs{M}", (M,), "uniform", 0.5, 0.5, bf16=False).to(DEV)
+    for scale in (None, rs):
+        o1 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        ops.gemm(a, w, bias, o1, PV_EPI_BIAS_RES_F32, res=res, row_scale=scale)
+        h1 = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        ops.layernorm_bf16(o1, g, b, 1e-5, h1, scale)
+        o2 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        h2 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, w, bias, o2, PV_EPI_BIAS_RES_F32, res=res, row_scale=scale, ln=(g, b, 1e-5, h2, scale))
+        assert torch.equal(o1, o2)
+        assert torch.equal(h1, h2)
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from peekvit_amd._lib import PV_EPI_BIAS_BF16, PeekvitHipError
     a, w = bf(T("ba", (8, 96))), bf(T("bw", (16, 96)))
