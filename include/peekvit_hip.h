@@ -44,6 +44,12 @@ int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P,
                    void* stream);
 
+/* The same patch gather straight from the DataLoader's RAW image: x uint8 [B,H,W,3] (NHWC); ToTensor + Normalize of
+ *   data/imagenette.py:73 (x/255, then (x - mean[c]) / std[c], fp32, this op order) are applied per element, so `cols` is
+ * bit-identical to pv_im2col_bf16 of the normalised fp32 NCHW tensor at a quarter of the input bytes.  P % 8 == 0. */
+int pv_im2col_u8_bf16(const uint8_t* x, uint16_t* cols, int64_t B, int64_t H, int64_t W, int64_t P, float mean0,
+                      float mean1, float mean2, float std0, float std1, float std2, void* stream);
+
 /* Token prologue rows that are not produced by the patch GEMM:
  *   models/vit.py:230-236 (cat registers, cat class tokens) + models/vit.py:92 (+ pos_embedding),
  *   models/residualvit.py:566-568,345 (append learnable_budget_token_1 * budget, no pos-embedding).

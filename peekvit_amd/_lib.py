@@ -38,6 +38,7 @@ SIGNATURES = {
     "pv_error_string": (C.c_char_p, [C.c_int]),
     "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "pv_im2col_u8_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p]),
     "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),

@@ -75,6 +75,43 @@ extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// uint8 NHWC input pipeline fused into the patch gather: the DataLoader's ToTensor + Normalize
+// (reference data/imagenette.py:73: x/255, then (x - mean)/std, fp32) happen here, per element, in the same op order, so the
+// bf16 patch matrix is bit-identical to im2col of the normalised fp32 NCHW tensor - at 1/4 of the input bytes.
+// ------------------------------------------------------------------------------------------------
+struct PvNorm3 { float mean[3], std[3]; };
+
+__global__ __launch_bounds__(256) void pv_im2col_u8_kernel(const uint8_t* __restrict__ x, uint16_t* __restrict__ cols, int64_t B, int H, int W,
+                                                           int P, PvNorm3 nm) {
+    const int Hp = H / P, Wp = W / P, Np = Hp * Wp, K = 3 * P * P, K8 = K >> 3;
+    const int64_t total = B * (int64_t)Np * K8;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t m = idx / K8;
+        const int k = (int)(idx - m * K8) << 3;
+        const int c = k / (P * P), kh = (k / P) % P, kw = k % P;
+        const int64_t b = m / Np;
+        const int pi = (int)(m - b * Np), ph = pi / Wp, pw = pi - ph * Wp;
+        const uint8_t* s = x + ((b * H + (int64_t)ph * P + kh) * W + pw * P + kw) * 3 + c;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)s[3 * j] / 255.0f - nm.mean[c]) / nm.std[c];
+        u32x4 o = {pv_pack_bf16x2(v[0], v[1]), pv_pack_bf16x2(v[2], v[3]), pv_pack_bf16x2(v[4], v[5]), pv_pack_bf16x2(v[6], v[7])};
+        reinterpret_cast<u32x4*>(cols)[idx] = o;
+    }
+}
+
+extern "C" int pv_im2col_u8_bf16(const uint8_t* x, uint16_t* cols, int64_t B, int64_t H, int64_t W, int64_t P, float mean0, float mean1,
+                                 float mean2, float std0, float std1, float std2, void* stream) {
+    if (!x || !cols || B <= 0 || H <= 0 || W <= 0 || P <= 0 || H % P || W % P) return PV_ERR_INVALID_ARG;
+    if (std0 == 0.f || std1 == 0.f || std2 == 0.f) return PV_ERR_INVALID_ARG;
+    if (P % 8 || ((uintptr_t)cols & 15)) return PV_ERR_UNSUPPORTED;
+    const int64_t work = B * (H / P) * (W / P) * (3 * P * P / 8);
+    PvNorm3 nm = {{mean0, mean1, mean2}, {std0, std1, std2}};
+    PV_LAUNCH(pv_im2col_u8_kernel, dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)H, (int)W, (int)P, nm);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // token prologue: special rows (+pos) and the optional budget token row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pv_token_prologue_kernel(float* __restrict__ tokens, const float* __restrict__ special,

@@ -81,6 +81,10 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     return w
 
 
+# ToTensor + Normalize constants of the reference's datasets (data/imagenette.py:73, data/imagenet.py)
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
 def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if p is None:
         return None
@@ -187,20 +191,26 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
                  budget: float = 0.0) -> torch.Tensor:
     """img fp32 [B,3,R,R] -> tokens fp32 [B,S_total,D] = [cls | registers | patches] + pos_embedding
     (+ one trailing budget-token row without positional embedding for ResidualViT)."""
-    if img.dtype != torch.float32:
+    u8 = img.dtype == torch.uint8            # raw NHWC image: normalisation is fused into the patch gather
+    if not u8 and img.dtype != torch.float32:
         img = img.float()
     if not img.is_contiguous():
         img = img.contiguous()
     B = img.shape[0]
     P, D = model.patch_size, model.hidden_dim
-    Np = (img.shape[2] // P) * (img.shape[3] // P)
+    Hh, Ww, Cin = (img.shape[1], img.shape[2], img.shape[3]) if u8 else (img.shape[2], img.shape[3], img.shape[1])
+    Np = (Hh // P) * (Ww // P)
     n_special = model.num_class_tokens + model.num_registers
     S = n_special + Np + (1 if budget_token is not None else 0)
-    K = img.shape[1] * P * P
+    K = Cin * P * P
     dev = img.device
 
     cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
-    ops.im2col(img, P, cols)
+    if u8:
+        mean, std = getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD)
+        ops.im2col_u8(img, P, cols, mean, std)
+    else:
+        ops.im2col(img, P, cols)
     tokens = torch.empty((B, S, D), dtype=torch.float32, device=dev)
     pos = _f32(model.encoder.pos_embedding).view(-1, D)
     ops.gemm(cols, bf16_weight(model.conv_proj.weight), _f32(model.conv_proj.bias), tokens.view(B * S, D),

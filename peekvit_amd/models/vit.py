@@ -105,7 +105,8 @@ class _ViTBase(nn.Module):
         nn.init.zeros_(self.conv_proj.bias)
 
     def _check_image(self, x: torch.Tensor):
-        h, w = x.shape[2], x.shape[3]
+        # fp32 NCHW (the reference's contract) or, MI355X path only, the raw uint8 NHWC image (normalisation fused in-kernel)
+        h, w = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
         torch._assert(h == self.image_size, f"Wrong image height! Expected {self.image_size} but got {h}!")
         torch._assert(w == self.image_size, f"Wrong image width! Expected {self.image_size} but got {w}!")
 

@@ -110,6 +110,19 @@ def im2col(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def im2col_u8(x: torch.Tensor, patch: int, out: torch.Tensor, mean, std) -> torch.Tensor:
+    """x: uint8 [B,H,W,3] (NHWC) -> bf16 patch matrix of the ToTensor+Normalize'd image."""
+    _chk(x, torch.uint8, "x")
+    B, H, W, Cc = x.shape
+    if Cc != 3:
+        raise _lib.PeekvitHipError("uint8 input must be NHWC with 3 channels")
+    with _timed("pv_im2col_u8_bf16", x.device, 0.0, 3.0 * x.numel()):
+        check(_lib.load().pv_im2col_u8_bf16(_ptr(x), _ptr(out), B, H, W, patch, *[float(v) for v in mean], *[float(v) for v in std],
+                                            _stream(x)), "pv_im2col_u8_bf16")
+    _count()
+    return out
+
+
 def token_prologue(tokens, special, pos, budget_token, budget: float, n_special: int):
     B, S, D = tokens.shape
     with _timed("pv_token_prologue", tokens.device, 0.0, 0.0):

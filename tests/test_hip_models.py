@@ -205,3 +205,17 @@ def test_hip_graph_replay_matches_eager():
     assert torch.equal(g(x), eager)
     x2 = torch.flip(x, dims=[0])
     assert torch.equal(g(x2), torch.flip(eager, dims=[0]))
+
+
+def test_uint8_nhwc_input_is_bit_identical_to_normalised_fp32_nchw():
+    """raw uint8 NHWC images through the fused gather == ToTensor+Normalize on the host, then the fp32 path."""
+    from peekvit_amd.engine import IMAGENET_MEAN, IMAGENET_STD
+    cfg, m = _model("vit", "vit_tiny")
+    gen = torch.Generator().manual_seed(3)
+    raw = torch.randint(0, 256, (3, cfg["image_size"], cfg["image_size"], 3), generator=gen, dtype=torch.uint8)
+    mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    x = (raw.permute(0, 3, 1, 2).float().div(255.0) - mean) / std          # torchvision ToTensor + Normalize
+    with torch.no_grad():
+        a = m(x.contiguous().to(DEV)).cpu()
+        b = m(raw.to(DEV)).cpu()
+    assert torch.equal(a, b)
