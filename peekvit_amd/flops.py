@@ -1,0 +1,87 @@
+"""Analytic FLOP / sparsity accounting with the conventions of the reference's counter.
+
+The reference measures FLOPs with ptflops plus two custom hooks (utils/flops_count.py:27-145) that fire when the stock
+`nn.Linear.forward` / `nn.MultiheadAttention.forward` run and that DISCOUNT tokens whose input row is all zeros
+("masked" tokens of ResidualViT).  The MI355X path never calls those forwards, so the hooks cannot fire; this module
+restates their arithmetic analytically, per image, from the model's shapes and the per-block masks:
+
+  Linear (flops_count.py:27-39)        MACs = (in*out + out[bias]) * live_rows
+  MultiheadAttention (:45-145)         MACs = L*D (q scale) + 3*L*D*D + 3*L*D (in-proj + bias)
+                                              + H*(L*L*dh + L*L + L*L*dh) + L*D*(D+1) (out-proj), L = live tokens
+  Conv2d, LayerNorm                    ptflops defaults: out_elems*(Cin*k*k) + out_elems (bias); 2 * numel (affine LN)
+  compute_flops returns 2 * MACs       (flops_count.py:175-180)
+
+ptflops itself is not installed in the build image, so the hook arithmetic above is restated from the reference source and
+from ptflops 0.7.2.2's published conv / norm hooks; it is NOT cross-checked against a ptflops run ("parity unpinned" for
+this helper, which is outside the hot path).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def _linear_macs(rows: float, fin: int, fout: int, bias: bool = True) -> float:
+    return (fin * fout + (fout if bias else 0)) * rows
+
+
+def _mha_macs(live: float, D: int, H: int) -> float:
+    dh = D // H
+    return live * D + 3 * live * D * D + 3 * live * D + H * (live * live * dh + live * live + live * live * dh) + live * D * (D + 1)
+
+
+def block_macs(live_tokens: float, total_tokens: int, D: int, M: int, H: int) -> float:
+    """One pre-LN block; `live_tokens` = rows that are not all-zero at the attention / MLP inputs."""
+    ln = 2 * (2 * total_tokens * D)                           # two affine LayerNorms over every row
+    return ln + _mha_macs(live_tokens, D, H) + _linear_macs(live_tokens, D, M) + _linear_macs(live_tokens, M, D)
+
+
+def model_flops(model, seq_per_layer: Optional[Sequence[int]] = None, live_per_layer: Optional[Sequence[float]] = None) -> float:
+    """2 * MACs per image for a VisionTransformer / RankVisionTransformer / ResidualVisionTransformer.
+
+    seq_per_layer: tokens entering each block (RankViT shrinks it); live_per_layer: of those, how many are non-zero rows at
+    the block's attention / MLP inputs (ResidualViT masks with relu(...) == 0 zero their rows).  Defaults: full sequence."""
+    D, M, P = model.hidden_dim, model.mlp_dim, model.patch_size
+    H = model.encoder.layers[0].self_attention.self_attention.num_heads
+    L = len(model.encoder.layers)
+    Np = (model.image_size // P) ** 2
+    S = Np + model.num_class_tokens + model.num_registers + (1 if getattr(model, "add_budget_token", False) else 0)
+    seqs = list(seq_per_layer) if seq_per_layer is not None else [S] * L
+    lives = list(live_per_layer) if live_per_layer is not None else seqs
+    macs = Np * D * (3 * P * P) + Np * D                                   # conv_proj (+ bias)
+    for s, lv in zip(seqs, lives):
+        macs += block_macs(lv, s, D, M, H)
+        blk_extra = 0.0
+        macs += blk_extra
+    macs += 2 * seqs[-1] * D                                               # encoder.ln
+    macs += _linear_macs(1, D, model.num_classes)                          # head on the pooled class token
+    if hasattr(model.encoder.layers[0], "residual_gate"):
+        for s in seqs:                                                     # gate projection D->1 on image tokens (+ budget gate)
+            macs += _linear_macs(s - 2, D, 1) + _linear_macs(1, D, 1)
+    return 2.0 * macs
+
+
+@torch.no_grad()
+def measured_flops(model, x: torch.Tensor):
+    """Run one forward and account for what it actually did: RankViT sequence lengths and ResidualViT zero rows are read
+    from the blocks after the pass (block.last_keep / block.mask).  Returns (flops_per_image, avg_sparsity)."""
+    out = model(x)
+    B = out.shape[0]
+    seqs, lives = [], []
+    S = (model.image_size // model.patch_size) ** 2 + model.num_class_tokens + model.num_registers
+    S += 1 if getattr(model, "add_budget_token", False) else 0
+    sparsity: List[float] = []
+    for blk in model.encoder.layers:
+        keep = getattr(blk, "last_keep", None)
+        if keep is not None and getattr(blk, "current_budget", 1) != 1:
+            S = 1 + keep.shape[1]
+        seqs.append(S)
+        mask = getattr(blk, "mask", None)
+        if mask is not None:
+            zero = float((mask == 0).sum().item()) / B                     # zero rows per image
+            lives.append(S - zero)
+            sparsity.append(zero / S)
+        else:
+            lives.append(S)
+    return model_flops(model, seqs, lives), (sum(sparsity) / len(sparsity) if sparsity else 0.0)

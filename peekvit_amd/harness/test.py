@@ -1,0 +1,69 @@
+"""Evaluation entry point, counterpart of validate/test.py:35-179: per budget - accuracy, images/sec with the REFERENCE's
+definition (len(dataset) / wall time of the whole loader loop incl. host->device copies, test.py:113-124) next to pure device
+time, FLOPs with the reference's conventions (peekvit_amd.flops) and sparsity.
+
+    python -m peekvit_amd.harness.test model=vit_b_16 test.test_batch_size=2048 dataset.val_size=4096 device=cuda:0
+"""
+from __future__ import annotations
+
+import json
+import sys
+import time
+from typing import List, Sequence
+
+import torch
+from torch.utils.data import DataLoader
+
+from .. import flops
+from . import checkpoint
+from .config import instantiate, load_config
+
+
+@torch.no_grad()
+def evaluate(model, loader, device, budgets: Sequence, n_images: int) -> List[dict]:
+    model.eval().to(device)
+    results = []
+    for budget in budgets:
+        if budget is not None and hasattr(model, "set_budget"):
+            model.set_budget(budget)
+        correct, dev_ms = 0, 0.0
+        start = time.time()
+        for batch, labels in loader:
+            batch, labels = batch.to(device), labels.to(device)
+            if device.type == "cuda":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = model(batch)
+            if device.type == "cuda":
+                e1.record()
+                e1.synchronize()
+                dev_ms += e0.elapsed_time(e1)
+            correct += int((out.argmax(1) == labels).sum().item())
+        elapsed = time.time() - start
+        fl, sparsity = flops.measured_flops(model, batch)
+        results.append({"budget": budget, "accuracy": correct / n_images, "images_per_second": n_images / elapsed,
+                        "device_images_per_second": n_images / (dev_ms * 1e-3) if dev_ms else None,
+                        "flops_per_image": fl, "sparsity": sparsity})
+    return results
+
+
+def main(argv: Sequence[str] = ()) -> List[dict]:
+    cfg = load_config("test_config", list(argv))
+    torch.manual_seed(cfg["seed"])
+    device = torch.device(cfg["device"])
+    dataset = instantiate(cfg["dataset"])
+    loader = DataLoader(dataset.val_dataset, batch_size=cfg["test"]["test_batch_size"], shuffle=False,
+                        num_workers=cfg["test"].get("num_workers", 0), pin_memory=device.type == "cuda")
+    if cfg.get("load_from"):
+        model, _ = checkpoint.load_state(checkpoint.get_checkpoint_path(cfg["load_from"]))
+    else:
+        model = instantiate(cfg["model"])
+    budgets = cfg["test"].get("budgets") or [None]
+    results = evaluate(model, loader, device, budgets, len(dataset.val_dataset))
+    for r in results:
+        print(json.dumps(r))
+    return results
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,79 @@
+"""Training entry point, counterpart of train/train.py:34-211: epochs of forward -> CrossEntropy -> backward ->
+[data-parallel gradient all-reduce] -> clip_grad_norm_(1.0) -> Adam step, validation and reference-format checkpoints.
+The forward/backward of a training step runs on the stock-op composite (autograd); the MI355X kernels serve evaluation.
+
+    python -m peekvit_amd.harness.train model=vit_tiny training.num_epochs=1 device=cpu
+    torchrun --nproc-per-node 8 -m peekvit_amd.harness.train model=vit_b_16 training.train_batch_size=1024 device=cuda
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from typing import Sequence
+
+import torch
+import torch.distributed as td
+from torch.utils.data import DataLoader
+
+from .. import dist as pdist
+from . import checkpoint
+from .config import instantiate, load_config
+from .test import evaluate
+
+
+def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool) -> float:
+    model.train()
+    loss_fn = torch.nn.CrossEntropyLoss()
+    last = float("nan")
+    for batch, labels in loader:
+        batch, labels = batch.to(device), labels.to(device)
+        if distributed:                                   # rank r trains on samples r::world of the global batch
+            batch, labels = pdist.shard_batch(batch), pdist.shard_batch(labels)
+        optimizer.zero_grad()
+        loss = loss_fn(model(batch), labels)
+        loss.backward()
+        if distributed:
+            pdist.allreduce_gradients(model.parameters())  # before the global-norm clip (train.py:120-121)
+        if clip:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        optimizer.step()
+        last = float(loss.item())
+    return last
+
+
+def main(argv: Sequence[str] = ()) -> dict:
+    cfg = load_config("train_config", list(argv))
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    device = torch.device(cfg["device"])
+    if distributed:
+        td.init_process_group("nccl" if device.type == "cuda" else "gloo")
+        if device.type == "cuda":
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(device)
+    torch.manual_seed(cfg["seed"])
+    dataset = instantiate(cfg["dataset"])
+    tr = cfg["training"]
+    loader = DataLoader(dataset.train_dataset, batch_size=tr["train_batch_size"], shuffle=False, num_workers=tr.get("num_workers", 0))
+    val_loader = DataLoader(dataset.val_dataset, batch_size=tr["eval_batch_size"], shuffle=False)
+    model = instantiate(cfg["model"]).to(device)
+    torch.nn.init.normal_(model.head.weight, std=0.02)        # the reference's zero head gives zero gradients to the trunk at step 0
+    optimizer = instantiate(cfg["optimizer"], params=model.parameters())
+    history = {"loss": [], "val_accuracy": []}
+    model_args = {k: v for k, v in cfg["model"].items() if k != "_target_"}
+    for epoch in range(tr["num_epochs"]):
+        history["loss"].append(train_epoch(model, loader, optimizer, device, tr.get("clip_grad_norm", 1.0), distributed))
+        if (epoch + 1) % tr.get("eval_every", 1) == 0:
+            budget = [1.0] if hasattr(model, "set_budget") and not getattr(model, "add_budget_token", False) else [None]
+            history["val_accuracy"].append(evaluate(model, val_loader, device, budget, len(dataset.val_dataset))[0]["accuracy"])
+        if cfg.get("experiment_dir") and (not distributed or td.get_rank() == 0):
+            history["checkpoint"] = checkpoint.save_state(cfg["experiment_dir"], model, model_args, epoch=epoch)
+    if not distributed or td.get_rank() == 0:
+        print(json.dumps(history))
+    if distributed:
+        td.destroy_process_group()
+    return history
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

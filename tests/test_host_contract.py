@@ -162,3 +162,32 @@ def test_flop_model_matches_baseline_table():
     assert abs(f("vit_tiny") - 2.800) < 2e-3 and abs(f("vit_small") - 6.171) < 2e-3 and abs(f("vit_b_16") - 35.128) < 2e-3
     seqs = [197] * 3 + [99] * 3 + [50] * 3 + [26] * 3
     assert abs(f("vit_b_16", seq_per_layer=seqs) - 16.508) < 5e-3
+
+
+def test_flop_accounting_conventions():
+    """peekvit_amd.flops restates utils/flops_count.py: 2*MACs, bias MACs counted, zero rows discounted, RankViT shrinks S."""
+    from peekvit_amd import flops
+    VT, RVT, ResVT = _models()
+    cfg = synth.MODEL_CONFIGS["vit_b_16"]
+    m = VT(**cfg)
+    f = flops.model_flops(m)
+    gemm_only = synth.fwd_flops_per_image(cfg)
+    assert gemm_only < f < 1.02 * gemm_only            # + biases, LayerNorms, softmax, q scaling: ~1 %
+    # Linear hook arithmetic on a known case: (in*out + out) * rows, x2
+    assert flops._linear_macs(10, 8, 4) == (8 * 4 + 4) * 10
+    # rank: fewer tokens -> fewer flops; budget 1 -> identical
+    r = RVT(**cfg, rankvit_layers=[3, 6, 9])
+    seqs = [197] * 3 + [99] * 3 + [50] * 3 + [26] * 3
+    assert flops.model_flops(r, seqs) < 0.5 * f and flops.model_flops(r) == f
+    # residual: zero rows are discounted, soft (non-zero) masks are not
+    mc = synth.MODEL_CONFIGS["vit_micro"]
+    extra = dict(gate_type="sigmoid", gate_bias=0, gate_temp=1, add_budget_token="learnable")
+    rs = ResVT(**mc, **extra).eval()
+    synth.load_synth_weights(rs, dict(mc, **extra), "residualvit")
+    rs.set_budget(0.5)
+    x = torch.from_numpy(synth.synth_images(2, mc["image_size"]))
+    fl, sp = flops.measured_flops(rs, x)
+    assert 0.5 < sp < 1.0 and fl < flops.model_flops(rs)
+    rs.set_budget(0.2)
+    fl2, sp2 = flops.measured_flops(rs, x)
+    assert sp2 < sp and fl2 > fl                       # golden: 81 % zeros at 0.2 vs 92 % at 0.5
