@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
+                    help="operand precision of the MFMA products: bf16 (headline) or split bf16x3 (meets the 1e-3 logits tolerance)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     return ap.parse_args()
 
@@ -122,7 +124,8 @@ def main():
             td.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
+    from peekvit_amd import engine
+    with torch.no_grad(), engine.precision(args.precision):
         for _ in range(args.warmup):
             out = model(x)
         barrier()
@@ -161,7 +164,7 @@ def main():
                       else f"images/sec {workload}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "gflop_per_image": round(flops_img / 1e9, 3)},
             "model_mfma_roofline_frac": round(value / world * flops_img / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),

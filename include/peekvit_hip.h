@@ -72,6 +72,10 @@ int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const flo
 #define PV_EPI_BIAS_RES_F32 2   /* out f32  = res[m,n] + row_scale[m]*(acc + bias[n])       [out-proj, fc2]    */
 #define PV_EPI_BIAS_POS_F32 3   /* out f32 row (m/rpi)*rpo+row_off+(m%rpi) = acc+bias[n]+pos[(row_off+m%rpi),n] [patch embed] */
 
+/* precision mode "bf16x3" (split operands concatenated along K): */
+#define PV_EPI_BIAS_F32 4             /* out f32 = (acc + bias[n]) * (n < qcols ? qscale : 1)           [in-proj, fp32 q|k|v]  */
+#define PV_EPI_BIAS_GELU_SPLIT_BF16 5 /* out bf16 [M, 3N] = [hi | lo | hi] of gelu_erf(acc + bias[n]), ldo >= 3N [MLP fc1]    */
+
 typedef struct pv_gemm_args {
     const uint16_t* A;       /* bf16 [M,K], row stride lda            (activations)                    */
     const uint16_t* W;       /* bf16 [N,K], row stride ldw            (nn.Linear weight layout (out,in)) */
@@ -113,6 +117,19 @@ int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
  * qkv: bf16 [B,S,3*H*dh] packed q|k|v (nn.MultiheadAttention in_proj layout), out: bf16 [B,S,H*dh].
  * dh in {32,48,64}, S <= 416. */
 int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
+
+/* ---- precision mode "bf16x3" (opt-in): split operands v = hi + lo, concatenated along K so that the
+ * SAME bf16 MFMA GEMM computes a_hi.w_hi + a_lo.w_hi + a_hi.w_lo; meets the 1e-3 logits tolerance at ~3x the GEMM work. ---- */
+
+/* fp32 [rows,K] -> bf16 [rows,3K]: order 0 = [hi | lo | hi] (activations), order 1 = [hi | hi | lo] (weights). K % 4 == 0. */
+int pv_split3_f32_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t K, int order, void* stream);
+/* pv_im2col_bf16 / pv_layernorm_bf16 writing [hi | lo | hi] rows of 3K / 3D. */
+int pv_im2col_split_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream);
+int pv_layernorm_split_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* row_scale,
+                            uint16_t* out, int64_t rows, int64_t D, float eps, void* stream);
+/* Attention core in exact fp32 (f32-input MFMA): qkv fp32 [B,S,3*H*dh] (q pre-scaled) -> out bf16 [B*S, 3*H*dh] in
+ * [hi | lo | hi] planes.  dh in {32,48,64}, S <= 208. */
+int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
 
 /* Final LayerNorm on the class-token rows only + sum over class tokens:
  *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.

@@ -20,6 +20,7 @@ from ._build import LIB
 _i64, _f32, _p, _i32 = C.c_int64, C.c_float, C.c_void_p, C.c_int32
 
 PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_BIAS_POS_F32 = 0, 1, 2, 3
+PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_SPLIT_BF16 = 4, 5
 
 
 class GemmArgs(C.Structure):
@@ -39,6 +40,10 @@ SIGNATURES = {
     "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "pv_im2col_u8_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p]),
+    "pv_split3_f32_bf16": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
+    "pv_im2col_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "pv_layernorm_split_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
+    "pv_attention_f32_split": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),

@@ -266,6 +266,149 @@ static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Precision mode ("bf16x3"): the same attention in exact fp32 on the f32-input MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the
+// bf16 rate - attention is 4 % of the model's FLOPs).  qkv fp32 [B,S,3D] -> out bf16 [B*S, 3D] = [hi | lo | hi] planes (the
+// split A operand of the out-proj GEMM).  Same swapped S^T = K.Q^T layout: lane (g, q) holds keys 4g+r of a 16-key tile, so
+// at PV step s the lane group g contributes key 4g+s on both operands (A = V[key][d], B = its own P register s).
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NKT>
+__global__ __launch_bounds__(256) void pv_attn_f32_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
+    constexpr int RS = DH + 1;            // padded LDS row (floats): breaks the power-of-two stride
+    constexpr int SP = NKT * 16;
+    constexpr int NDT = DH / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + SP * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const float* qb = qkv + (int64_t)b * S * ld + h * DH;
+    for (int e = tid; e < SP * (DH / 4); e += 256) {
+        const int row = e / (DH / 4), c4 = (e - row * (DH / 4)) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (row < S) {
+            kv = *reinterpret_cast<const float4*>(qb + (int64_t)row * ld + D + c4);
+            vv = *reinterpret_cast<const float4*>(qb + (int64_t)row * ld + 2 * D + c4);
+        }
+        float* kd = Ks + row * RS + c4;
+        float* vd = Vs + row * RS + c4;
+        kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+        vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+    }
+    __syncthreads();
+    const int nqt = (S + 15) >> 4;
+    for (int qt = wid; qt < nqt; qt += 4) {
+        const int q0 = qt << 4;
+        int qr = q0 + i16; qr = qr < S ? qr : S - 1;
+        float qv[DH / 4];                  // B operand: Q[q][4*step + g]
+#pragma unroll
+        for (int st = 0; st < DH / 4; ++st) qv[st] = qb[(int64_t)qr * ld + 4 * st + g];
+        f32x4 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < DH / 4; ++st) a = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(kt * 16 + i16) * RS + 4 * st + g], qv[st], a, 0, 0, 0);
+            sc[kt] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = expf(sc[kt][r] - m);
+                sc[kt][r] = pe;
+                l += pe;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + st) * RS + dt * 16 + i16], sc[kt][st], o[dt], 0, 0, 0);
+        if (q0 + i16 < S) {
+            const float inv = 1.0f / l;
+            uint16_t* op = out + ((int64_t)b * S + q0 + i16) * 3 * D + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const PvHiLo s0 = pv_split2(o[dt][0] * inv, o[dt][1] * inv), s1 = pv_split2(o[dt][2] * inv, o[dt][3] * inv);
+                *reinterpret_cast<u32x2*>(op + dt * 16) = (u32x2){s0.hi, s1.hi};
+                *reinterpret_cast<u32x2*>(op + dt * 16 + D) = (u32x2){s0.lo, s1.lo};
+                *reinterpret_cast<u32x2*>(op + dt * 16 + 2 * D) = (u32x2){s0.hi, s1.hi};
+            }
+        }
+    }
+}
+
+template <int DH, int NKT>
+static int pv_launch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    constexpr int lds = 2 * NKT * 16 * (DH + 1) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_f32_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    PV_LAUNCH((pv_attn_f32_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    return pv_check_launch();
+}
+
+template <int DH>
+static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_f32<DH, N>(qkv, out, B, S, H, stream);
+        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
+        default: break;
+    }
+    if constexpr (DH == 32) {                   // fp32 K and V of one head must fit the LDS: S <= 208 at dh = 64/48, <= 416 at dh = 32
+        switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_f32<DH, N>(qkv, out, B, S, H, stream);
+            PV_ATTN_CASE(14) PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20)
+            PV_ATTN_CASE(21) PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
+#undef PV_ATTN_CASE
+            default: break;
+        }
+    }
+    return PV_ERR_UNSUPPORTED;
+}
+#if 0
+    {
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+#endif
+
+extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
+    if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return PV_ERR_INVALID_ARG;
+    if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 32: return pv_dispatch_attn_f32<32>(qkv, out, B, (int)S, (int)H, s);
+        case 48: return pv_dispatch_attn_f32<48>(qkv, out, B, (int)S, (int)H, s);
+        case 64: return pv_dispatch_attn_f32<64>(qkv, out, B, (int)S, (int)H, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return PV_ERR_INVALID_ARG;

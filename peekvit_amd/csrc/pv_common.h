@@ -26,6 +26,16 @@ __device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
     const pv_f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// split-precision helpers (precision mode "bf16x3"): v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi)
+struct PvHiLo { uint32_t hi, lo; };
+__device__ __forceinline__ PvHiLo pv_split2(float a, float b) {
+    PvHiLo r;
+    r.hi = pv_pack_bf16x2(a, b);
+    const float ah = __builtin_bit_cast(float, r.hi << 16), bh = __builtin_bit_cast(float, r.hi & 0xffff0000u);
+    r.lo = pv_pack_bf16x2(a - ah, b - bh);
+    return r;
+}
+
 __device__ __forceinline__ float pv_bf2f(uint16_t b) {
     return __builtin_bit_cast(float, (uint32_t)b << 16);
 }

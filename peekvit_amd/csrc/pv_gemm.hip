@@ -95,6 +95,16 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.ldr + n);
         float4 o = make_float4(fmaf(s, v0, r.x), fmaf(s, v1, r.y), fmaf(s, v2, r.z), fmaf(s, v3, r.w));
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = o;
+    } else if (EPI == PV_EPI_BIAS_F32) {
+        const float s = n < p.qcols ? p.qscale : 1.0f;
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0 * s, v1 * s, v2 * s, v3 * s);
+    } else if (EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
+        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const PvHiLo a = pv_split2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), b = pv_split2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab));
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
+        *reinterpret_cast<u32x2*>(o) = (u32x2){a.hi, b.hi};
+        *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){a.lo, b.lo};
+        *reinterpret_cast<u32x2*>(o + 2 * p.N) = (u32x2){a.hi, b.hi};
     } else {   // PV_EPI_BIAS_POS_F32
         const int img = m / p.rpi, pi = m - img * p.rpi;
         const int64_t orow = (int64_t)img * p.rpo + p.row_off + pi;
@@ -368,7 +378,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
     PV_STAMP(0);
-    if (EPI == PV_EPI_BIAS_GELU_BF16) {
+    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
         // GELU table (32 KiB) into the LDS above the staging buffers: the OLDEST operations of the kernel, so every later
         // counted wait covers them and nothing else changes
 #pragma unroll
@@ -402,37 +412,66 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
     const int g = lane >> 4, i16 = lane & 15;
-    if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) {
-        // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7)
+    if (EPI == PV_EPI_BIAS_BF16 || (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16)) {
+        // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7).  SPLIT (precision mode): the fp32
+        // results stay in the accumulators; pass 0 stores their bf16 "hi" image to planes 0 and 2 of the [M, 3N] output, pass 1
+        // the "lo" image (v - hi) to plane 1.
+        constexpr bool SPLIT = EPI == PV_EPI_BIAS_GELU_SPLIT_BF16;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int row = wr * 128 + mt * 16 + i16;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
-                // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
-                const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
-                u32x4 pk;
-                if (EPI == PV_EPI_BIAS_GELU_BF16) {
-                    const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
-                    pk = (u32x4){pv_pack_bf16x2(pv_gelu_lut(lo[0], tab), pv_gelu_lut(lo[1], tab)), pv_pack_bf16x2(pv_gelu_lut(lo[2], tab), pv_gelu_lut(lo[3], tab)),
-                                 pv_pack_bf16x2(pv_gelu_lut(hi[0], tab), pv_gelu_lut(hi[1], tab)), pv_pack_bf16x2(pv_gelu_lut(hi[2], tab), pv_gelu_lut(hi[3], tab))};
-                } else {
-                    pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
-                                 pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
-                }
-                const int c = wc * 8 + u * 4 + g;
-                *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+        for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+            if (pass == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // pass 0's image has been read by every wave
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = wid * 32 + 2 * j + (lane >> 5);
-            const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
-            if (m0 + row < p.M && n0 + (lane & 31) * 8 < p.N) *reinterpret_cast<u32x4*>(ob + (int64_t)(m0 + row) * p.ldo) = v;
+            for (int mt = 0; mt < 8; ++mt) {
+                const int row = wr * 128 + mt * 16 + i16;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
+                    // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
+                    const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
+                    u32x4 pk;
+                    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
+                        if (pass == 0) {
+                            const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
+                            if (SPLIT) { acc[2 * u][mt] = lo; acc[2 * u + 1][mt] = hi; }
+                        }
+                        if (SPLIT) {
+                            const PvHiLo s0 = pv_split2(lo[0], lo[1]), s1 = pv_split2(lo[2], lo[3]), s2 = pv_split2(hi[0], hi[1]), s3 = pv_split2(hi[2], hi[3]);
+                            pk = pass == 0 ? (u32x4){s0.hi, s1.hi, s2.hi, s3.hi} : (u32x4){s0.lo, s1.lo, s2.lo, s3.lo};
+                        } else {
+                            pk = (u32x4){pv_pack_bf16x2(lo[0], lo[1]), pv_pack_bf16x2(lo[2], lo[3]), pv_pack_bf16x2(hi[0], hi[1]), pv_pack_bf16x2(hi[2], hi[3])};
+                        }
+                    } else {
+                        pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
+                                     pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
+                    }
+                    const int c = wc * 8 + u * 4 + g;
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = wid * 32 + 2 * j + (lane >> 5);
+                const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
+                if (m0 + row < p.M && n0 + (lane & 31) * 8 < p.N) {
+                    uint16_t* o = ob + (int64_t)(m0 + row) * p.ldo;
+                    if (!SPLIT) {
+                        *reinterpret_cast<u32x4*>(o) = v;
+                    } else if (pass == 0) {
+                        *reinterpret_cast<u32x4*>(o) = v;
+                        *reinterpret_cast<u32x4*>(o + 2 * p.N) = v;
+                    } else {
+                        *reinterpret_cast<u32x4*>(o + p.N) = v;
+                    }
+                }
+            }
         }
     } else {
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
@@ -447,7 +486,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             for (int j = 0; j < 16; ++j) {
                 int m = m0 + ps * 128 + wid * 16 + j;
                 m = m < p.M ? m : p.M - 1;
-                if (EPI == PV_EPI_BIAS_RES_F32) {
+                if (EPI == PV_EPI_BIAS_F32) {
+                    orow[j] = m;
+                    rr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     orow[j] = m;
                     rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
                 } else {
@@ -477,7 +519,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 float sc = 1.0f;
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) sc = p.row_scale[orow[j]];
                 f32x4 o;
-                if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
+                if (EPI == PV_EPI_BIAS_F32) {
+                    const float qs = ncol < p.qcols ? p.qscale : 1.0f;
+                    o = (f32x4){v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs};
+                } else if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
                 else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
                 if (m0 + ps * 128 + row < p.M && col_ok)
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
@@ -582,7 +627,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static bool attr_set = false;
-    constexpr int lds = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
+    constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
@@ -636,10 +681,10 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     const int tn256 = (p.N + G2_BN - 1) / G2_BN;
     const bool n_ok = p.N % 128 == 0 && (int64_t)tn256 * G2_BN * 3 <= (int64_t)p.N * 4;
     // (the 256^2 epilogue applies the q-scale per 8-column chunk, the 128^2 one per 4 columns)
-    const bool big = !(a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % 8) &&
+    const bool big = !((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 8) &&
                      (force == 256 || (force != 128 && n_ok && p.K % (2 * G2_BK) == 0 && p.M >= 2048));
     if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
-    if (a->epilogue == PV_EPI_BIAS_BF16 && p.qcols % 4) return PV_ERR_UNSUPPORTED;
+    if ((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
     p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
@@ -655,6 +700,10 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
         case PV_EPI_BIAS_GELU_BF16: return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_BF16>(p, s);
         case PV_EPI_BIAS_RES_F32: return big ? pv_launch_gemm256<PV_EPI_BIAS_RES_F32>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_RES_F32>(p, s);
         case PV_EPI_BIAS_POS_F32: return big ? pv_launch_gemm256<PV_EPI_BIAS_POS_F32>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_POS_F32>(p, s);
+        case PV_EPI_BIAS_F32: return big ? pv_launch_gemm256<PV_EPI_BIAS_F32>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_F32>(p, s);
+        case PV_EPI_BIAS_GELU_SPLIT_BF16:
+            if (a->ldo < 3 * a->N) return PV_ERR_INVALID_ARG;
+            return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_SPLIT_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_SPLIT_BF16>(p, s);
         default: return PV_ERR_INVALID_ARG;
     }
 }

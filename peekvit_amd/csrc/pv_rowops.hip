@@ -28,9 +28,38 @@ extern "C" int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-precision packing (precision mode "bf16x3"): src fp32 [rows, K] -> dst bf16 [rows, 3K]
+//   order 0 (activations): [hi | lo | hi]      order 1 (weights): [hi | hi | lo]
+// so that dst_act . dst_w^T = a_hi.w_hi + a_lo.w_hi + a_hi.w_lo  - the plain bf16 MFMA GEMM at 3K gives ~fp32 products.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_split3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t rows, int K, int order) {
+    const int K4 = K >> 2;
+    const int64_t total = rows * K4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / K4;
+        const int k = (int)(idx - r * K4) << 2;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * K + k);
+        u32x2 hi, lo;
+        { const PvHiLo t_ = pv_split2(v.x, v.y); hi[0] = t_.hi; lo[0] = t_.lo; }
+        { const PvHiLo t_ = pv_split2(v.z, v.w); hi[1] = t_.hi; lo[1] = t_.lo; }
+        uint16_t* d = dst + r * 3 * (int64_t)K + k;
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + K) = order == 0 ? lo : hi;
+        *reinterpret_cast<u32x2*>(d + 2 * K) = order == 0 ? hi : lo;
+    }
+}
+
+extern "C" int pv_split3_f32_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t K, int order, void* stream) {
+    if (!src || !dst || rows <= 0 || K <= 0 || (order != 0 && order != 1)) return PV_ERR_INVALID_ARG;
+    if (K % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_split3_kernel, dim3(pv_stream_grid(rows * (K / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, (int)K, order);
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // im2col for the stride-P / kernel-P patch convolution (models/vit.py:212)
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict__ x, uint16_t* __restrict__ cols, int64_t B, int C,
                                                         int H, int W, int P) {
     const int Hp = H / P, Wp = W / P, Np = Hp * Wp, K = C * P * P;
@@ -45,8 +74,18 @@ __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict_
             int pi = (int)(m - b * Np), ph = pi / Wp, pw = pi - ph * Wp;
             const float* s = x + ((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw;
             float4 a = reinterpret_cast<const float4*>(s)[0], d = reinterpret_cast<const float4*>(s)[1];
-            u32x4 o = {pv_pack_bf16x2(a.x, a.y), pv_pack_bf16x2(a.z, a.w), pv_pack_bf16x2(d.x, d.y), pv_pack_bf16x2(d.z, d.w)};
-            reinterpret_cast<u32x4*>(cols)[idx] = o;
+            if (SPLIT) {          // [hi | lo | hi] rows of 3K
+                u32x4 hi, lo;
+                { const PvHiLo t_ = pv_split2(a.x, a.y); hi[0] = t_.hi; lo[0] = t_.lo; } { const PvHiLo t_ = pv_split2(a.z, a.w); hi[1] = t_.hi; lo[1] = t_.lo; }
+                { const PvHiLo t_ = pv_split2(d.x, d.y); hi[2] = t_.hi; lo[2] = t_.lo; } { const PvHiLo t_ = pv_split2(d.z, d.w); hi[3] = t_.hi; lo[3] = t_.lo; }
+                uint16_t* o = cols + m * 3 * (int64_t)K + k;
+                *reinterpret_cast<u32x4*>(o) = hi;
+                *reinterpret_cast<u32x4*>(o + K) = lo;
+                *reinterpret_cast<u32x4*>(o + 2 * K) = hi;
+            } else {
+                u32x4 o = {pv_pack_bf16x2(a.x, a.y), pv_pack_bf16x2(a.z, a.w), pv_pack_bf16x2(d.x, d.y), pv_pack_bf16x2(d.z, d.w)};
+                reinterpret_cast<u32x4*>(cols)[idx] = o;
+            }
         }
     } else {
         const int64_t total = B * (int64_t)Np * K;
@@ -59,6 +98,14 @@ __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict_
             cols[idx] = pv_f2bf(x[((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw]);
         }
     }
+}
+
+extern "C" int pv_im2col_split_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream) {
+    if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || H % P || W % P) return PV_ERR_INVALID_ARG;
+    if (P % 8 || W % 4 || ((uintptr_t)x & 15) || ((uintptr_t)cols & 15)) return PV_ERR_UNSUPPORTED;
+    const int64_t work = B * (H / P) * (W / P) * (C * P * P / 8);
+    PV_LAUNCH((pv_im2col_kernel<true, true>), dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+    return pv_check_launch();
 }
 
 extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream) {
@@ -144,7 +191,7 @@ extern "C" int pv_token_prologue(float* tokens, const float* special, const floa
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (one wave per row; the row stays in registers: two-pass mean / variance in fp32)
 // ------------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pv_layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ row_scale,
                                                            uint16_t* __restrict__ out, int64_t rows, int D, float eps) {
@@ -154,13 +201,22 @@ __global__ __launch_bounds__(256) void pv_layernorm_kernel(const float* __restri
         pv_load_row<NCH>(r, x + row * ldx, nvec, lane);
         pv_ln_row<NCH>(r, gamma, beta, D, nvec, lane, eps);
         const float sc = row_scale ? row_scale[row] : 1.0f;
-        u32x2* o = reinterpret_cast<u32x2*>(out + row * (int64_t)D);
+        u32x2* o = reinterpret_cast<u32x2*>(out + row * (int64_t)D * (SPLIT ? 3 : 1));
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             int idx = lane + 64 * j;
             if (idx < nvec) {
-                u32x2 p = {pv_pack_bf16x2(r.v[j].x * sc, r.v[j].y * sc), pv_pack_bf16x2(r.v[j].z * sc, r.v[j].w * sc)};
-                o[idx] = p;
+                if (SPLIT) {      // [hi | lo | hi] rows of 3D
+                    u32x2 hi, lo;
+                    { const PvHiLo t_ = pv_split2(r.v[j].x * sc, r.v[j].y * sc); hi[0] = t_.hi; lo[0] = t_.lo; }
+                    { const PvHiLo t_ = pv_split2(r.v[j].z * sc, r.v[j].w * sc); hi[1] = t_.hi; lo[1] = t_.lo; }
+                    o[idx] = hi;
+                    o[idx + nvec] = lo;
+                    o[idx + 2 * nvec] = hi;
+                } else {
+                    u32x2 p = {pv_pack_bf16x2(r.v[j].x * sc, r.v[j].y * sc), pv_pack_bf16x2(r.v[j].z * sc, r.v[j].w * sc)};
+                    o[idx] = p;
+                }
             }
         }
     }
@@ -176,6 +232,18 @@ __global__ __launch_bounds__(256) void pv_layernorm_kernel(const float* __restri
         else if (nch_ <= 8) { MACRO(8); }  \
         else { MACRO(16); }                \
     } while (0)
+
+extern "C" int pv_layernorm_split_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* row_scale, uint16_t* out,
+                                       int64_t rows, int64_t D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
+    if (ldx % 4 || ldx < D || ((uintptr_t)x & 15) || ((uintptr_t)out & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return PV_ERR_INVALID_ARG;
+    dim3 grid(pv_stream_grid(rows, 4));
+#define LNS_LAUNCH(N) PV_LAUNCH((pv_layernorm_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
+    PV_DISPATCH_NCH(D, LNS_LAUNCH);
+#undef LNS_LAUNCH
+    return pv_check_launch();
+}
 
 extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* row_scale, uint16_t* out,
                                  int64_t rows, int64_t D, float eps, void* stream) {

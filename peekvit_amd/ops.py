@@ -194,6 +194,46 @@ def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
     return logits
 
 
+# ---- precision mode "bf16x3" ---------------------------------------------------------------------------------------
+def split3(src: torch.Tensor, order: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [rows,K] -> bf16 [rows,3K]: order 0 = [hi|lo|hi] (activations), 1 = [hi|hi|lo] (weights)."""
+    _chk(src, torch.float32, "src")
+    rows, K = src.shape
+    if out is None:
+        out = torch.empty((rows, 3 * K), dtype=torch.bfloat16, device=src.device)
+    with _timed("pv_split3_f32_bf16", src.device, 0.0, 10.0 * src.numel()):
+        check(_lib.load().pv_split3_f32_bf16(_ptr(src), _ptr(out), rows, K, order, _stream(src)), "pv_split3_f32_bf16")
+    _count()
+    return out
+
+
+def im2col_split(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    B, Cc, H, W = x.shape
+    with _timed("pv_im2col_split_bf16", x.device, 0.0, 10.0 * x.numel()):
+        check(_lib.load().pv_im2col_split_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _stream(x)), "pv_im2col_split_bf16")
+    _count()
+    return out
+
+
+def layernorm_split(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, row_scale=None):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    with _timed("pv_layernorm_split_bf16", x.device, 0.0, 10.0 * x.numel()):
+        check(_lib.load().pv_layernorm_split_bf16(_ptr(x), D, _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(out), rows, D,
+                                                  float(eps), _stream(x)), "pv_layernorm_split_bf16")
+    _count()
+    return out
+
+
+def attention_f32(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
+    _chk(qkv, torch.float32, "qkv")
+    with _timed("pv_attention_f32_split", qkv.device, 4.0 * B * H * S * S * dh, 18.0 * B * S * H * dh):
+        check(_lib.load().pv_attention_f32_split(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_f32_split")
+    _count()
+    return out
+
+
 def token_norm(x: torch.Tensor) -> torch.Tensor:
     B, S, D = x.shape
     norms = torch.empty((B, S - 1), dtype=torch.float32, device=x.device)

@@ -1,0 +1,28 @@
+"""Accuracy / throughput of the two operand-precision modes against the reference's golden fp32 logits."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from peekvit_amd import synth, engine
+from peekvit_amd.models.vit import VisionTransformer
+gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))
+for name in ("vit_micro", "vit_tiny", "vit_small", "vit_b_16"):
+    cfg = synth.MODEL_CONFIGS[name]
+    m = VisionTransformer(**cfg); synth.load_synth_weights(m, cfg); m = m.eval().cuda()
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"])).cuda()
+    g = np.load(os.path.join(gold, name + ".npz"))["logits"]
+    with torch.no_grad():
+        a = m(x).cpu().numpy()
+        with engine.precision("bf16x3"):
+            b = m(x).cpu().numpy()
+    print(f"{name:10s} rel-L2 logits error vs reference fp32:  bf16 {rel(a, g):.2e}   bf16x3 {rel(b, g):.2e}")
+cfg = synth.MODEL_CONFIGS["vit_b_16"]
+m = VisionTransformer(**cfg); synth.load_synth_weights(m, cfg); m = m.eval().cuda()
+x = torch.randn(2048, 3, 224, 224, device="cuda")
+for mode in ("bf16", "bf16x3"):
+    with torch.no_grad(), engine.precision(mode):
+        for _ in range(2): m(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): m(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    print(f"ViT-B/16 B=2048 {mode}: {dt*1e3:.1f} ms/forward  {2048/dt:.0f} img/s")

@@ -1,0 +1,108 @@
+"""Precision mode "bf16x3" (opt-in): split operands concatenated along K on the same MFMA GEMM + exact-fp32 attention.
+It meets BASELINE.json's tolerance - logits within 1e-3 (relative L2) of the REFERENCE's fp32 logits - which plain bf16
+operands cannot (4e-3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from peekvit_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_NORTH_STAR = 1e-3
+
+
+def T(name, shape, kind="normal", scale=1.0, shift=0.0):
+    return torch.from_numpy(synth.tensor("px/" + name, shape, kind, scale, shift, seed=2, bf16=False))
+
+
+def test_split3_layout_and_accuracy():
+    from peekvit_amd import ops
+    v = T("v", (37, 64), scale=3.0)
+    for order in (0, 1):
+        s = ops.split3(v.to(DEV), order).float().cpu()
+        hi, lo = s[:, :64], (s[:, 64:128] if order == 0 else s[:, 128:])
+        assert torch.equal(hi, v.to(torch.bfloat16).float())
+        assert torch.equal(s[:, 128:] if order == 0 else s[:, 64:128], hi)
+        assert ((hi + lo).double() - v.double()).abs().max() <= 2.0 ** -16 * v.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 128, 64), (2304, 768, 768), (2100, 768, 256)])
+def test_gemm_x3_products_are_fp32_accurate(M, N, K):
+    from peekvit_amd import ops
+    from peekvit_amd._lib import PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_SPLIT_BF16, PV_EPI_BIAS_RES_F32
+    a, w = T(f"a{M}{K}", (M, K)), T(f"w{N}{K}", (N, K), "uniform", 1.0 / math.sqrt(K))
+    bias, res = T(f"b{N}", (N,), "uniform", 0.1).to(DEV), T(f"r{M}{N}", (M, N)).to(DEV)
+    a3, w3 = ops.split3(a.to(DEV), 0), ops.split3(w.to(DEV), 1)
+    ref = a.double() @ w.double().t() + bias.cpu().double()
+    o = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a3, w3, bias, o, PV_EPI_BIAS_RES_F32, res=res)
+    assert rel_l2(o.cpu(), ref + res.cpu().double()) < 2e-5          # plain bf16 operands: ~3e-3
+    qc = (N // 3) // 8 * 8
+    ops.gemm(a3, w3, bias, o, PV_EPI_BIAS_F32, qcols=qc, qscale=0.125)
+    r = ref.clone(); r[:, :qc] *= 0.125
+    assert rel_l2(o.cpu(), r) < 2e-5
+    g3 = torch.empty((M, 3 * N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a3, w3, bias, g3, PV_EPI_BIAS_GELU_SPLIT_BF16)
+    g = g3.float().cpu()
+    assert torch.equal(g[:, :N], g[:, 2 * N:])
+    assert rel_l2(g[:, :N].double() + g[:, N:2 * N].double(), torch.nn.functional.gelu(ref)) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 197, 12, 64), (1, 401, 8, 32), (2, 197, 8, 48), (2, 26, 3, 64), (1, 5, 2, 32)])
+def test_attention_f32(B, S, H, dh):
+    from peekvit_amd import ops
+    D = H * dh
+    qkv = T(f"qkv{S}{H}{dh}", (B, S, 3 * D))
+    qkv[..., :D] *= dh ** -0.5
+    out = torch.empty((B * S, 3 * D), dtype=torch.bfloat16, device=DEV)
+    ops.attention_f32(qkv.to(DEV).contiguous(), out, B, S, H, dh)
+    q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2).double() for t in qkv.split(D, dim=-1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * S, D)
+    o = out.float().cpu()
+    assert torch.equal(o[:, :D], o[:, 2 * D:])
+    assert rel_l2(o[:, :D].double() + o[:, D:2 * D].double(), ref) < 1e-5
+
+
+def _model(kind, name, **extra):
+    from peekvit_amd.models.vit import VisionTransformer
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    cfg = synth.MODEL_CONFIGS[name]
+    cls = dict(vit=VisionTransformer, rank=RankVisionTransformer, res=ResidualVisionTransformer)[kind]
+    m = cls(**cfg, **extra)
+    synth.load_synth_weights(m, dict(cfg, **extra), "residualvit" if kind == "res" else "vit", seed=0)
+    return cfg, m.eval().to(DEV)
+
+
+@pytest.mark.parametrize("name", ["vit_micro", "vit_tiny", "vit_small", "vit_b_16"])
+def test_logits_within_north_star_tolerance_of_reference(golden, name):
+    from peekvit_amd import engine
+    cfg, m = _model("vit", name)
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    with torch.no_grad(), engine.precision("bf16x3"):
+        logits = m(x).cpu().numpy()
+    err = rel_l2(logits, golden(name)["logits"])               # golden = the REAL reference's fp32 logits
+    assert err < TOL_NORTH_STAR, err
+
+
+def test_rankvit_and_residualvit_within_tolerance(golden):
+    from peekvit_amd import engine
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    m.set_budget(0.5)
+    with torch.no_grad(), engine.precision("bf16x3"):
+        logits = m(x).cpu().numpy()
+    g = golden("rankvit")
+    for li in (3, 6, 9):          # with fp32-accurate layers the END-TO-END keep indices match the reference bit for bit
+        assert np.array_equal(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), g[f"vit_b_16_b0.5_keep{li}"])
+    assert rel_l2(logits, g["vit_b_16_b0.5_logits"]) < TOL_NORTH_STAR
+    extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5)
+    cfg, m = _model("res", "vit_b_16", **extra)
+    m.set_budget(0.5)
+    with torch.no_grad(), engine.precision("bf16x3"):
+        logits = m(x).cpu().numpy()
+    assert rel_l2(logits, golden("residualvit")["vit_b_16_b0.5_logits"]) < TOL_NORTH_STAR

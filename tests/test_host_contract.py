@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
-    assert lib.pv_version() == 2 and lib.pv_arch() == b"gfx950"
+    assert lib.pv_version() == 3 and lib.pv_arch() == b"gfx950"
     assert b"launch" in lib.pv_error_string(-3)
 
 
