@@ -128,18 +128,27 @@ def main():
     with torch.no_grad(), engine.precision(args.precision):
         for _ in range(args.warmup):
             out = model(x)
+        # (1) the contract's timed region: exactly K steps between barrier + synchronize, nothing else on the stream
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # (2) the same K steps again with two HIP events around EVERY launch (on the launch stream) for the per-kernel
+        # roofline numbers; the ~200 extra stream commands per step cost ~3 %, which is why (1) is timed without them
         barrier()
         with ops.KernelTimer() as kt:
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             for _ in range(args.steps):
                 out = model(x)
             barrier()
-            elapsed = time.perf_counter() - t0
+            elapsed_instr = time.perf_counter() - t1
     assert torch.isfinite(out).all()
     if dist:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_instr], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_instr = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
@@ -155,6 +164,20 @@ def main():
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         roof["launches_per_step"] = d["launches"] // args.steps
         roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)
+        roof["algorithmic_per_launch"] = round((d["flops"] if d["flops"] > 0 else d["bytes"]) / d["launches"] / (1e12 if d["flops"] > 0 else 1e9), 4)
+        # HBM/fabric bytes per launch of this kernel from the committed PMC passes of this same command (separate FETCH_SIZE /
+        # WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r01_kernel_summary.json
+        try:
+            summ = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_summary.json")))["kernels"]
+            fam = [v for k, v in summ.items() if k.startswith(dom.replace("_bf16", "").replace("pv_", "pv_")) and "hbm_read_MB" in v]
+            if dom == "pv_gemm_bf16":
+                fam = [v for k, v in summ.items() if k.startswith("pv_gemm") and "hbm_read_MB" in v]
+            if fam and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None:
+                n = sum(v["launches"] for v in fam)
+                roof["traffic"] = round(sum((v["hbm_read_MB"] + v["hbm_write_MB"]) * 1e6 * v["launches"] for v in fam) / n)
+                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted mean over the GEMM variants)"
+        except (OSError, KeyError, ValueError):
+            pass
         kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                        "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
@@ -163,7 +186,8 @@ def main():
             "metric": "images/sec ViT-B/16 fwd @ batch 2048, 224x224" if args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None
                       else f"images/sec {workload}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_instrumented": round(elapsed_instr / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "gflop_per_image": round(flops_img / 1e9, 3)},
