@@ -101,6 +101,10 @@ typedef struct pv_gemm_args {
     const float* ln_row_scale; /* fp32 [M] or NULL                                                      */
     uint16_t* ln_out;          /* bf16 [M,N] contiguous, or NULL (no fused LayerNorm)                   */
     float ln_eps;
+    /* split-K for weight gradients (ABI v4): ksplit > 1 with PV_EPI_BIAS_F32 makes the launch compute `ksplit` partial
+     * products over K slices of K/ksplit (K % (64*ksplit) == 0) into out[t] = out + t*M*ldo (fp32), bias added by slice 0;
+     * pv_sum_slices_f32 reduces them.  dW = dY^T . X (train.py:118 loss.backward()) = this GEMM on transposed activations. */
+    int32_t ksplit;
 } pv_gemm_args;
 
 /* out = epilogue(A . W^T): bf16 MFMA operands, fp32 accumulation.  Replaces the addmm/mm behind
@@ -130,6 +134,15 @@ int pv_layernorm_split_bf16(const float* x, int64_t ldx, const float* gamma, con
 /* Attention core in exact fp32 (f32-input MFMA): qkv fp32 [B,S,3*H*dh] (q pre-scaled) -> out bf16 [B*S, 3*H*dh] in
  * [hi | lo | hi] planes.  dh in {32,48,64}, S <= 208. */
 int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
+
+/* ---- backward building blocks (SURVEY.md section 2b "B*": what train/train.py:118 `loss.backward()` needs) ---- */
+
+/* out[n] (+)= sum_t partials[t*n_elems + n]: reduces split-K slices (accumulate != 0 adds to the existing out). fp32. */
+int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream);
+/* bf16 [R,C] row-major -> bf16 [C,R] (ldo = R): K-contiguous operands for dW = (dY^T) . (X^T)^T. R, C % 8 == 0 not required. */
+int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, void* stream);
+/* Column sums of a bf16 or fp32 [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]); ws: fp32 [ceil(R/1024)*C]. */
+int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 
 /* Final LayerNorm on the class-token rows only + sum over class tokens:
  *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.

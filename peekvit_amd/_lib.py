@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("M", _i64), ("N", _i64), ("K", _i64), ("lda", _i64), ("ldw", _i64), ("ldo", _i64), ("ldr", _i64),
                 ("rows_per_img_in", _i64), ("rows_per_img_out", _i64), ("row_off", _i64), ("qcols", _i64),
                 ("qscale", _f32), ("epilogue", _i32),
-                ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32)]
+                ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32),
+                ("ksplit", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
@@ -44,6 +45,9 @@ SIGNATURES = {
     "pv_im2col_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_split_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_attention_f32_split": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_sum_slices_f32": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
+    "pv_transpose_bf16": (C.c_int, [_p, _p, _i64, _i64, _p]),
+    "pv_colsum_f32": (C.c_int, [_p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p]),
     "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),

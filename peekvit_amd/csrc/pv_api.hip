@@ -1,7 +1,7 @@
 // ABI identification and error strings of libpeekvit_hip.so.
 #include "pv_common.h"
 
-extern "C" int pv_version(void) { return 3; }
+extern "C" int pv_version(void) { return 4; }
 extern "C" const char* pv_arch(void) { return "gfx950"; }
 extern "C" const char* pv_error_string(int code) {
     switch (code) {

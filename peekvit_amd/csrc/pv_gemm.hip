@@ -39,6 +39,9 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
+    int ksplit;                // split-K (wgrad): blocks [t*ntiles, (t+1)*ntiles) compute K slice t into out + t*split_stride
+    int k_slice;
+    int64_t split_stride;      // elements of `out` between consecutive slices
     const float* ln_gamma;     // fused LayerNorm of the finished output rows (row-block kernel): out rows -> ln_out bf16
     const float* ln_beta;
     const float* ln_row_scale;
@@ -121,13 +124,21 @@ constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 64;
 constexpr int G1_TILE_BYTES = G1_BM * G1_BK * 2;   // 16 KiB per operand per stage
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p) {
+__global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
 
-    const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    GemmDev p = p_in;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int slice = blockIdx.x / ntiles;                       // split-K slice (0 when ksplit <= 1)
+    if (p.ksplit > 1) {
+        p.A += (int64_t)slice * p.k_slice; p.W += (int64_t)slice * p.k_slice; p.K = p.k_slice;
+        p.out = reinterpret_cast<float*>(p.out) + slice * p.split_stride;
+        if (slice) p.bias = nullptr;
+    }
+    const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * G1_BM, n0 = tn * G1_BN;
 
@@ -220,7 +231,7 @@ static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm128_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, stream, p);
+    PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(256), lds, stream, p);
     return pv_check_launch();
 }
 
@@ -537,11 +548,19 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p) {
+__global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // tile order: every XCD walks a contiguous range of a list in which groups of `gm` M-blocks are swept with n as the slow
     // index, so the ~32 co-running blocks of an XCD touch gm A panels and ~32/gm weight tiles at a time (L2 = 4 MiB per XCD)
-    const int tile = pv_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    GemmDev p = p_in;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int slice = blockIdx.x / ntiles;                       // split-K slice (0 when ksplit <= 1)
+    if (p.ksplit > 1) {
+        p.A += (int64_t)slice * p.k_slice; p.W += (int64_t)slice * p.k_slice; p.K = p.k_slice;
+        p.out = reinterpret_cast<float*>(p.out) + slice * p.split_stride;
+        if (slice) p.bias = nullptr;
+    }
+    const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
     const int grp = tile / (p.gm * p.tiles_n), rem = tile - grp * (p.gm * p.tiles_n);
     const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
     const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
@@ -632,7 +651,7 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
+    PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(512), lds, stream, p);
     return pv_check_launch();
 }
 
@@ -662,6 +681,11 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
 #ifdef PV_STAMPS
     p.dbg = g_pv_dbg;
 #endif
+    p.ksplit = a->ksplit > 1 ? a->ksplit : 1; p.k_slice = (int)(a->K / p.ksplit); p.split_stride = a->M * a->ldo;
+    if (p.ksplit > 1) {
+        // split-K: fp32 partial slices out[t] (t < ksplit) of M*ldo floats each, summed by pv_sum_slices_f32; bias goes to slice 0
+        if (a->epilogue != PV_EPI_BIAS_F32 || a->qcols != 0 || a->ln_out || a->K % (p.ksplit * 64)) return PV_ERR_INVALID_ARG;
+    }
     p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_row_scale = a->ln_row_scale; p.ln_out = a->ln_out; p.ln_eps = a->ln_eps;
     hipStream_t s = (hipStream_t)stream;
     if (a->ln_out) {
@@ -681,9 +705,11 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
     const int tn256 = (p.N + G2_BN - 1) / G2_BN;
     const bool n_ok = p.N % 128 == 0 && (int64_t)tn256 * G2_BN * 3 <= (int64_t)p.N * 4;
     // (the 256^2 epilogue applies the q-scale per 8-column chunk, the 128^2 one per 4 columns)
+    const int k_eff = p.ksplit > 1 ? p.k_slice : p.K;
     const bool big = !((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 8) &&
-                     (force == 256 || (force != 128 && n_ok && p.K % (2 * G2_BK) == 0 && p.M >= 2048));
-    if (big && (p.K % (2 * G2_BK) || p.K < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+                     (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
+                                       (p.M >= 2048 || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
+    if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
     if ((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
     p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768

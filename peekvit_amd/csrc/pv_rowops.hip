@@ -159,6 +159,75 @@ extern "C" int pv_im2col_u8_bf16(const uint8_t* x, uint16_t* cols, int64_t B, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward helpers: split-K slice reduction, bf16 transpose, column sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int slices, int accumulate) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < slices; ++t) {
+            const float4 v = reinterpret_cast<const float4*>(part + (int64_t)t * n)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream) {
+    if (!partials || !out || n_elems <= 0 || slices <= 0) return PV_ERR_INVALID_ARG;
+    if (n_elems % 4 || ((uintptr_t)partials & 15) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_sum_slices_kernel, dim3(pv_stream_grid(n_elems / 4, 256)), dim3(256), 0, (hipStream_t)stream, partials, out, n_elems, (int)slices, accumulate);
+    return pv_check_launch();
+}
+
+// 64 x 64 tiles through LDS (rows padded by one element pair): coalesced 128-byte reads and writes
+__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C) {
+    __shared__ uint16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < C && r0 + tx < R) dst[(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+extern "C" int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+    if (grid.y > 65535u) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+    return pv_check_launch();
+}
+
+// stage 1: one block per 1024-row chunk, thread t owns columns t, t+256, ...; stage 2 = pv_sum_slices over the chunks
+template <bool BF16>
+__global__ __launch_bounds__(256) void pv_colsum_kernel(const void* __restrict__ src, float* __restrict__ ws, int64_t R, int C) {
+    const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        if (BF16) {
+            const uint16_t* p = reinterpret_cast<const uint16_t*>(src);
+            for (int64_t r = r0; r < r1; ++r) s += pv_bf2f(p[r * C + c]);
+        } else {
+            const float* p = reinterpret_cast<const float*>(src);
+            for (int64_t r = r0; r < r1; ++r) s += p[r * C + c];
+        }
+        ws[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+extern "C" int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream) {
+    if (!src || !out || !ws || R <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
+    if (C % 4 || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15)) return PV_ERR_UNSUPPORTED;
+    const int64_t chunks = (R + 1023) / 1024;
+    if (src_is_bf16) PV_LAUNCH(pv_colsum_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
+    else PV_LAUNCH(pv_colsum_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
+    if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
+    return pv_sum_slices_f32(ws, out, C, chunks, accumulate, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // token prologue: special rows (+pos) and the optional budget token row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pv_token_prologue_kernel(float* __restrict__ tokens, const float* __restrict__ special,

@@ -143,8 +143,9 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
+    ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
     ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
     K = a.shape[-1]
     if M is None:
@@ -160,7 +161,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     qcols=qcols, qscale=float(qscale), epilogue=epilogue,
                     ln_gamma=ln[0].data_ptr() if ln else 0, ln_beta=ln[1].data_ptr() if ln else 0,
                     ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
-                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0)
+                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit))
     with _timed("pv_gemm_bf16", a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
         check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
@@ -192,6 +193,56 @@ def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
         check(_lib.load().pv_head_f32(_ptr(pooled), _ptr(w), _ptr(b), _ptr(logits), B, D, Cn, _stream(pooled)), "pv_head_f32")
     _count()
     return logits
+
+
+# ---- backward building blocks ---------------------------------------------------------------------------------------
+def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out (+)= partials.sum(0); partials fp32 [S, ...] contiguous, out fp32 of the trailing shape."""
+    _chk(partials, torch.float32, "partials"); _chk(out, torch.float32, "out")
+    S = partials.shape[0]
+    with _timed("pv_sum_slices_f32", out.device, 0.0, 4.0 * (S + 1) * out.numel()):
+        check(_lib.load().pv_sum_slices_f32(_ptr(partials), _ptr(out), out.numel(), S, int(accumulate), _stream(out)), "pv_sum_slices_f32")
+    _count()
+    return out
+
+
+def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [R,C] -> bf16 [C,R]."""
+    _chk(src, torch.bfloat16, "src")
+    R, Cc = src.shape
+    if out is None:
+        out = torch.empty((Cc, R), dtype=torch.bfloat16, device=src.device)
+    with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
+        check(_lib.load().pv_transpose_bf16(_ptr(src), _ptr(out), R, Cc, _stream(src)), "pv_transpose_bf16")
+    _count()
+    return out
+
+
+def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out[C] (+)= src[R,C].sum(0) in fp32; src bf16 or fp32."""
+    assert src.dtype in (torch.bfloat16, torch.float32) and src.is_contiguous()
+    _chk(out, torch.float32, "out")
+    R, Cc = src.shape
+    ws = torch.empty(((R + 1023) // 1024, Cc), dtype=torch.float32, device=src.device)
+    with _timed("pv_colsum_f32", src.device, 0.0, float(src.element_size() * src.numel())):
+        check(_lib.load().pv_colsum_f32(_ptr(src), int(src.dtype == torch.bfloat16), _ptr(out), _ptr(ws), R, Cc, int(accumulate),
+                                        _stream(src)), "pv_colsum_f32")
+    _count()
+    return out
+
+
+def wgrad(dy_t: torch.Tensor, x_t: torch.Tensor, out: torch.Tensor, accumulate: bool = False, ksplit: int = 0) -> torch.Tensor:
+    """out[N_out, N_in] (+)= dY^T . X from the TRANSPOSED bf16 activations dy_t [N_out, M], x_t [N_in, M] (split-K over M)."""
+    No, M = dy_t.shape
+    Ni = x_t.shape[0]
+    if ksplit <= 0:
+        tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
+        ksplit = 1
+        while tiles * ksplit < 512 and M % (ksplit * 2 * 128) == 0 and M // (ksplit * 2) >= 1024:
+            ksplit *= 2
+    part = torch.empty((ksplit, No, Ni), dtype=torch.float32, device=out.device)
+    gemm(dy_t, x_t, None, part, _lib.PV_EPI_BIAS_F32, ksplit=ksplit)
+    return sum_slices(part, out, accumulate)
 
 
 # ---- precision mode "bf16x3" ---------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ def golden():
 
 def rel_l2(a, b):
     """Relative L2 error ||a-b|| / ||b|| in float64 (the metric of SURVEY.md section 7 H1)."""
+    a, b = (t.detach().double().cpu().numpy() if hasattr(t, "detach") else t for t in (a, b))
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

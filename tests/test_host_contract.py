@@ -20,14 +20,14 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
-    assert lib.pv_version() == 3 and lib.pv_arch() == b"gfx950"
+    assert lib.pv_version() == 4 and lib.pv_arch() == b"gfx950"
     assert b"launch" in lib.pv_error_string(-3)
 
 
 def test_gemm_args_struct_matches_header_layout():
     import ctypes as C
     from peekvit_amd._lib import GemmArgs
-    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8          # ABI v2: + fused-LN fields (ln_eps padded to 8)
+    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8          # ABI v2+: fused-LN fields, then ln_eps + ksplit (v4) share 8 bytes
     assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
     assert GemmArgs.ln_gamma.offset == 19 * 8 and GemmArgs.ln_eps.offset == 23 * 8
 
