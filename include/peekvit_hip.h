@@ -144,6 +144,12 @@ int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, 
 /* Column sums of a bf16 or fp32 [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]); ws: fp32 [ceil(R/1024)*C]. */
 int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 
+/* Attention backward for one block (models/blocks.py:32-37 under train/train.py:118 loss.backward()):
+ * qkv bf16 [B,S,3D] as the forward in-proj wrote it (q columns pre-scaled by qscale), dout bf16 [B,S,D] = dL/d(attention
+ * output); dqkv bf16 [B,S,3D] = dL/d(in-proj output before the q pre-scale).  Probabilities are recomputed.  dh = 64, S <= 208. */
+int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
+                          float qscale, void* stream);
+
 /* Final LayerNorm on the class-token rows only + sum over class tokens:
  *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.
  * x: fp32 [B,S,D]; pooled: fp32 [B,D] = sum_{c<num_cls} LN(x[b,c]). */

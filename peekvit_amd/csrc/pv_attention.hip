@@ -389,12 +389,225 @@ static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int 
     }
     return PV_ERR_UNSUPPORTED;
 }
-#if 0
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward (train/train.py:118 loss.backward() through models/blocks.py:32-37), dh = 64, S <= 208.
+//   in : qkv bf16 [B,S,3D] (q pre-scaled by qscale, as the forward wrote it), dout bf16 [B,S,D] = dL/d(attention output)
+//   out: dqkv bf16 [B,S,3D] = dL/d(in-proj output BEFORE the q pre-scale)  (the A operand of the in-proj dgrad / wgrad GEMMs)
+// One workgroup (8 waves) per (image, head); Q, K, V, dO of the head live in LDS (swizzled row-major images).  Probabilities
+// are recomputed (nothing but qkv and the output gradient is read).  Two wave-private passes, no atomics:
+//   pass 1, wave owns a 16-query tile, swapped S^T / dP^T = K.Q^T / V.dO^T tiles (lane = 4 keys of one query): softmax row
+//           statistics m, 1/l and D = rowsum(P o dP), dS = P o (dP - D), dQ^T = K^T . dS^T (A = K^T by transposed LDS reads,
+//           B = the bf16-packed dS registers, K=16 MFMA); statistics go to LDS.
+//   pass 2, wave owns a 16-key tile, S / dP = Q.K^T / dO.V^T tiles (lane = 4 queries of one key) recomputed with the saved
+//           statistics: dV^T = dO^T . P, dK^T = Q^T . dS (A by transposed LDS reads of dO and Q, B from registers).
+// ------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                          uint16_t* __restrict__ dqkv, int S, int H, float qscale) {
+    constexpr int DH = 64, SP = NKT * 16, IMG = SP * DH * 2, NDT = DH / 16, KS = DH / 32;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Qs = smem;
+    char* const Ks = smem + IMG;
+    char* const Vs = smem + 2 * IMG;
+    char* const Os = smem + 3 * IMG;
+    float* const st_m = reinterpret_cast<float*>(smem + 4 * IMG);     // row max (of the raw scores), 1/l, D per query
+    float* const st_i = st_m + SP;
+    float* const st_d = st_i + SP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
+    const uint16_t* ob = dout + (int64_t)b * S * D + h * DH;
+    uint16_t* gb = dqkv + (int64_t)b * S * ld + h * DH;
+
+    // ---- stage the four images; rows >= S are zero: zero Q / dO rows make every padded-query contribution vanish ------
+    for (int e = tid; e < SP * 8; e += 512) {
+        const int row = e >> 3, c = e & 7;
+        u32x4 q = {0u, 0u, 0u, 0u}, k = q, v = q, o = q;
+        if (row < S) {
+            const uint16_t* rp = qb + (int64_t)row * ld + c * 8;
+            q = *reinterpret_cast<const u32x4*>(rp);
+            k = *reinterpret_cast<const u32x4*>(rp + D);
+            v = *reinterpret_cast<const u32x4*>(rp + 2 * D);
+            o = *reinterpret_cast<const u32x4*>(ob + (int64_t)row * D + c * 8);
+        }
+        const int off = pv_swz<8>(row, c);
+        *reinterpret_cast<u32x4*>(Qs + off) = q;
+        *reinterpret_cast<u32x4*>(Ks + off) = k;
+        *reinterpret_cast<u32x4*>(Vs + off) = v;
+        *reinterpret_cast<u32x4*>(Os + off) = o;
+    }
+    __syncthreads();
+
+    // lane-constant LDS offsets: plain fragment X[tile*16 + i16][ks*32 + 8g ..+8] and transposed fragment
+    // X[tile*16 + 4g + j][dt*16 + i16] (j = 0..3); 16 rows further = + 2048 bytes with the same swizzle term
+    int foff[KS], toff[NDT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<8>(i16, ks * 4 + g);
     {
+        const int tq_ = i16 >> 2, tp_ = i16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<8>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+    }
+    auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * 2048);
+    };
+    auto tfrag = [&](const char* X, int tile, int dt) __attribute__((always_inline)) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * 2048));
+    };
+    const int nqt = (S + 15) >> 4;
+
+    // =============================== pass 1: per 16-query tile ===============================
+    for (int qt = wid; qt < nqt; qt += 8) {
+        const int q0 = qt << 4;
+        bf16x8 qf[KS], of[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag(Qs, qt, ks); of[ks] = frag(Os, qt, ks); }
+        f32x4 sc[NKT], dp[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Ks, kt, ks), qf[ks], a, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Vs, kt, ks), of[ks], c, 0, 0, 0);
+            }
+            sc[kt] = a; dp[kt] = c;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * LOG2E;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], LOG2E, nm));
+                sc[kt][r] = pe;
+                l += pe;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        float dd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] *= inv;                                  // P
+                dd = fmaf(sc[kt][r], dp[kt][r], dd);
+            }
+        dd += __shfl_xor(dd, 16, 64);
+        dd += __shfl_xor(dd, 32, 64);
+        if (g == 0) { st_m[q0 + i16] = m; st_i[q0 + i16] = inv; st_d[q0 + i16] = dd; }
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const u32x2 dw = {pv_pack_bf16x2(sc[kt][0] * (dp[kt][0] - dd), sc[kt][1] * (dp[kt][1] - dd)),
+                              pv_pack_bf16x2(sc[kt][2] * (dp[kt][2] - dd), sc[kt][3] * (dp[kt][3] - dd))};
+            const s16x4 dsf = __builtin_bit_cast(s16x4, dw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Ks, kt, dt), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q0 + i16 < S) {       // dq[dt][r] = dL/dq'[q0+i16][dt*16 + 4g + r]; the in-proj output is q'/qscale
+            uint16_t* op = gb + (int64_t)(q0 + i16) * ld + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const u32x2 ov = {pv_pack_bf16x2(dq[dt][0] * qscale, dq[dt][1] * qscale), pv_pack_bf16x2(dq[dt][2] * qscale, dq[dt][3] * qscale)};
+                *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+            }
+        }
+    }
+    __syncthreads();
+
+    // =============================== pass 2: per 16-key tile ===============================
+    for (int kt = wid; kt < nqt; kt += 8) {
+        const int k0 = kt << 4;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag(Ks, kt, ks); vf[ks] = frag(Vs, kt, ks); }
+        const bool key_ok = k0 + i16 < S;
+        f32x4 dv[NDT], dk[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+        for (int qt = 0; qt < nqt; ++qt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Qs, qt, ks), kf[ks], s, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Os, qt, ks), vf[ks], c, 0, 0, 0);
+            }
+            const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
+            const float4 i4 = *reinterpret_cast<const float4*>(st_i + qt * 16 + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * g);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            float p[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = key_ok ? __builtin_amdgcn_exp2f((s[r] - mm[r]) * LOG2E) * ii[r] : 0.f;
+                ds[r] = p[r] * (c[r] - dd[r]);
+            }
+            const u32x2 pw = {pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
+            const u32x2 dw = {pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+            const s16x4 pf = __builtin_bit_cast(s16x4, pw), dsf = __builtin_bit_cast(s16x4, dw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Os, qt, dt), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Qs, qt, dt), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (key_ok) {             // d*[dt][r] = dL/d{k,v}[k0+i16][dt*16 + 4g + r]
+            uint16_t* op = gb + (int64_t)(k0 + i16) * ld + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const u32x2 kv = {pv_pack_bf16x2(dk[dt][0], dk[dt][1]), pv_pack_bf16x2(dk[dt][2], dk[dt][3])};
+                const u32x2 vv = {pv_pack_bf16x2(dv[dt][0], dv[dt][1]), pv_pack_bf16x2(dv[dt][2], dv[dt][3])};
+                *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
+                *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;
+            }
+        }
+    }
+}
+
+template <int NKT>
+static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int S, int H, float qscale, hipStream_t stream) {
+    constexpr int lds = 4 * NKT * 16 * 128 + 3 * NKT * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    PV_LAUNCH((pv_attn_bwd_kernel<NKT>), dim3((unsigned)(B * H)), dim3(512), lds, stream, qkv, dout, dqkv, S, H, qscale);
+    return pv_check_launch();
+}
+
+extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
+                                     float qscale, void* stream) {
+    if (!qkv || !dout || !dqkv || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return PV_ERR_INVALID_ARG;
+    if (dh != 64 || S > 208 || B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<N>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
+        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
         default: return PV_ERR_UNSUPPORTED;
     }
 }
-#endif
 
 extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;

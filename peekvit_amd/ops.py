@@ -231,6 +231,14 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
     return out
 
 
+def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, B: int, S: int, H: int, dh: int, qscale: float):
+    with _timed("pv_attention_bwd_bf16", qkv.device, 14.0 * B * H * S * S * dh, 14.0 * B * S * H * dh):
+        check(_lib.load().pv_attention_bwd_bf16(_ptr(qkv), _ptr(dout), _ptr(dqkv), B, S, H, dh, float(qscale), _stream(qkv)),
+              "pv_attention_bwd_bf16")
+    _count()
+    return dqkv
+
+
 def wgrad(dy_t: torch.Tensor, x_t: torch.Tensor, out: torch.Tensor, accumulate: bool = False, ksplit: int = 0) -> torch.Tensor:
     """out[N_out, N_in] (+)= dY^T . X from the TRANSPOSED bf16 activations dy_t [N_out, M], x_t [N_in, M] (split-K over M)."""
     No, M = dy_t.shape

@@ -61,3 +61,32 @@ def test_wgrad_split_k(ops, M, No, Ni, ksplit):
     assert rel_l2(out, ref) < 2e-6
     ops.wgrad(ops.transpose(dy), ops.transpose(x), out, accumulate=True, ksplit=ksplit)
     assert rel_l2(out, 2 * ref) < 2e-6
+
+
+def _attn_ref(qkv, dout, B, S, H, dh, qscale):
+    """fp32 autograd through softmax(q' k^T) v on the same bf16 values; q' = the pre-scaled q the forward stored."""
+    D = H * dh
+    t = qkv.float().reshape(B, S, 3, H, dh).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3,B,H,S,dh]
+    q, k, v = t[0], t[1], t[2]
+    out = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v                                            # [B,H,S,dh]
+    out = out.permute(0, 2, 1, 3).reshape(B, S, D)
+    (out * dout.float()).sum().backward()
+    g = t.grad.clone()
+    g[0] *= qscale                                                  # dL/d(in-proj output) = qscale * dL/dq'
+    return g.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D)
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 16, 2), (3, 50, 2), (2, 197, 12), (1, 101, 3), (4, 208, 1), (2, 5, 2)])
+def test_attention_backward(ops, B, S, H):
+    dh, D = 64, H * 64
+    qscale = dh ** -0.5
+    qkv = _bf(B, S, 3 * D, seed=S)
+    qkv[..., :D] = (qkv[..., :D].float() * qscale).to(torch.bfloat16)
+    dout = _bf(B, S, D, seed=S + 1, scale=0.1)
+    dqkv = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.attention_bwd(qkv, dout, dqkv, B, S, H, dh, qscale)
+    ref = _attn_ref(qkv, dout, B, S, H, dh, qscale)
+    assert torch.isfinite(dqkv.float()).all()
+    for i, name in enumerate("qkv"):
+        err = rel_l2(dqkv[..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
+        assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
