@@ -139,8 +139,17 @@ int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S
 
 /* out[n] (+)= sum_t partials[t*n_elems + n]: reduces split-K slices (accumulate != 0 adds to the existing out). fp32. */
 int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream);
-/* bf16 [R,C] row-major -> bf16 [C,R] (ldo = R): K-contiguous operands for dW = (dY^T) . (X^T)^T. R, C % 8 == 0 not required. */
-int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, void* stream);
+/* bf16 [R,C] row-major -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be a multiple
+ * of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
+int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream);
+/* LayerNorm backward (models/blocks.py:60,77): x fp32 [rows,D] (the saved LN input), dy bf16 [rows,D], gamma fp32 [D];
+ * dx_out = (dres_in or 0) + dL/dx, fp32 [rows,D] (may alias dres_in); dgb fp32 [2,D] (+)= (dgamma, dbeta).
+ * ws: fp32 scratch of >= min(ceil(rows/4),1024)*2*D floats.  D % 4 == 0, D <= 1024. */
+int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, float* dgb,
+                     float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
+/* Training-path GELU (models/blocks.py:82) on bf16 streams: out = gelu(pre);  dpre = dg * gelu'(pre) (may alias dg). n % 8 == 0. */
+int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream);
+int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream);
 /* Column sums of a bf16 or fp32 [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]); ws: fp32 [ceil(R/1024)*C]. */
 int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 

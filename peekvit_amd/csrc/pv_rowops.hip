@@ -181,22 +181,22 @@ extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_el
 }
 
 // 64 x 64 tiles through LDS (rows padded by one element pair): coalesced 128-byte reads and writes
-__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C) {
+__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C, int64_t ldd) {
     __shared__ uint16_t tile[64][66];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4)
-        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(r0 + i) * C + c0 + tx];
+        tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * C + c0 + tx] : (uint16_t)0;
     __syncthreads();
     for (int i = ty; i < 64; i += 4)
-        if (c0 + i < C && r0 + tx < R) dst[(c0 + i) * R + r0 + tx] = tile[tx][i];
+        if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
 }
 
-extern "C" int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, void* stream) {
-    if (!src || !dst || R <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
-    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+extern "C" int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return PV_ERR_INVALID_ARG;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ldd + 63) / 64));
     if (grid.y > 65535u) return PV_ERR_UNSUPPORTED;
-    PV_LAUNCH(pv_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+    PV_LAUNCH(pv_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
     return pv_check_launch();
 }
 
@@ -323,6 +323,148 @@ extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma
 #define LN_LAUNCH(N) PV_LAUNCH(pv_layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
     PV_DISPATCH_NCH(D, LN_LAUNCH);
 #undef LN_LAUNCH
+    return pv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (models/blocks.py:60,77 under loss.backward()): y = xhat * gamma + beta, xhat = (x - mean) * rstd
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;   dres_out = dres_in + dx   (x also feeds the skip)
+//   dgamma = sum_rows dy * xhat, dbeta = sum_rows dy:  per-lane column accumulators over the rows a wave walks, combined per
+//   block through LDS into ws[block][2][D]; pv_sum_slices_f32 finishes the reduction.  Statistics are recomputed from x.
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ dres_in,
+                                                               float* __restrict__ dx_out, float* __restrict__ ws, int64_t rows, int D, float eps) {
+    __shared__ float red[4][2][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    float4 ag[NCH], ab[NCH], gm[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
+        const int idx = lane + 64 * j;
+        gm[j] = idx < nvec ? reinterpret_cast<const float4*>(gamma)[idx] : ag[j];
+    }
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        RowRegs<NCH> r;
+        pv_load_row<NCH>(r, x + row * D, nvec, lane);
+        float4 d[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            u32x2 w = {0u, 0u};
+            if (idx < nvec) w = reinterpret_cast<const u32x2*>(dy + row * D)[idx];
+            d[j] = make_float4(__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u));
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
+        const float mean = pv_wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (lane + 64 * j < nvec) {
+                const float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, e = r.v[j].w - mean;
+                q += (a * a + b * b) + (c * c + e * e);
+            }
+        const float rstd = 1.0f / sqrtf(pv_wave_sum(q) * invD + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (lane + 64 * j < nvec) {
+                float4& v = r.v[j];                                          // v <- xhat
+                v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+                ag[j].x += d[j].x * v.x; ag[j].y += d[j].y * v.y; ag[j].z += d[j].z * v.z; ag[j].w += d[j].w * v.w;
+                ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+                d[j].x *= gm[j].x; d[j].y *= gm[j].y; d[j].z *= gm[j].z; d[j].w *= gm[j].w;     // d <- g
+                s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
+                s2 += (d[j].x * v.x + d[j].y * v.y) + (d[j].z * v.z + d[j].w * v.w);
+            }
+        s1 = pv_wave_sum(s1) * invD;
+        s2 = pv_wave_sum(s2) * invD;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                float4 o = dres_in ? reinterpret_cast<const float4*>(dres_in + row * D)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                o.x += rstd * (d[j].x - s1 - r.v[j].x * s2);
+                o.y += rstd * (d[j].y - s1 - r.v[j].y * s2);
+                o.z += rstd * (d[j].z - s1 - r.v[j].z * s2);
+                o.w += rstd * (d[j].w - s1 - r.v[j].w * s2);
+                reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        reinterpret_cast<float4*>(red[wave][0])[lane + 64 * j] = ag[j];
+        reinterpret_cast<float4*>(red[wave][1])[lane + 64 * j] = ab[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += 256) {
+        const int which = e >= D, c = e - which * D;
+        ws[(int64_t)blockIdx.x * 2 * D + e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, float* dgb,
+                                float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream) {
+    if (!x || !dy || !gamma || !dx_out || !dgb || !ws || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 1024) return PV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)dx_out & 15) || ((uintptr_t)dgb & 15) ||
+        ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15))) return PV_ERR_INVALID_ARG;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (ws_floats < blocks * 2 * D) return PV_ERR_INVALID_ARG;
+    dim3 grid((unsigned)blocks);
+#define LNB_LAUNCH(N) PV_LAUNCH(pv_layernorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, ws, rows, (int)D, eps)
+    { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
+#undef LNB_LAUNCH
+    if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
+    return pv_sum_slices_f32(ws, dgb, 2 * D, blocks, accumulate, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU forward / backward on bf16 streams for the training path (models/blocks.py:82): g = gelu(pre);
+// dpre = dg * (Phi(pre) + pre * phi(pre)), exact erf form.
+// ------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void pv_gelu_kernel(const uint16_t* __restrict__ pre, const uint16_t* __restrict__ dg, uint16_t* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const u32x4 pw = reinterpret_cast<const u32x4*>(pre)[i];
+        u32x4 gw = {0u, 0u, 0u, 0u};
+        if (BWD) gw = reinterpret_cast<const u32x4*>(dg)[i];
+        u32x4 ow;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = __builtin_bit_cast(float, pw[k] << 16), x1 = __builtin_bit_cast(float, pw[k] & 0xffff0000u);
+            float y0, y1;
+            if (BWD) {
+                const float g0 = __builtin_bit_cast(float, gw[k] << 16), g1 = __builtin_bit_cast(float, gw[k] & 0xffff0000u);
+                y0 = g0 * (0.5f * (1.0f + erff(x0 * 0.70710678118654752440f)) + x0 * 0.3989422804014327f * __expf(-0.5f * x0 * x0));
+                y1 = g1 * (0.5f * (1.0f + erff(x1 * 0.70710678118654752440f)) + x1 * 0.3989422804014327f * __expf(-0.5f * x1 * x1));
+            } else {
+                y0 = pv_gelu_erf(x0); y1 = pv_gelu_erf(x1);
+            }
+            ow[k] = pv_pack_bf16x2(y0, y1);
+        }
+        reinterpret_cast<u32x4*>(out)[i] = ow;
+    }
+}
+
+extern "C" int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream) {
+    if (!pre || !out || n <= 0) return PV_ERR_INVALID_ARG;
+    if (n % 8 || ((uintptr_t)pre & 15) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_gelu_kernel<false>, dim3(pv_stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, pre, (const uint16_t*)nullptr, out, n / 8);
+    return pv_check_launch();
+}
+
+extern "C" int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream) {
+    if (!pre || !dg || !dpre || n <= 0) return PV_ERR_INVALID_ARG;
+    if (n % 8 || ((uintptr_t)pre & 15) || ((uintptr_t)dg & 15) || ((uintptr_t)dpre & 15)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_gelu_kernel<true>, dim3(pv_stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, pre, dg, dpre, n / 8);
     return pv_check_launch();
 }
 

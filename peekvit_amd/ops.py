@@ -206,14 +206,16 @@ def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = Fal
     return out
 
 
-def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 [R,C] -> bf16 [C,R]."""
+def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
+    """bf16 [R,C] -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
     _chk(src, torch.bfloat16, "src")
     R, Cc = src.shape
+    ldd = (R + pad_to - 1) // pad_to * pad_to
     if out is None:
-        out = torch.empty((Cc, R), dtype=torch.bfloat16, device=src.device)
+        out = torch.empty((Cc, ldd), dtype=torch.bfloat16, device=src.device)
+    assert out.shape == (Cc, ldd) and out.is_contiguous()
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
-        check(_lib.load().pv_transpose_bf16(_ptr(src), _ptr(out), R, Cc, _stream(src)), "pv_transpose_bf16")
+        check(_lib.load().pv_transpose_bf16(_ptr(src), _ptr(out), R, Cc, ldd, _stream(src)), "pv_transpose_bf16")
     _count()
     return out
 
@@ -229,6 +231,41 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
                                         _stream(src)), "pv_colsum_f32")
     _count()
     return out
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: torch.Tensor, dgb: torch.Tensor, eps: float,
+                  accumulate: bool = False):
+    """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [2,D] (+)= (dgamma, dbeta).  x fp32 [rows,D], dy bf16 [rows,D]."""
+    _chk(x, torch.float32, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    blocks = min((rows + 3) // 4, 1024)
+    ws = torch.empty((blocks, 2 * D), dtype=torch.float32, device=x.device)
+    with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0)) * x.numel()):
+        check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dgb),
+                                           _ptr(ws), ws.numel(), rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd")
+    _count()
+    return dx_out
+
+
+def gelu(pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(pre, torch.bfloat16, "pre")
+    if out is None:
+        out = torch.empty_like(pre)
+    with _timed("pv_gelu_bf16", pre.device, 0.0, 4.0 * pre.numel()):
+        check(_lib.load().pv_gelu_bf16(_ptr(pre), _ptr(out), pre.numel(), _stream(pre)), "pv_gelu_bf16")
+    _count()
+    return out
+
+
+def gelu_bwd(pre: torch.Tensor, dg: torch.Tensor, dpre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(pre, torch.bfloat16, "pre"); _chk(dg, torch.bfloat16, "dg")
+    if dpre is None:
+        dpre = dg
+    with _timed("pv_gelu_bwd_bf16", pre.device, 0.0, 6.0 * pre.numel()):
+        check(_lib.load().pv_gelu_bwd_bf16(_ptr(pre), _ptr(dg), _ptr(dpre), pre.numel(), _stream(pre)), "pv_gelu_bwd_bf16")
+    _count()
+    return dpre
 
 
 def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, B: int, S: int, H: int, dh: int, qscale: float):

@@ -90,3 +90,42 @@ def test_attention_backward(ops, B, S, H):
     for i, name in enumerate("qkv"):
         err = rel_l2(dqkv[..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
+
+
+def test_transpose_padded(ops):
+    x = _bf(197, 72, seed=5)
+    y = ops.transpose(x, pad_to=64)
+    assert y.shape == (72, 256)
+    assert torch.equal(y[:, :197], x.t()) and (y[:, 197:] == 0).all()
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 192), (4099, 384), (3940, 768), (64, 1024)])
+def test_layernorm_backward(ops, rows, D):
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, D, generator=g, device="cuda") * 2 + 0.5
+    gamma = torch.randn(D, generator=g, device="cuda") * 0.3 + 1
+    beta = torch.randn(D, generator=g, device="cuda") * 0.1
+    dy = _bf(rows, D, seed=rows + 1, scale=0.05)
+    dres = torch.randn(rows, D, generator=g, device="cuda") * 0.05
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
+    dx = torch.empty_like(x)
+    dgb = torch.full((2, D), 7.0, device="cuda")
+    ops.layernorm_bwd(x, dy, gamma, dres, dx, dgb, 1e-6)
+    assert rel_l2(dx, dres + xr.grad) < 5e-6
+    assert rel_l2(dgb[0], gr.grad) < 5e-6 and rel_l2(dgb[1], br.grad) < 5e-6
+    ops.layernorm_bwd(x, dy, gamma, None, dx, dgb, 1e-6, accumulate=True)
+    assert rel_l2(dx, xr.grad) < 5e-6
+    assert rel_l2(dgb[0], 2 * gr.grad) < 5e-6
+
+
+def test_gelu_forward_backward(ops):
+    pre = _bf(1000, 3072, seed=9, scale=2.0)
+    dg = _bf(1000, 3072, seed=10, scale=0.1)
+    pr = pre.float().requires_grad_(True)
+    y = torch.nn.functional.gelu(pr)
+    y.backward(dg.float())
+    assert torch.equal(ops.gelu(pre), y.detach().to(torch.bfloat16))
+    got = ops.gelu_bwd(pre, dg.clone())
+    assert rel_l2(got.float(), pr.grad) < 3e-3                      # bf16 rounding of the stored gradient (2^-9 relative)
+    assert (got.float() - pr.grad).abs().max() <= pr.grad.abs().max() * 2 ** -8
