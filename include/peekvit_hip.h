@@ -155,7 +155,8 @@ int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64
 
 /* Attention backward for one block (models/blocks.py:32-37 under train/train.py:118 loss.backward()):
  * qkv bf16 [B,S,3D] as the forward in-proj wrote it (q columns pre-scaled by qscale), dout bf16 [B,S,D] = dL/d(attention
- * output); dqkv bf16 [B,S,3D] = dL/d(in-proj output before the q pre-scale).  Probabilities are recomputed.  dh = 64, S <= 208. */
+ * output); dqkv bf16 [B,S,3D] = dL/d(in-proj output before the q pre-scale).  Probabilities are recomputed.
+ * dh in {32, 48, 64}; S <= 208 (S <= 416 at dh = 32): Q, K, V and dO of one head live in the LDS. */
 int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
                           float qscale, void* stream);
 

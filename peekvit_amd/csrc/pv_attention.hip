@@ -391,7 +391,7 @@ static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention backward (train/train.py:118 loss.backward() through models/blocks.py:32-37), dh = 64, S <= 208.
+// Attention backward (train/train.py:118 loss.backward() through models/blocks.py:32-37); dh in {32, 48, 64}, S <= 208 (416 at dh = 32).
 //   in : qkv bf16 [B,S,3D] (q pre-scaled by qscale, as the forward wrote it), dout bf16 [B,S,D] = dL/d(attention output)
 //   out: dqkv bf16 [B,S,3D] = dL/d(in-proj output BEFORE the q pre-scale)  (the A operand of the in-proj dgrad / wgrad GEMMs)
 // One workgroup (8 waves) per (image, head); Q, K, V, dO of the head live in LDS (swizzled row-major images).  Probabilities
@@ -402,10 +402,11 @@ static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int 
 //   pass 2, wave owns a 16-key tile, S / dP = Q.K^T / dO.V^T tiles (lane = 4 queries of one key) recomputed with the saved
 //           statistics: dV^T = dO^T . P, dK^T = Q^T . dS (A by transposed LDS reads of dO and Q, B from registers).
 // ------------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+template <int DH, int NKT, int NW>     // NW waves per workgroup: 8, or 4 when the 2*NKT accumulator tiles need the full register file
+__global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                           uint16_t* __restrict__ dqkv, int S, int H, float qscale) {
-    constexpr int DH = 64, SP = NKT * 16, IMG = SP * DH * 2, NDT = DH / 16, KS = DH / 32;
+    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;      // TB: bytes of 16 LDS rows
+    constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
     constexpr float LOG2E = 1.44269504088896340736f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Qs = smem;
@@ -426,17 +427,17 @@ __global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __rest
     uint16_t* gb = dqkv + (int64_t)b * S * ld + h * DH;
 
     // ---- stage the four images; rows >= S are zero: zero Q / dO rows make every padded-query contribution vanish ------
-    for (int e = tid; e < SP * 8; e += 512) {
-        const int row = e >> 3, c = e & 7;
+    for (int e = tid; e < SP * CPR; e += NW * 64) {
+        const int row = e / CPR, c = e - row * CPR;
         u32x4 q = {0u, 0u, 0u, 0u}, k = q, v = q, o = q;
-        if (row < S) {
+        if (row < S && c * 8 < DH) {
             const uint16_t* rp = qb + (int64_t)row * ld + c * 8;
             q = *reinterpret_cast<const u32x4*>(rp);
             k = *reinterpret_cast<const u32x4*>(rp + D);
             v = *reinterpret_cast<const u32x4*>(rp + 2 * D);
             o = *reinterpret_cast<const u32x4*>(ob + (int64_t)row * D + c * 8);
         }
-        const int off = pv_swz<8>(row, c);
+        const int off = pv_swz<CPR>(row, c);
         *reinterpret_cast<u32x4*>(Qs + off) = q;
         *reinterpret_cast<u32x4*>(Ks + off) = k;
         *reinterpret_cast<u32x4*>(Vs + off) = v;
@@ -445,25 +446,25 @@ __global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __rest
     __syncthreads();
 
     // lane-constant LDS offsets: plain fragment X[tile*16 + i16][ks*32 + 8g ..+8] and transposed fragment
-    // X[tile*16 + 4g + j][dt*16 + i16] (j = 0..3); 16 rows further = + 2048 bytes with the same swizzle term
+    // X[tile*16 + 4g + j][dt*16 + i16] (j = 0..3); 16 rows further = + TB bytes with the same swizzle term
     int foff[KS], toff[NDT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<8>(i16, ks * 4 + g);
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
     {
         const int tq_ = i16 >> 2, tp_ = i16 & 3;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<8>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
     }
     auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
-        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * 2048);
+        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * TB);
     };
     auto tfrag = [&](const char* X, int tile, int dt) __attribute__((always_inline)) {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * 2048));
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * TB));
     };
     const int nqt = (S + 15) >> 4;
 
     // =============================== pass 1: per 16-query tile ===============================
-    for (int qt = wid; qt < nqt; qt += 8) {
+    for (int qt = wid; qt < nqt; qt += NW) {
         const int q0 = qt << 4;
         bf16x8 qf[KS], of[KS];
 #pragma unroll
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __rest
     __syncthreads();
 
     // =============================== pass 2: per 16-key tile ===============================
-    for (int kt = wid; kt < nqt; kt += 8) {
+    for (int kt = wid; kt < nqt; kt += NW) {
         const int k0 = kt << 4;
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -582,29 +583,52 @@ __global__ __launch_bounds__(512) void pv_attn_bwd_kernel(const uint16_t* __rest
     }
 }
 
-template <int NKT>
+template <int DH, int NKT>
 static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int S, int H, float qscale, hipStream_t stream) {
-    constexpr int lds = 4 * NKT * 16 * 128 + 3 * NKT * 16 * 4;
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int lds = 4 * NKT * 16 * DHP * 2 + 3 * NKT * 16 * 4;
+    constexpr int NW = NKT <= 13 ? 8 : 4;
+    static_assert(lds <= 160 * 1024, "Q, K, V, dO of one head must fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd_kernel<DH, NKT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH((pv_attn_bwd_kernel<NKT>), dim3((unsigned)(B * H)), dim3(512), lds, stream, qkv, dout, dqkv, S, H, qscale);
+    PV_LAUNCH((pv_attn_bwd_kernel<DH, NKT, NW>), dim3((unsigned)(B * H)), dim3(NW * 64), lds, stream, qkv, dout, dqkv, S, H, qscale);
     return pv_check_launch();
+}
+
+template <int DH>
+static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int S, int H, float qscale, hipStream_t s) {
+    switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, B, S, H, qscale, s);
+        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
+        default: break;
+    }
+    if constexpr (DH == 32) {                  // 64-byte LDS rows: twice the sequence fits
+        switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, B, S, H, qscale, s);
+            PV_ATTN_CASE(14) PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20)
+            PV_ATTN_CASE(21) PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
+#undef PV_ATTN_CASE
+            default: break;
+        }
+    }
+    return PV_ERR_UNSUPPORTED;
 }
 
 extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
                                      float qscale, void* stream) {
     if (!qkv || !dout || !dqkv || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return PV_ERR_INVALID_ARG;
-    if (dh != 64 || S > 208 || B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<N>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
-        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
-        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
-#undef PV_ATTN_CASE
+    switch (dh) {          // S <= 208 at dh = 48 / 64, S <= 416 at dh = 32
+        case 32: return pv_dispatch_attn_bwd<32>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
+        case 48: return pv_dispatch_attn_bwd<48>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
+        case 64: return pv_dispatch_attn_bwd<64>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
         default: return PV_ERR_UNSUPPORTED;
     }
 }

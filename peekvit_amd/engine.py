@@ -44,8 +44,8 @@ def precision(mode: str):
 
 
 def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> str:
-    """'hip' for GPU tensors outside autograd, else 'torch' (stock-op composite used on CPU tensors and
-    while autograd is recording - backward kernels are a later row of SURVEY.md section 8).
+    """'hip' for GPU tensors outside autograd, else 'torch' (stock-op composite used on CPU tensors and - for the
+    modules train_engine does not cover yet: RankViT / ResidualViT blocks - while autograd is recording).
     PEEKVIT_AMD_BACKEND=hip makes every non-eligible call raise instead of taking the composite path."""
     forced = os.environ.get("PEEKVIT_AMD_BACKEND", "")
     eligible = x.is_cuda and not torch.is_grad_enabled() and not (module.training and dropout_p > 0.0)

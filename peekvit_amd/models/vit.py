@@ -15,7 +15,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
-from .. import engine
+from .. import engine, train_engine
 from .blocks import MLP, SelfAttention
 
 
@@ -46,6 +46,9 @@ class ViTBlock(nn.Module):
 
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        if train_engine.train_eligible(input, self, self._p_drop) and \
+                train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]):
+            return train_engine.block_forward_train(self, input)          # autograd records: HIP forward + HIP backward
         if engine.backend_for(input, self, self._p_drop) == "hip":
             return engine.block_forward(self, input, self.ln_1.eps, next_ln=self._pv_next_ln)
         return self._composite(input)
@@ -173,6 +176,11 @@ class VisionTransformer(_ViTBase):
 
     def forward(self, x: torch.Tensor):
         self._check_image(x)
+        if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
+                train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
+            tokens = train_engine.embed_tokens_train(self, x)      # same kernels, recorded for loss.backward()
+            tokens = self.encoder(tokens, _pos_added=True)
+            return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             tokens = engine.embed_tokens(self, x)                  # im2col + GEMM (+bias +pos), cls rows
             tokens = self.encoder(tokens, _pos_added=True)         # blocks dispatch themselves

@@ -1,0 +1,230 @@
+"""Training path of the MI355X engine: forward WITH saved activations and the hand-written backward, exposed to PyTorch as
+autograd Functions so that the reference's loop (train/train.py:112-121: `out = model(x)`, `loss.backward()`,
+`optimizer.step()`) runs unchanged.  Pure plumbing like engine.py: every product / reduction is a C-ABI kernel.
+
+Per encoder block (reference models/vit.py:45-55), R = B*S token rows:
+  forward   h1 = LN1(x) | qkv = h1.Win^T+b (q pre-scaled) | att = attention(qkv) | x1 = x + att.Wo^T+b | h2 = LN2(x1)
+            pre = h2.W1^T+b | gl = gelu(pre) | out = x1 + gl.W2^T+b             saved: x, h1, qkv, att, x1, h2, pre, gl
+  backward  d2 = bf16(dout)
+            dgl = d2.W2        dW2 = d2^T.gl     db2 = colsum(d2)
+            dpre = dgl*gelu'(pre)
+            dh2 = dpre.W1      dW1 = dpre^T.h2   db1 = colsum(dpre)
+            dx1 = dout + LN2'(dh2)               (dgamma2, dbeta2)
+            d1 = bf16(dx1)
+            datt = d1.Wo       dWo = d1^T.att    dbo = colsum(d1)
+            dqkv = attention'(qkv, datt)
+            dh1 = dqkv.Win     dWin = dqkv^T.h1  dbin = colsum(dqkv)
+            dx = dx1 + LN1'(dh1)                 (dgamma1, dbeta1)
+Data gradients (x.W) are the forward NT GEMM on the transposed bf16 weight; weight gradients (dY^T.X) are the same NT GEMM on
+the transposed activations with split-K over the R rows (pv_transpose_bf16 + pv_gemm_bf16 ksplit + pv_sum_slices_f32).
+Gradients of bf16 tensors travel in bf16 (as under torch autocast); the residual-stream gradient and all parameter
+gradients are fp32.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Dict, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import PV_EPI_BIAS_BF16, PV_EPI_BIAS_POS_F32, PV_EPI_BIAS_RES_F32, PeekvitHipError
+from .engine import _f32, bf16_weight, workspace
+
+_wtcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
+
+
+def bf16_weight_t(p: torch.Tensor) -> torch.Tensor:
+    """bf16 TRANSPOSE [K, N] of an fp32 [N, K] parameter (the 'weight' of the data-gradient GEMM), cached per version."""
+    key = id(p)
+    ent = _wtcache.get(key)
+    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+        return ent[3]
+    wt = ops.transpose(bf16_weight(p))
+    _wtcache[key] = (weakref.ref(p, lambda _r, k=key: _wtcache.pop(k, None)), p._version, p.data_ptr(), wt)
+    return wt
+
+
+def supported(D: int, H: int, S: int) -> bool:
+    """Shapes the backward kernels cover (include/peekvit_hip.h): dh in {32,48,64}, S <= 208 (416 at dh = 32), D <= 1024."""
+    dh = D // H
+    return D % H == 0 and dh in (32, 48, 64) and S <= (416 if dh == 32 else 208) and D <= 1024 and D % 8 == 0
+
+
+def _pad_rows(R: int) -> int:
+    """K of the weight-gradient GEMMs: R rounded up so that up to 32 (big batches) / 8 split-K slices stay multiples of 128."""
+    q = 4096 if R >= 65536 else 1024
+    return (R + q - 1) // q * q
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str) -> torch.Tensor:
+    """fp32 [No, Ni] = dy^T . x for bf16 dy [R, No], x [R, Ni]."""
+    R, No = dy.shape
+    Ni = x.shape[1]
+    Rp = _pad_rows(R)
+    dev = dy.device
+    dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), torch.bfloat16, dev), pad_to=Rp)
+    x_t = ops.transpose(x, workspace.get("wg_b", (Ni, Rp), torch.bfloat16, dev), pad_to=Rp)
+    tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
+    ksplit = 1
+    while ksplit < 32 and tiles * ksplit < 512 and Rp % (ksplit * 2 * 128) == 0:
+        ksplit *= 2
+    out = torch.empty((No, Ni), dtype=torch.float32, device=dev)
+    if ksplit == 1:
+        from ._lib import PV_EPI_BIAS_F32
+        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32)
+    part = workspace.get("wg_part", (ksplit, No, Ni), torch.float32, dev)
+    from ._lib import PV_EPI_BIAS_F32
+    ops.gemm(dy_t, x_t, None, part, PV_EPI_BIAS_F32, ksplit=ksplit)
+    return ops.sum_slices(part, out)
+
+
+def _colsum(src: torch.Tensor) -> torch.Tensor:
+    return ops.colsum(src, torch.empty((src.shape[1],), dtype=torch.float32, device=src.device))
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-LN encoder block with the MI355X forward + backward."""
+
+    @staticmethod
+    def forward(ctx, blk, x, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+        x = x.float() if x.dtype != torch.float32 else x
+        x = x if x.is_contiguous() else x.contiguous()
+        B, S, D = x.shape
+        mha = blk.self_attention.self_attention
+        H = mha.num_heads
+        dh = D // H
+        Mh = blk.mlp.fc1.out_features
+        R, dev, eps = B * S, x.device, blk.ln_1.eps
+        bf = torch.bfloat16
+        h1 = torch.empty((R, D), dtype=bf, device=dev)
+        qkv = torch.empty((R, 3 * D), dtype=bf, device=dev)
+        att = torch.empty((R, D), dtype=bf, device=dev)
+        x1 = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        h2 = torch.empty((R, D), dtype=bf, device=dev)
+        pre = torch.empty((R, Mh), dtype=bf, device=dev)
+        gl = torch.empty((R, Mh), dtype=bf, device=dev)
+        out = torch.empty_like(x)
+        qscale = float(dh) ** -0.5
+        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1)
+        ops.gemm(h1, bf16_weight(mha.in_proj_weight), _f32(inb), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=qscale)
+        ops.attention(qkv, att, B, S, H, dh)
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D))
+        ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2)
+        ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pre, PV_EPI_BIAS_BF16, M=R)
+        ops.gelu(pre, gl)
+        ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
+        ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.save_for_backward(x, h1, qkv, att, x1, h2, pre, gl)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        x, h1, qkv, att, x1, h2, pre, gl = ctx.saved_tensors
+        B, S, D, H, dh, Mh, qscale = ctx.dims
+        mha = blk.self_attention.self_attention
+        R, dev, bf = B * S, x.device, torch.bfloat16
+        dout = dout.float() if dout.dtype != torch.float32 else dout
+        dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
+        ws = workspace
+
+        # ---- MLP branch ------------------------------------------------------------------------------------
+        d2 = ops.cast_bf16(dout, ws.get("bw_d", (R, D), bf, dev))
+        db2 = _colsum(d2)
+        dw2 = _wgrad(d2, gl, "fc2")
+        dgl = ws.get("bw_dgl", (R, Mh), bf, dev)
+        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dgl, PV_EPI_BIAS_BF16, M=R)
+        dpre = ops.gelu_bwd(pre, dgl)                                           # in place
+        db1 = _colsum(dpre)
+        dw1 = _wgrad(dpre, h2, "fc1")
+        dhid = ws.get("bw_dh", (R, D), bf, dev)
+        ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R)
+        dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
+        dgb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps)
+        # ---- attention branch ------------------------------------------------------------------------------
+        d1 = ops.cast_bf16(dx1, ws.get("bw_d", (R, D), bf, dev))
+        dbo = _colsum(d1)
+        dwo = _wgrad(d1, att, "proj")
+        datt = ws.get("bw_datt", (R, D), bf, dev)
+        ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R)
+        dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
+        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale)
+        dbin = _colsum(dqkv)
+        dwin = _wgrad(dqkv, h1, "qkv")
+        ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R)
+        dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        dgb1 = torch.empty((2, D), dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps)
+        return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+
+
+def block_forward_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    mha = blk.self_attention.self_attention
+    return BlockFn.apply(blk, x, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                         mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                         blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+
+
+class EmbedFn(torch.autograd.Function):
+    """Patch embedding + class/register tokens + positional embedding (reference models/vit.py:203-236, :92) with backward:
+    dW_conv = dpatch^T . im2col(img), db_conv = colsum(dpatch), dpos = sum_b dtok[b], dcls = dpos[:n_cls]."""
+
+    @staticmethod
+    def forward(ctx, model, img, conv_w, conv_b, pos, cls, reg):
+        from . import engine
+        tokens = engine.embed_tokens(model, img)
+        ctx.model = model
+        ctx.has_reg = reg is not None
+        ctx.save_for_backward(img)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtok):
+        model = ctx.model
+        (img,) = ctx.saved_tensors
+        dtok = dtok.float() if dtok.dtype != torch.float32 else dtok
+        dtok = dtok if dtok.is_contiguous() else dtok.contiguous()
+        B, S, D = dtok.shape
+        P = model.patch_size
+        ncls, nreg = model.num_class_tokens, model.num_registers
+        nsp = ncls + nreg
+        Np = S - nsp
+        dev = dtok.device
+        u8 = img.dtype == torch.uint8
+        Cin = img.shape[3] if u8 else img.shape[1]
+        K = Cin * P * P
+        cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
+        if u8:
+            from .engine import IMAGENET_MEAN, IMAGENET_STD
+            ops.im2col_u8(img, P, cols, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
+        else:
+            ops.im2col(img if img.dtype == torch.float32 else img.float(), P, cols)
+        dpatch32 = dtok[:, nsp:, :].contiguous().view(B * Np, D)
+        dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), torch.bfloat16, dev))
+        dwc = _wgrad(dpatch, cols, "conv").view(model.conv_proj.weight.shape)
+        dbc = _colsum(dpatch)
+        dpos = ops.colsum(dtok.view(B, S * D), torch.empty((S * D,), dtype=torch.float32, device=dev)).view(1, S, D)
+        dcls = dpos[:, :ncls].clone()
+        dreg = dpos[:, ncls:nsp].clone() if ctx.has_reg else None
+        return (None, None, dwc, dbc, dpos, dcls, dreg)
+
+
+def embed_tokens_train(model: nn.Module, img: torch.Tensor) -> torch.Tensor:
+    reg = model.register_tokens if model.num_registers > 0 else None
+    return EmbedFn.apply(model, img, model.conv_proj.weight, model.conv_proj.bias, model.encoder.pos_embedding, model.class_tokens, reg)
+
+
+def pool_and_head_train(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
+    """Final LayerNorm on the class-token rows, sum, head: [B, n_cls, D] fp32 stock ops under autograd (0.02 % of the
+    step's FLOPs; the gradient re-enters the HIP backward as dL/d(tokens), zero outside the class rows)."""
+    cls = model.encoder.ln(tokens[:, 0:model.num_class_tokens])
+    return model.head(cls.sum(dim=1))
+
+
+def train_eligible(x: torch.Tensor, module: nn.Module, dropout_p: float) -> bool:
+    return (x.is_cuda and torch.is_grad_enabled() and not (module.training and dropout_p > 0.0)
+            and os.environ.get("PEEKVIT_AMD_BACKEND", "") != "torch" and os.environ.get("PEEKVIT_AMD_TRAIN", "hip") == "hip")
