@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--model", default="vit_b_16")
     ap.add_argument("--batch", type=int, default=2048, help="images per GPU per step")
     ap.add_argument("--rank-budget", type=float, default=None, help="run RankViT (rankvit_layers 3,6,9) at this budget")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE.json configs[2]/[4]: a step = forward + cross-entropy + backward (HIP backward kernels); with N > 1 "
+                         "ranks the parameter gradients are all-reduced over RCCL (data-parallel training path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
@@ -111,8 +114,10 @@ def main():
             seqs.append(S)
         workload = f"rank{args.model} layers={layers} budget={args.rank_budget} forward, batch {args.batch}/GPU"
     synth.load_synth_weights(model, cfg)
-    model = model.eval().to(dev)
-    flops_img = synth.fwd_flops_per_image(cfg, seqs)
+    model = (model.train() if args.train else model.eval()).to(dev)
+    flops_img = synth.fwd_flops_per_image(cfg, seqs) * (3 if args.train else 1)      # backward = dgrad + wgrad = 2x forward
+    if args.train:
+        workload = workload.replace("forward", "fwd+bwd (cross-entropy, parameter gradients" + (", RCCL all-reduce)" if world > 1 else ")"))
 
     # random (never zero-filled) device-resident input, bf16-representable like the parity fixtures
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -125,7 +130,22 @@ def main():
         torch.cuda.synchronize(dev)
 
     from peekvit_amd import engine
-    with torch.no_grad(), engine.precision(args.precision):
+    if args.train:
+        from peekvit_amd import dist as pvdist
+        y = torch.randint(0, cfg["num_classes"], (args.batch,), generator=gen, device=dev)
+        infer = model
+
+        def train_step(inp):
+            for p in infer.parameters():
+                p.grad = None
+            logits = infer(inp)
+            torch.nn.functional.cross_entropy(logits, y).backward()
+            if dist:
+                pvdist.allreduce_gradients(infer.parameters())
+            return logits.detach()
+
+        model = train_step
+    with (torch.enable_grad() if args.train else torch.no_grad()), engine.precision(args.precision):
         for _ in range(args.warmup):
             out = model(x)
         # (1) the contract's timed region: exactly K steps between barrier + synchronize, nothing else on the stream
@@ -172,7 +192,7 @@ def main():
             fam = [v for k, v in summ.items() if k.startswith(dom.replace("_bf16", "").replace("pv_", "pv_")) and "hbm_read_MB" in v]
             if dom == "pv_gemm_bf16":
                 fam = [v for k, v in summ.items() if k.startswith("pv_gemm") and "hbm_read_MB" in v]
-            if fam and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None:
+            if fam and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train:
                 n = sum(v["launches"] for v in fam)
                 roof["traffic"] = round(sum((v["hbm_read_MB"] + v["hbm_write_MB"]) * 1e6 * v["launches"] for v in fam) / n)
                 roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted mean over the GEMM variants)"
@@ -183,7 +203,7 @@ def main():
                        "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                    for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}
         line = {
-            "metric": "images/sec ViT-B/16 fwd @ batch 2048, 224x224" if args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None
+            "metric": "images/sec ViT-B/16 fwd @ batch 2048, 224x224" if args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train
                       else f"images/sec {workload}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_instrumented": round(elapsed_instr / args.steps * 1e3, 3),

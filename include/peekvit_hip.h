@@ -150,7 +150,8 @@ int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, con
 /* Training-path GELU (models/blocks.py:82) on bf16 streams: out = gelu(pre);  dpre = dg * gelu'(pre) (may alias dg). n % 8 == 0. */
 int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream);
 int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream);
-/* Column sums of a bf16 or fp32 [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]); ws: fp32 [ceil(R/1024)*C]. */
+/* Column sums of a bf16 (C % 8 == 0) or fp32 (C % 4 == 0) [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]);
+ * ws: fp32 scratch [ceil(R/1024)*C]. */
 int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 
 /* Attention backward for one block (models/blocks.py:32-37 under train/train.py:118 loss.backward()):

@@ -180,51 +180,118 @@ extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_el
     return pv_check_launch();
 }
 
-// 64 x 64 tiles through LDS (rows padded by one element pair): coalesced 128-byte reads and writes
+// 64 x 64 tiles through LDS.  Fast path (C % 8 == 0, ldd % 8 == 0, 16-byte aligned): 16-byte global loads and stores, the
+// transposition happens in the LDS read (8 two-byte reads down a tile column).  Otherwise element-wise.
+template <bool VEC>
 __global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C, int64_t ldd) {
-    __shared__ uint16_t tile[64][66];
+    __shared__ uint16_t tile[64][72];          // 144-byte rows: 16-byte aligned chunks, 36-bank pitch
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4)
-        tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * C + c0 + tx] : (uint16_t)0;
-    __syncthreads();
-    for (int i = ty; i < 64; i += 4)
-        if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
+    if (VEC) {
+        const int rr = threadIdx.x >> 3, ch = threadIdx.x & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t r = r0 + rr + 32 * h, c = c0 + ch * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(src + r * C + c);
+            *reinterpret_cast<u32x4*>(&tile[rr + 32 * h][ch * 8]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oc = rr + 32 * h;                                  // output row = source column
+            const int64_t orow = c0 + oc, ocol = r0 + ch * 8;
+            if (orow < C && ocol < ldd) {
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[ch * 8 + 2 * k][oc] | ((uint32_t)tile[ch * 8 + 2 * k + 1][oc] << 16);
+                *reinterpret_cast<u32x4*>(dst + orow * ldd + ocol) = (u32x4){w[0], w[1], w[2], w[3]};
+            }
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        for (int i = ty; i < 64; i += 4)
+            tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * C + c0 + tx] : (uint16_t)0;
+        __syncthreads();
+        for (int i = ty; i < 64; i += 4)
+            if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
+    }
 }
 
 extern "C" int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ldd + 63) / 64));
     if (grid.y > 65535u) return PV_ERR_UNSUPPORTED;
-    PV_LAUNCH(pv_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
+    const bool vec = C % 8 == 0 && ldd % 8 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
+    if (vec) PV_LAUNCH(pv_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
+    else PV_LAUNCH(pv_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
     return pv_check_launch();
 }
 
-// stage 1: one block per 1024-row chunk, thread t owns columns t, t+256, ...; stage 2 = pv_sum_slices over the chunks
+// Column sums, stage 1: a workgroup owns a 1024-row chunk x 512-column (bf16: 8 per lane) / 256-column (fp32: 4 per lane)
+// strip; its 4 waves interleave the rows with 16-byte loads and combine through LDS into ws[chunk][C].  Stage 2 sums the
+// chunks: a workgroup per 64 columns, 4 waves striding the chunk list.
 template <bool BF16>
 __global__ __launch_bounds__(256) void pv_colsum_kernel(const void* __restrict__ src, float* __restrict__ ws, int64_t R, int C) {
-    const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        if (BF16) {
-            const uint16_t* p = reinterpret_cast<const uint16_t*>(src);
-            for (int64_t r = r0; r < r1; ++r) s += pv_bf2f(p[r * C + c]);
-        } else {
-            const float* p = reinterpret_cast<const float*>(src);
-            for (int64_t r = r0; r < r1; ++r) s += p[r * C + c];
+    constexpr int VW = BF16 ? 8 : 4;
+    __shared__ float red[4][64 * VW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * VW;
+    const int64_t r0 = (int64_t)blockIdx.y * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
+    float acc[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) acc[k] = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int64_t r = r0 + wave; r < r1; r += 4) {
+            if (BF16) {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(src) + r * C + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+                    acc[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xffff0000u);
+                }
+            } else {
+                const float4 w = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + r * C + c);
+                acc[0] += w.x; acc[1] += w.y; acc[2] += w.z; acc[3] += w.w;
+            }
         }
-        ws[(int64_t)blockIdx.x * C + c] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < VW; ++k) red[wave][lane * VW + k] = acc[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * VW; e += 256) {
+        const int cc = blockIdx.x * 64 * VW + e;
+        if (cc < C) ws[(int64_t)blockIdx.y * C + cc] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pv_colsum_stage2_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t chunks, int C, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t t = wave; t < chunks; t += 4) s += ws[t * C + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        out[c] = accumulate ? out[c] + v : v;
     }
 }
 
 extern "C" int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream) {
     if (!src || !out || !ws || R <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
-    if (C % 4 || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15)) return PV_ERR_UNSUPPORTED;
+    const int vw = src_is_bf16 ? 8 : 4;
+    if (C % vw || ((uintptr_t)src & 15) || C > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     const int64_t chunks = (R + 1023) / 1024;
-    if (src_is_bf16) PV_LAUNCH(pv_colsum_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
-    else PV_LAUNCH(pv_colsum_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
+    if (chunks > 65535) return PV_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((C / vw + 63) / 64), (unsigned)chunks);
+    if (src_is_bf16) PV_LAUNCH(pv_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
+    else PV_LAUNCH(pv_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
-    return pv_sum_slices_f32(ws, out, C, chunks, accumulate, stream);
+    PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, out, chunks, (int)C, accumulate);
+    return pv_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -26,7 +26,8 @@ def test_transpose_exact(ops, R, C):
     assert torch.equal(y, x.t().contiguous())
 
 
-@pytest.mark.parametrize("R,C,dt", [(5, 8, torch.float32), (1024, 768, torch.bfloat16), (4099, 128, torch.float32), (20000, 3072, torch.bfloat16)])
+@pytest.mark.parametrize("R,C,dt", [(5, 8, torch.float32), (1024, 768, torch.bfloat16), (4099, 128, torch.float32), (20000, 3072, torch.bfloat16),
+                                    (3, 2567 * 8, torch.float32), (2050, 40, torch.bfloat16)])
 def test_colsum(ops, R, C, dt):
     x = _bf(R, C, seed=R).to(dt)
     out = torch.full((C,), 3.0, device="cuda")
