@@ -75,6 +75,9 @@ int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const flo
 /* precision mode "bf16x3" (split operands concatenated along K): */
 #define PV_EPI_BIAS_F32 4             /* out f32 = (acc + bias[n]) * (n < qcols ? qscale : 1)           [in-proj, fp32 q|k|v]  */
 #define PV_EPI_BIAS_GELU_SPLIT_BF16 5 /* out bf16 [M, 3N] = [hi | lo | hi] of gelu_erf(acc + bias[n]), ldo >= 3N [MLP fc1]    */
+/* training path (ABI v4): */
+#define PV_EPI_BIAS_GELU_PAIR_BF16  6   /* out bf16 [M, 2N] (ldo >= 2N): cols [0,N) = gelu(acc+bias), cols [N,2N) = acc+bias (saved for backward) */
+#define PV_EPI_GELU_GRAD_BF16       7   /* out bf16 = (acc+bias) * gelu'(pre[m][n]), pre = bf16 matrix passed in `res` (row stride ldr elements) */
 
 typedef struct pv_gemm_args {
     const uint16_t* A;       /* bf16 [M,K], row stride lda            (activations)                    */
@@ -139,9 +142,9 @@ int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S
 
 /* out[n] (+)= sum_t partials[t*n_elems + n]: reduces split-K slices (accumulate != 0 adds to the existing out). fp32. */
 int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream);
-/* bf16 [R,C] row-major -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be a multiple
- * of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
-int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream);
+/* bf16 [R,C] (row stride lds >= C) -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be
+ * a multiple of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
+int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream);
 /* LayerNorm backward (models/blocks.py:60,77): x fp32 [rows,D] (the saved LN input), dy bf16 [rows,D], gamma fp32 [D];
  * dx_out = (dres_in or 0) + dL/dx, fp32 [rows,D] (may alias dres_in); dgb fp32 [2,D] (+)= (dgamma, dbeta).
  * ws: fp32 scratch of >= min(ceil(rows/4),1024)*2*D floats.  D % 4 == 0, D <= 1024. */

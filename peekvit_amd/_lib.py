@@ -21,6 +21,7 @@ _i64, _f32, _p, _i32 = C.c_int64, C.c_float, C.c_void_p, C.c_int32
 
 PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_BIAS_POS_F32 = 0, 1, 2, 3
 PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_SPLIT_BF16 = 4, 5
+PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_GELU_GRAD_BF16 = 6, 7
 
 
 class GemmArgs(C.Structure):
@@ -46,7 +47,7 @@ SIGNATURES = {
     "pv_layernorm_split_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_attention_f32_split": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_sum_slices_f32": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
-    "pv_transpose_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "pv_transpose_bf16": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "pv_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, C.c_int, _p]),
     "pv_gelu_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "pv_gelu_bwd_bf16": (C.c_int, [_p, _p, _p, _i64, _p]),

@@ -25,6 +25,18 @@ __device__ __forceinline__ float pv_gelu_lut(float x, TabPtr tab) {
     return x * fmaf(fr, e[1], e[0]);
 }
 
+// gelu'(x) = Phi(x) + x * phi(x): Phi from the same table, phi(x) = exp(-x^2/2)/sqrt(2 pi) by one v_exp
+template <typename TabPtr>
+__device__ __forceinline__ float pv_gelu_grad_lut(float x, TabPtr tab) {
+    float t = fmaf(x, 256.0f, 2048.0f);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, 4095.9998f);
+    const int i = (int)t;
+    const float fr = t - (float)i;
+    const pv_f32x2_t e = tab[i];
+    const float u = x * 0.84932180028801904f;                      // sqrt(0.5*log2(e)): exp(-x^2/2) = exp2(-u*u)
+    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(-(u * u)), fmaf(fr, e[1], e[0]));
+}
+
 struct GemmDev {
     const uint16_t* A;
     const uint16_t* W;
@@ -108,6 +120,19 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         *reinterpret_cast<u32x2*>(o) = (u32x2){a.hi, b.hi};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){a.lo, b.lo};
         *reinterpret_cast<u32x2*>(o + 2 * p.N) = (u32x2){a.hi, b.hi};
+    } else if (EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
+        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
+        *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
+        *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
+    } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
+        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + n);
+        const float x0 = __builtin_bit_cast(float, w[0] << 16), x1 = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+        const float x2 = __builtin_bit_cast(float, w[1] << 16), x3 = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+        u32x2 o = {pv_pack_bf16x2(v0 * pv_gelu_grad_lut(x0, tab), v1 * pv_gelu_grad_lut(x1, tab)),
+                   pv_pack_bf16x2(v2 * pv_gelu_grad_lut(x2, tab), v3 * pv_gelu_grad_lut(x3, tab))};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else {   // PV_EPI_BIAS_POS_F32
         const int img = m / p.rpi, pi = m - img * p.rpi;
         const int64_t orow = (int64_t)img * p.rpo + p.row_off + pi;
@@ -389,7 +414,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
     PV_STAMP(0);
-    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
+    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) {
         // GELU table (32 KiB) into the LDS above the staging buffers: the OLDEST operations of the kernel, so every later
         // counted wait covers them and nothing else changes
 #pragma unroll
@@ -423,13 +448,15 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
     const int g = lane >> 4, i16 = lane & 15;
-    if (EPI == PV_EPI_BIAS_BF16 || (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16)) {
+    if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
         // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7).  SPLIT (precision mode): the fp32
         // results stay in the accumulators; pass 0 stores their bf16 "hi" image to planes 0 and 2 of the [M, 3N] output, pass 1
         // the "lo" image (v - hi) to plane 1.
+        // PAIR (training forward): pass 0 stores bf16 of the raw pre-activation to plane 1 of the [M, 2N] output, pass 1 its GELU to plane 0.
         constexpr bool SPLIT = EPI == PV_EPI_BIAS_GELU_SPLIT_BF16;
+        constexpr bool PAIR = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
 #pragma unroll
-        for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+        for (int pass = 0; pass < (SPLIT || PAIR ? 2 : 1); ++pass) {
             if (pass == 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                      // pass 0's image has been read by every wave
@@ -443,7 +470,14 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
                     const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
                     u32x4 pk;
-                    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
+                    if (PAIR) {
+                        if (pass == 1) {
+                            const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
+                        }
+                        pk = (u32x4){pv_pack_bf16x2(lo[0], lo[1]), pv_pack_bf16x2(lo[2], lo[3]), pv_pack_bf16x2(hi[0], hi[1]), pv_pack_bf16x2(hi[2], hi[3])};
+                    } else if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
                         if (pass == 0) {
                             const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
 #pragma unroll
@@ -473,7 +507,9 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
                 if (m0 + row < p.M && n0 + (lane & 31) * 8 < p.N) {
                     uint16_t* o = ob + (int64_t)(m0 + row) * p.ldo;
-                    if (!SPLIT) {
+                    if (PAIR) {
+                        *reinterpret_cast<u32x4*>(pass == 0 ? o + p.N : o) = v;
+                    } else if (!SPLIT) {
                         *reinterpret_cast<u32x4*>(o) = v;
                     } else if (pass == 0) {
                         *reinterpret_cast<u32x4*>(o) = v;
@@ -500,6 +536,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 if (EPI == PV_EPI_BIAS_F32) {
                     orow[j] = m;
                     rr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved bf16 pre-activation row, 512 B per instruction
+                    orow[j] = m;
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + ncol);
+                    rr[j] = (f32x4){__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                                    __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     orow[j] = m;
                     rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
@@ -533,10 +574,18 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 if (EPI == PV_EPI_BIAS_F32) {
                     const float qs = ncol < p.qcols ? p.qscale : 1.0f;
                     o = (f32x4){v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs};
+                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
+                    const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+                    o = (f32x4){v[0] * pv_gelu_grad_lut(rr[j][0], tab), v[1] * pv_gelu_grad_lut(rr[j][1], tab),
+                                v[2] * pv_gelu_grad_lut(rr[j][2], tab), v[3] * pv_gelu_grad_lut(rr[j][3], tab)};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
                 else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
-                if (m0 + ps * 128 + row < p.M && col_ok)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
+                if (m0 + ps * 128 + row < p.M && col_ok) {
+                    if (EPI == PV_EPI_GELU_GRAD_BF16)
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow[j] * p.ldo + ncol) = (u32x2){pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
+                    else
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
+                }
             }
         }
     }
@@ -646,7 +695,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static bool attr_set = false;
-    constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
+    constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
@@ -695,6 +744,7 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
         if (((uintptr_t)a->ln_out & 7) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return PV_ERR_INVALID_ARG;
     }
     if (a->epilogue == PV_EPI_BIAS_RES_F32 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15))) return PV_ERR_INVALID_ARG;
+    if (a->epilogue == PV_EPI_GELU_GRAD_BF16 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 7))) return PV_ERR_INVALID_ARG;
     if (a->epilogue == PV_EPI_BIAS_POS_F32 &&
         (!a->pos || a->rows_per_img_in <= 0 || a->rows_per_img_out < a->rows_per_img_in + a->row_off || a->row_off < 0 || ((uintptr_t)a->pos & 15)))
         return PV_ERR_INVALID_ARG;
@@ -730,6 +780,10 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
         case PV_EPI_BIAS_GELU_SPLIT_BF16:
             if (a->ldo < 3 * a->N) return PV_ERR_INVALID_ARG;
             return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_SPLIT_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_SPLIT_BF16>(p, s);
+        case PV_EPI_BIAS_GELU_PAIR_BF16:
+            if (a->ldo < 2 * a->N) return PV_ERR_INVALID_ARG;
+            return big ? pv_launch_gemm256<PV_EPI_BIAS_GELU_PAIR_BF16>(p, s) : pv_launch_gemm128<PV_EPI_BIAS_GELU_PAIR_BF16>(p, s);
+        case PV_EPI_GELU_GRAD_BF16: return big ? pv_launch_gemm256<PV_EPI_GELU_GRAD_BF16>(p, s) : pv_launch_gemm128<PV_EPI_GELU_GRAD_BF16>(p, s);
         default: return PV_ERR_INVALID_ARG;
     }
 }

@@ -183,7 +183,7 @@ extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_el
 // 64 x 64 tiles through LDS.  Fast path (C % 8 == 0, ldd % 8 == 0, 16-byte aligned): 16-byte global loads and stores, the
 // transposition happens in the LDS read (8 two-byte reads down a tile column).  Otherwise element-wise.
 template <bool VEC>
-__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C, int64_t ldd) {
+__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C, int64_t lds, int64_t ldd) {
     __shared__ uint16_t tile[64][72];          // 144-byte rows: 16-byte aligned chunks, 36-bank pitch
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     if (VEC) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __res
         for (int h = 0; h < 2; ++h) {
             const int64_t r = r0 + rr + 32 * h, c = c0 + ch * 8;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(src + r * C + c);
+            if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(src + r * lds + c);
             *reinterpret_cast<u32x4*>(&tile[rr + 32 * h][ch * 8]) = v;
         }
         __syncthreads();
@@ -210,20 +210,20 @@ __global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __res
     } else {
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
         for (int i = ty; i < 64; i += 4)
-            tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * C + c0 + tx] : (uint16_t)0;
+            tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * lds + c0 + tx] : (uint16_t)0;
         __syncthreads();
         for (int i = ty; i < 64; i += 4)
             if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
     }
 }
 
-extern "C" int pv_transpose_bf16(const uint16_t* src, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream) {
-    if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return PV_ERR_INVALID_ARG;
+extern "C" int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || ldd < R || lds < C) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ldd + 63) / 64));
     if (grid.y > 65535u) return PV_ERR_UNSUPPORTED;
-    const bool vec = C % 8 == 0 && ldd % 8 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
-    if (vec) PV_LAUNCH(pv_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
-    else PV_LAUNCH(pv_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, ldd);
+    const bool vec = C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
+    if (vec) PV_LAUNCH(pv_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds, ldd);
+    else PV_LAUNCH(pv_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds, ldd);
     return pv_check_launch();
 }
 

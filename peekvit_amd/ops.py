@@ -143,7 +143,7 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag=""):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
     ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
     ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
@@ -155,14 +155,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
                     row_scale=row_scale.data_ptr() if row_scale is not None else 0,
                     pos=pos.data_ptr() if pos is not None else 0,
-                    M=M, N=N, K=K, lda=K, ldw=w.shape[-1], ldo=out.shape[-1],
-                    ldr=res.shape[-1] if res is not None else 0,
+                    M=M, N=N, K=K, lda=a.stride(0) if a.dim() == 2 else K, ldw=w.stride(0) if w.dim() == 2 else w.shape[-1],
+                    ldo=out.stride(-2) if out.dim() >= 2 else out.shape[-1],
+                    ldr=(res.stride(0) if res.dim() == 2 else res.shape[-1]) if res is not None else 0,
                     rows_per_img_in=rows_per_img_in, rows_per_img_out=rows_per_img_out, row_off=row_off,
                     qcols=qcols, qscale=float(qscale), epilogue=epilogue,
                     ln_gamma=ln[0].data_ptr() if ln else 0, ln_beta=ln[1].data_ptr() if ln else 0,
                     ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
                     ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit))
-    with _timed("pv_gemm_bf16", a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
+    with _timed("pv_gemm_bf16" + tag, a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
         check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
     return out
@@ -207,15 +208,16 @@ def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = Fal
 
 
 def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
-    """bf16 [R,C] -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
-    _chk(src, torch.bfloat16, "src")
+    """bf16 [R,C] (row-strided view allowed) -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
+    if not (src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1):
+        raise _lib.PeekvitHipError("transpose: expected a 2-D bf16 GPU tensor with unit column stride")
     R, Cc = src.shape
     ldd = (R + pad_to - 1) // pad_to * pad_to
     if out is None:
         out = torch.empty((Cc, ldd), dtype=torch.bfloat16, device=src.device)
     assert out.shape == (Cc, ldd) and out.is_contiguous()
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
-        check(_lib.load().pv_transpose_bf16(_ptr(src), _ptr(out), R, Cc, ldd, _stream(src)), "pv_transpose_bf16")
+        check(_lib.load().pv_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), R, Cc, ldd, _stream(src)), "pv_transpose_bf16")
     _count()
     return out
 

@@ -4,10 +4,10 @@ autograd Functions so that the reference's loop (train/train.py:112-121: `out = 
 
 Per encoder block (reference models/vit.py:45-55), R = B*S token rows:
   forward   h1 = LN1(x) | qkv = h1.Win^T+b (q pre-scaled) | att = attention(qkv) | x1 = x + att.Wo^T+b | h2 = LN2(x1)
-            pre = h2.W1^T+b | gl = gelu(pre) | out = x1 + gl.W2^T+b             saved: x, h1, qkv, att, x1, h2, pre, gl
+            [gl | pre] = fc1 epilogue pair: pre = h2.W1^T+b, gl = gelu(pre) | out = x1 + gl.W2^T+b
+                                                                         saved: x, h1, qkv, att, x1, h2, [gl | pre]
   backward  d2 = bf16(dout)
-            dgl = d2.W2        dW2 = d2^T.gl     db2 = colsum(d2)
-            dpre = dgl*gelu'(pre)
+            dpre = (d2.W2)*gelu'(pre)  [one GEMM, PV_EPI_GELU_GRAD_BF16]      dW2 = d2^T.gl     db2 = colsum(d2)
             dh2 = dpre.W1      dW1 = dpre^T.h2   db1 = colsum(dpre)
             dx1 = dout + LN2'(dh2)               (dgamma2, dbeta2)
             d1 = bf16(dx1)
@@ -30,7 +30,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import PV_EPI_BIAS_BF16, PV_EPI_BIAS_POS_F32, PV_EPI_BIAS_RES_F32, PeekvitHipError
+from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_GELU_GRAD_BF16)
 from .engine import _f32, bf16_weight, workspace
 
 _wtcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
@@ -73,11 +73,9 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str) -> torch.Tensor:
         ksplit *= 2
     out = torch.empty((No, Ni), dtype=torch.float32, device=dev)
     if ksplit == 1:
-        from ._lib import PV_EPI_BIAS_F32
-        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32)
+        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32, tag="[wgrad]")
     part = workspace.get("wg_part", (ksplit, No, Ni), torch.float32, dev)
-    from ._lib import PV_EPI_BIAS_F32
-    ops.gemm(dy_t, x_t, None, part, PV_EPI_BIAS_F32, ksplit=ksplit)
+    ops.gemm(dy_t, x_t, None, part, PV_EPI_BIAS_F32, ksplit=ksplit, tag="[wgrad]")
     return ops.sum_slices(part, out)
 
 
@@ -104,8 +102,8 @@ class BlockFn(torch.autograd.Function):
         att = torch.empty((R, D), dtype=bf, device=dev)
         x1 = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         h2 = torch.empty((R, D), dtype=bf, device=dev)
-        pre = torch.empty((R, Mh), dtype=bf, device=dev)
-        gl = torch.empty((R, Mh), dtype=bf, device=dev)
+        pair = torch.empty((R, 2 * Mh), dtype=bf, device=dev)           # [gelu(pre) | pre]: one fc1 epilogue writes both
+        gl, pre = pair[:, :Mh], pair[:, Mh:]
         out = torch.empty_like(x)
         qscale = float(dh) ** -0.5
         ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1)
@@ -113,18 +111,18 @@ class BlockFn(torch.autograd.Function):
         ops.attention(qkv, att, B, S, H, dh)
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D))
         ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2)
-        ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pre, PV_EPI_BIAS_BF16, M=R)
-        ops.gelu(pre, gl)
+        ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=R)
         ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
-        ctx.save_for_backward(x, h1, qkv, att, x1, h2, pre, gl)
+        ctx.save_for_backward(x, h1, qkv, att, x1, h2, pair)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         blk = ctx.blk
-        x, h1, qkv, att, x1, h2, pre, gl = ctx.saved_tensors
+        x, h1, qkv, att, x1, h2, pair = ctx.saved_tensors
         B, S, D, H, dh, Mh, qscale = ctx.dims
+        gl, pre = pair[:, :Mh], pair[:, Mh:]
         mha = blk.self_attention.self_attention
         R, dev, bf = B * S, x.device, torch.bfloat16
         dout = dout.float() if dout.dtype != torch.float32 else dout
@@ -135,13 +133,12 @@ class BlockFn(torch.autograd.Function):
         d2 = ops.cast_bf16(dout, ws.get("bw_d", (R, D), bf, dev))
         db2 = _colsum(d2)
         dw2 = _wgrad(d2, gl, "fc2")
-        dgl = ws.get("bw_dgl", (R, Mh), bf, dev)
-        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dgl, PV_EPI_BIAS_BF16, M=R)
-        dpre = ops.gelu_bwd(pre, dgl)                                           # in place
+        dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
+        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]")
         db1 = _colsum(dpre)
         dw1 = _wgrad(dpre, h2, "fc1")
         dhid = ws.get("bw_dh", (R, D), bf, dev)
-        ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R)
+        ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
         dgb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
         ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps)
@@ -150,12 +147,12 @@ class BlockFn(torch.autograd.Function):
         dbo = _colsum(d1)
         dwo = _wgrad(d1, att, "proj")
         datt = ws.get("bw_datt", (R, D), bf, dev)
-        ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R)
+        ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
         ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale)
         dbin = _colsum(dqkv)
         dwin = _wgrad(dqkv, h1, "qkv")
-        ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R)
+        ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dgb1 = torch.empty((2, D), dtype=torch.float32, device=dev)
         ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps)

@@ -171,3 +171,24 @@ def test_training_step_gradients(monkeypatch, name, B):
         worst = max(worst, err)
         assert err < 3e-2, (n, err)
     print("worst parameter-gradient rel-L2:", worst)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048, 768, 256), (4096, 1536, 384), (2300, 128, 64)])
+def test_gemm_training_epilogues(ops, M, N, K):
+    """PV_EPI_BIAS_GELU_PAIR_BF16 ([gelu | pre] in one pass) and PV_EPI_GELU_GRAD_BF16 (product * gelu'(pre)), both tile kernels."""
+    from peekvit_amd._lib import PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_GELU_GRAD_BF16
+    a, w = _bf(M, K, seed=M), _bf(N, K, seed=N + 1, scale=K ** -0.5)
+    bias = torch.randn(N, device="cuda") * 0.1
+    pair = torch.full((M, 2 * N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, bias, pair, PV_EPI_BIAS_GELU_PAIR_BF16)
+    pre = a.float() @ w.float().t() + bias
+    assert rel_l2(pair[:, N:].float(), pre) < 3e-3 and rel_l2(pair[:, :N].float(), torch.nn.functional.gelu(pre)) < 3e-3
+    assert (pair[:, N:].float() - pre).abs().max() <= pre.abs().max() * 2 ** -8
+    # gradient epilogue: out = (a . w^T) * gelu'(x) with x = the stored bf16 pre-activation plane (a row-strided view)
+    x = pair[:, N:]
+    xr = x.float().requires_grad_(True)
+    torch.nn.functional.gelu(xr).sum().backward()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, None, out, PV_EPI_GELU_GRAD_BF16, res=x)
+    ref = (a.float() @ w.float().t()) * xr.grad
+    assert rel_l2(out.float(), ref) < 3e-3
