@@ -144,12 +144,16 @@ int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S
 int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream);
 /* bf16 [R,C] (row stride lds >= C) -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be
  * a multiple of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
-int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream);
+/* colsum_out (fp32 [C], optional): also the column sums of src (the bias gradient when src = dY), from the same pass;
+ * colsum_ws: fp32 scratch [ceil(ldd/1024)*C], required with colsum_out. */
+int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, float* colsum_out,
+                      float* colsum_ws, void* stream);
 /* LayerNorm backward (models/blocks.py:60,77): x fp32 [rows,D] (the saved LN input), dy bf16 [rows,D], gamma fp32 [D];
- * dx_out = (dres_in or 0) + dL/dx, fp32 [rows,D] (may alias dres_in); dgb fp32 [2,D] (+)= (dgamma, dbeta).
+ * dx_out = (dres_in or 0) + dL/dx, fp32 [rows,D] (may alias dres_in); dx_bf16 (optional): the same values as bf16 (the
+ * operand of the next data/weight-gradient GEMMs); dgb fp32 [2,D] (+)= (dgamma, dbeta).
  * ws: fp32 scratch of >= min(ceil(rows/4),1024)*2*D floats.  D % 4 == 0, D <= 1024. */
-int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, float* dgb,
-                     float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
+int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, uint16_t* dx_bf16,
+                     float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
 /* Training-path GELU (models/blocks.py:82) on bf16 streams: out = gelu(pre);  dpre = dg * gelu'(pre) (may alias dg). n % 8 == 0. */
 int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream);
 int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream);

@@ -180,50 +180,96 @@ extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_el
     return pv_check_launch();
 }
 
-// 64 x 64 tiles through LDS.  Fast path (C % 8 == 0, ldd % 8 == 0, 16-byte aligned): 16-byte global loads and stores, the
-// transposition happens in the LDS read (8 two-byte reads down a tile column).  Otherwise element-wise.
-template <bool VEC>
-__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C, int64_t lds, int64_t ldd) {
+// 64 x 64 tiles through LDS; a workgroup walks a 64-column strip over 1024 source rows (16 tiles).  Fast path (C, lds, ldd
+// multiples of 8, 16-byte aligned): 16-byte global loads and stores, the transposition happens in the LDS read (8 two-byte
+// reads down a tile column).  CSUM: the strip's column sums over those 1024 rows fall out of the loaded registers and go
+// to ws[chunk][C] (bias gradient = column sums of the dY being transposed for the weight gradient; pv_colsum stage 2 ends it).
+template <bool VEC, bool CSUM>
+__global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C,
+                                                           int64_t lds, int64_t ldd, float* __restrict__ ws) {
     __shared__ uint16_t tile[64][72];          // 144-byte rows: 16-byte aligned chunks, 36-bank pitch
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    if (VEC) {
-        const int rr = threadIdx.x >> 3, ch = threadIdx.x & 7;
+    __shared__ float red[32][65];
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int64_t rbeg = (int64_t)blockIdx.y * 1024, rend = rbeg + 1024 < ldd ? rbeg + 1024 : ldd;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int rr = threadIdx.x >> 3, ch = threadIdx.x & 7;
+    for (int64_t r0 = rbeg; r0 < rend; r0 += 64) {
+        if (VEC) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t r = r0 + rr + 32 * h, c = c0 + ch * 8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(src + r * lds + c);
-            *reinterpret_cast<u32x4*>(&tile[rr + 32 * h][ch * 8]) = v;
-        }
-        __syncthreads();
+            for (int h = 0; h < 2; ++h) {
+                const int64_t r = r0 + rr + 32 * h, c = c0 + ch * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(src + r * lds + c);
+                *reinterpret_cast<u32x4*>(&tile[rr + 32 * h][ch * 8]) = v;
+                if (CSUM) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int oc = rr + 32 * h;                                  // output row = source column
-            const int64_t orow = c0 + oc, ocol = r0 + ch * 8;
-            if (orow < C && ocol < ldd) {
-                uint32_t w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[ch * 8 + 2 * k][oc] | ((uint32_t)tile[ch * 8 + 2 * k + 1][oc] << 16);
-                *reinterpret_cast<u32x4*>(dst + orow * ldd + ocol) = (u32x4){w[0], w[1], w[2], w[3]};
+                    for (int k = 0; k < 4; ++k) {
+                        cs[2 * k] += __builtin_bit_cast(float, v[k] << 16);
+                        cs[2 * k + 1] += __builtin_bit_cast(float, v[k] & 0xffff0000u);
+                    }
+                }
             }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int oc = rr + 32 * h;                                  // output row = source column
+                const int64_t orow = c0 + oc, ocol = r0 + ch * 8;
+                if (orow < C && ocol < ldd) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[ch * 8 + 2 * k][oc] | ((uint32_t)tile[ch * 8 + 2 * k + 1][oc] << 16);
+                    *reinterpret_cast<u32x4*>(dst + orow * ldd + ocol) = (u32x4){w[0], w[1], w[2], w[3]};
+                }
+            }
+        } else {
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+            for (int i = ty; i < 64; i += 4) {
+                const uint16_t v = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * lds + c0 + tx] : (uint16_t)0;
+                tile[i][tx] = v;
+                if (CSUM) cs[0] += pv_bf2f(v);
+            }
+            __syncthreads();
+            for (int i = ty; i < 64; i += 4)
+                if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
         }
-    } else {
-        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-        for (int i = ty; i < 64; i += 4)
-            tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * lds + c0 + tx] : (uint16_t)0;
         __syncthreads();
-        for (int i = ty; i < 64; i += 4)
-            if (c0 + i < C && r0 + tx < ldd) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];      // columns R..ldd-1 are zero padding
+    }
+    if (CSUM) {
+        if (VEC) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[rr][ch * 8 + k] = cs[k];
+        } else if (threadIdx.x < 64 * 4) {
+            red[threadIdx.x >> 6][threadIdx.x & 63] = cs[0];
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+            float t = 0.f;
+            for (int k = 0; k < (VEC ? 32 : 4); ++k) t += red[k][threadIdx.x];
+            ws[(int64_t)blockIdx.y * C + c0 + threadIdx.x] = t;
+        }
     }
 }
 
-extern "C" int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, void* stream) {
+__global__ __launch_bounds__(256) void pv_colsum_stage2_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t chunks, int C, int accumulate);
+
+extern "C" int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, float* colsum_out,
+                                 float* colsum_ws, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || ldd < R || lds < C) return PV_ERR_INVALID_ARG;
-    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ldd + 63) / 64));
-    if (grid.y > 65535u) return PV_ERR_UNSUPPORTED;
+    if (colsum_out && !colsum_ws) return PV_ERR_INVALID_ARG;
+    const int64_t chunks = (ldd + 1023) / 1024;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)chunks);
+    if (chunks > 65535 || C > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     const bool vec = C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
-    if (vec) PV_LAUNCH(pv_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds, ldd);
-    else PV_LAUNCH(pv_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds, ldd);
+    hipStream_t s = (hipStream_t)stream;
+    if (colsum_out) {
+        if (vec) PV_LAUNCH((pv_transpose_kernel<true, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws);
+        else PV_LAUNCH((pv_transpose_kernel<false, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws);
+        if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
+        PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, (const float*)colsum_ws, colsum_out, chunks, (int)C, 0);
+    } else {
+        if (vec) PV_LAUNCH((pv_transpose_kernel<true, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr);
+        else PV_LAUNCH((pv_transpose_kernel<false, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr);
+    }
     return pv_check_launch();
 }
 
@@ -402,7 +448,8 @@ extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma
 template <int NCH>
 __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres_in,
-                                                               float* __restrict__ dx_out, float* __restrict__ ws, int64_t rows, int D, float eps) {
+                                                               float* __restrict__ dx_out, uint16_t* __restrict__ dx_bf16, float* __restrict__ ws,
+                                                               int64_t rows, int D, float eps) {
     __shared__ float red[4][2][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
     float4 ag[NCH], ab[NCH], gm[NCH];
@@ -461,6 +508,7 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 o.z += rstd * (d[j].z - s1 - r.v[j].z * s2);
                 o.w += rstd * (d[j].w - s1 - r.v[j].w * s2);
                 reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
+                if (dx_bf16) reinterpret_cast<u32x2*>(dx_bf16 + row * D)[idx] = (u32x2){pv_pack_bf16x2(o.x, o.y), pv_pack_bf16x2(o.z, o.w)};
             }
         }
     }
@@ -476,17 +524,17 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
     }
 }
 
-extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, float* dgb,
-                                float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream) {
+extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out,
+                                uint16_t* dx_bf16, float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream) {
     if (!x || !dy || !gamma || !dx_out || !dgb || !ws || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
     if (D % 4 || D > 1024) return PV_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)dx_out & 15) || ((uintptr_t)dgb & 15) ||
-        ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15))) return PV_ERR_INVALID_ARG;
+        ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15)) || (dx_bf16 && ((uintptr_t)dx_bf16 & 7))) return PV_ERR_INVALID_ARG;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (ws_floats < blocks * 2 * D) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)blocks);
-#define LNB_LAUNCH(N) PV_LAUNCH(pv_layernorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, ws, rows, (int)D, eps)
+#define LNB_LAUNCH(N) PV_LAUNCH(pv_layernorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps)
     { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
 #undef LNB_LAUNCH
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;

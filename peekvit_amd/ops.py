@@ -207,7 +207,7 @@ def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = Fal
     return out
 
 
-def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
+def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1, colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 [R,C] (row-strided view allowed) -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
     if not (src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1):
         raise _lib.PeekvitHipError("transpose: expected a 2-D bf16 GPU tensor with unit column stride")
@@ -216,8 +216,10 @@ def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int
     if out is None:
         out = torch.empty((Cc, ldd), dtype=torch.bfloat16, device=src.device)
     assert out.shape == (Cc, ldd) and out.is_contiguous()
+    ws = torch.empty(((ldd + 1023) // 1024, Cc), dtype=torch.float32, device=src.device) if colsum_out is not None else None
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
-        check(_lib.load().pv_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), R, Cc, ldd, _stream(src)), "pv_transpose_bf16")
+        check(_lib.load().pv_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), R, Cc, ldd, _ptr(colsum_out), _ptr(ws), _stream(src)),
+              "pv_transpose_bf16")
     _count()
     return out
 
@@ -236,15 +238,15 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: torch.Tensor, dgb: torch.Tensor, eps: float,
-                  accumulate: bool = False):
+                  accumulate: bool = False, dx_bf16: Optional[torch.Tensor] = None):
     """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [2,D] (+)= (dgamma, dbeta).  x fp32 [rows,D], dy bf16 [rows,D]."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
     D = x.shape[-1]
     rows = x.numel() // D
     blocks = min((rows + 3) // 4, 1024)
     ws = torch.empty((blocks, 2 * D), dtype=torch.float32, device=x.device)
-    with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0)) * x.numel()):
-        check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dgb),
+    with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0)) * x.numel()):
+        check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dx_bf16), _ptr(dgb),
                                            _ptr(ws), ws.numel(), rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd")
     _count()
     return dx_out

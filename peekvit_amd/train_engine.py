@@ -59,13 +59,15 @@ def _pad_rows(R: int) -> int:
     return (R + q - 1) // q * q
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str) -> torch.Tensor:
-    """fp32 [No, Ni] = dy^T . x for bf16 dy [R, No], x [R, Ni]."""
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
+    """(dW fp32 [No, Ni] = dy^T . x,  db fp32 [No] = column sums of dy) for bf16 dy [R, No], x [R, Ni]; db falls out of the
+    transposition pass over dy."""
     R, No = dy.shape
     Ni = x.shape[1]
     Rp = _pad_rows(R)
     dev = dy.device
-    dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), torch.bfloat16, dev), pad_to=Rp)
+    db = torch.empty((No,), dtype=torch.float32, device=dev) if bias_grad else None
+    dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), torch.bfloat16, dev), pad_to=Rp, colsum_out=db)
     x_t = ops.transpose(x, workspace.get("wg_b", (Ni, Rp), torch.bfloat16, dev), pad_to=Rp)
     tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
     ksplit = 1
@@ -73,14 +75,19 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str) -> torch.Tensor:
         ksplit *= 2
     out = torch.empty((No, Ni), dtype=torch.float32, device=dev)
     if ksplit == 1:
-        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32, tag="[wgrad]")
+        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32, tag="[wgrad]"), db
     part = workspace.get("wg_part", (ksplit, No, Ni), torch.float32, dev)
     ops.gemm(dy_t, x_t, None, part, PV_EPI_BIAS_F32, ksplit=ksplit, tag="[wgrad]")
-    return ops.sum_slices(part, out)
+    return ops.sum_slices(part, out), db
 
 
-def _colsum(src: torch.Tensor) -> torch.Tensor:
-    return ops.colsum(src, torch.empty((src.shape[1],), dtype=torch.float32, device=src.device))
+def _bf16_grad(dout: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of an incoming fp32 gradient: the producer's LayerNorm-backward kernel already wrote one (attached to the
+    very tensor object autograd hands over) unless the gradient comes from stock ops (the head) or was touched since."""
+    hand = getattr(dout, "_pv_bf16", None)
+    if hand is not None and hand[1] == dout._version and hand[0].numel() == buf.numel():
+        return hand[0].view(buf.shape)
+    return ops.cast_bf16((dout if dout.is_contiguous() else dout.contiguous()).view(buf.shape), buf)
 
 
 class BlockFn(torch.autograd.Function):
@@ -126,36 +133,35 @@ class BlockFn(torch.autograd.Function):
         mha = blk.self_attention.self_attention
         R, dev, bf = B * S, x.device, torch.bfloat16
         dout = dout.float() if dout.dtype != torch.float32 else dout
-        dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
         ws = workspace
 
         # ---- MLP branch ------------------------------------------------------------------------------------
-        d2 = ops.cast_bf16(dout, ws.get("bw_d", (R, D), bf, dev))
-        db2 = _colsum(d2)
-        dw2 = _wgrad(d2, gl, "fc2")
+        dout3 = dout
+        dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
+        d2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
+        dw2, db2 = _wgrad(d2, gl, "fc2")
         dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]")
-        db1 = _colsum(dpre)
-        dw1 = _wgrad(dpre, h2, "fc1")
+        dw1, db1 = _wgrad(dpre, h2, "fc1")
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
         dgb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
-        ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps)
+        d1 = ws.get("bw_d1", (R, D), bf, dev)
+        ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
         # ---- attention branch ------------------------------------------------------------------------------
-        d1 = ops.cast_bf16(dx1, ws.get("bw_d", (R, D), bf, dev))
-        dbo = _colsum(d1)
-        dwo = _wgrad(d1, att, "proj")
+        dwo, dbo = _wgrad(d1, att, "proj")
         datt = ws.get("bw_datt", (R, D), bf, dev)
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
         ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale)
-        dbin = _colsum(dqkv)
-        dwin = _wgrad(dqkv, h1, "qkv")
+        dwin, dbin = _wgrad(dqkv, h1, "qkv")
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dgb1 = torch.empty((2, D), dtype=torch.float32, device=dev)
-        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps)
+        dxb = torch.empty((B, S, D), dtype=bf, device=dev)
+        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        dx._pv_bf16 = (dxb, dx._version)             # hand-off to the previous block's backward (see _bf16_grad)
         return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
 
@@ -202,8 +208,8 @@ class EmbedFn(torch.autograd.Function):
             ops.im2col(img if img.dtype == torch.float32 else img.float(), P, cols)
         dpatch32 = dtok[:, nsp:, :].contiguous().view(B * Np, D)
         dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), torch.bfloat16, dev))
-        dwc = _wgrad(dpatch, cols, "conv").view(model.conv_proj.weight.shape)
-        dbc = _colsum(dpatch)
+        dwc, dbc = _wgrad(dpatch, cols, "conv")
+        dwc = dwc.view(model.conv_proj.weight.shape)
         dpos = ops.colsum(dtok.view(B, S * D), torch.empty((S * D,), dtype=torch.float32, device=dev)).view(1, S, D)
         dcls = dpos[:, :ncls].clone()
         dreg = dpos[:, ncls:nsp].clone() if ctx.has_reg else None

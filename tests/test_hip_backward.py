@@ -101,6 +101,18 @@ def test_transpose_padded(ops):
     assert torch.equal(y[:, :197], x.t()) and (y[:, 197:] == 0).all()
 
 
+@pytest.mark.parametrize("R,C,ld", [(3000, 768, 768), (2049, 256, 512), (700, 36, 36), (5000, 130, 130)])
+def test_transpose_with_column_sums(ops, R, C, ld):
+    """The weight-gradient transposition of dY also yields the bias gradient (column sums) from the same pass; strided source."""
+    base = _bf(R, ld, seed=R + C, scale=0.3)
+    x = base[:, :C]
+    db = torch.full((C,), float("nan"), device="cuda")
+    y = ops.transpose(x, pad_to=1024, colsum_out=db)
+    Rp = (R + 1023) // 1024 * 1024
+    assert y.shape == (C, Rp) and torch.equal(y[:, :R], x.t()) and (y[:, R:] == 0).all()
+    assert rel_l2(db, x.double().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize("rows,D", [(7, 128), (1000, 192), (4099, 384), (3940, 768), (64, 1024)])
 def test_layernorm_backward(ops, rows, D):
     g = torch.Generator(device="cuda").manual_seed(rows)
@@ -113,7 +125,9 @@ def test_layernorm_backward(ops, rows, D):
     torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
     dx = torch.empty_like(x)
     dgb = torch.full((2, D), 7.0, device="cuda")
-    ops.layernorm_bwd(x, dy, gamma, dres, dx, dgb, 1e-6)
+    dxb = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_bwd(x, dy, gamma, dres, dx, dgb, 1e-6, dx_bf16=dxb)
+    assert torch.equal(dxb, dx.to(torch.bfloat16))
     assert rel_l2(dx, dres + xr.grad) < 5e-6
     assert rel_l2(dgb[0], gr.grad) < 5e-6 and rel_l2(dgb[1], br.grad) < 5e-6
     ops.layernorm_bwd(x, dy, gamma, None, dx, dgb, 1e-6, accumulate=True)
