@@ -138,6 +138,12 @@ int pv_layernorm_split_bf16(const float* x, int64_t ldx, const float* gamma, con
  * [hi | lo | hi] planes.  dh in {32,48,64}, S <= 208. */
 int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
 
+/* Weight-gradient GEMM without transposed copies ("TN"): out[t][m][n] = sum over K slice t of A[k][m] * W[k][n], with
+ * A = dY bf16 [K, M] (row stride lda), W = X bf16 [K, N] (row stride ldw), out fp32 [ksplit][M][ldo] partial slices for
+ * pv_sum_slices_f32.  Same struct as pv_gemm_bf16 (epilogue must be PV_EPI_BIAS_F32, bias NULL).  M, N multiples of 128;
+ * K a multiple of 128 * max(ksplit, 1).  dW = dY^T . X of train/train.py:118 loss.backward(). */
+int pv_gemm_tn_bf16(const pv_gemm_args* args, void* stream);
+
 /* ---- backward building blocks (SURVEY.md section 2b "B*": what train/train.py:118 `loss.backward()` needs) ---- */
 
 /* out[n] (+)= sum_t partials[t*n_elems + n]: reduces split-K slices (accumulate != 0 adds to the existing out). fp32. */

@@ -11,6 +11,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
 // exact-erf GELU by table: Phi(x) linearly interpolated from 4096 samples on [-8, 8) (pv_gelu_table.h; |error| <= 5e-7, the
 // same class as torch's fp32 F.gelu).  ~7 VALU + one 8-byte gather per value instead of ~20 issue slots for the erfc
 // polynomial (rcp + exp).  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2 kernel), so both
@@ -614,6 +616,226 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
     const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
     const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
     pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, tn * G2_BN);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN variant for weight gradients: out[m][n] = sum_k A[k][m] * B[k][n] straight from the row-major activations (A = dY
+// [K = token rows, M = out features], B = X [K, N = in features]) - no transposed copies.  Same 256 x 256 x 64 tile, 4-phase
+// schedule, counted vmcnt and wave-group stagger as pv_gemm256_tile; what changes is the LDS image and the fragment reads:
+//   half-tile slot = 64 k-rows x 128 columns (256-byte rows), staged by LDS-DMA in 1-KiB pieces of 4 k-rows (16 lanes read
+//   256 contiguous bytes of one k-row);  16-byte chunk c of k-row r lives at chunk c ^ s(r), s(r) = ((r&3)<<2)|(((r>>2)&1)<<1);
+//   a fragment (16 columns x 32 k) = two ds_read_b64_tr_b16 (k-rows kb+4g+q and kb+16+4g+q, q = 0..3): the 32 lanes of a
+//   half-wave then cover 8 k-rows x 32 B on all 64 banks exactly once.  Both operands use the same k order inside a fragment,
+//   so the products are unchanged.  Slots are ordered {A0: buf0, buf1 | A1 | B0 | B1} so that buffer and k offsets are
+//   ds_read immediates on 8 + 4 lane-constant bases.
+// Output: fp32 split-K slices out[slice][M][ldo] (slice = K range), reduced by pv_sum_slices_f32.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GemmDev p = p_in;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int slice = blockIdx.x / ntiles;
+    p.A += (int64_t)slice * p.k_slice * p.lda; p.W += (int64_t)slice * p.k_slice * p.ldw; p.K = p.k_slice;
+    p.out = reinterpret_cast<float*>(p.out) + slice * p.split_stride;
+    const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    constexpr int SLOT = 2 * G2_HALF;                 // one operand half: both K-tile buffers, 32 KiB
+
+    // ---- LDS-DMA sources -------------------------------------------------------------------------------------------
+    const int sw_s = ((lane >> 4) << 2) | ((wid & 1) << 1);          // s(r) of this lane's k-row (r&3 = lane>>4, (r>>2)&1 = wid&1)
+    const int scol = ((lane & 15) ^ sw_s) * 8;                       // logical column (elements) inside the 128-column half
+    const char* const a_blk = reinterpret_cast<const char*>(p.A + m0);
+    const char* const w_blk = reinterpret_cast<const char*>(p.W + n0);
+    // one per-lane byte offset per operand (piece j = 0, half 0); piece 1 = 32 k-rows further, half 1 = 256 bytes further: both
+    // are workgroup-uniform additions to the scalar base.  M, N are multiples of 128 (host check), so a half-tile is entirely
+    // inside or entirely outside the matrix: an outside half re-reads half 0 (its results are never stored).
+    const uint32_t oa = (uint32_t)((4 * wid + (lane >> 4)) * (int)p.lda + scol) * 2u;
+    const uint32_t ow = (uint32_t)((4 * wid + (lane >> 4)) * (int)p.ldw + scol) * 2u;
+    const int a_h1 = m0 + 256 <= p.M ? 256 : 0, w_h1 = n0 + 256 <= p.N ? 256 : 0;
+    char* const lds_piece = smem + wid * 1024;
+    const int64_t a_step = (int64_t)G2_BK * p.lda * 2, w_step = (int64_t)G2_BK * p.ldw * 2;
+    auto stage_a = [&](int buf, int h, int kt) __attribute__((always_inline)) {
+        const char* src = a_blk + kt * a_step + (h ? a_h1 : 0);
+        pv_glds16(src + oa, lds_piece + h * SLOT + buf * G2_HALF);
+        pv_glds16(src + (a_step >> 1) + oa, lds_piece + h * SLOT + buf * G2_HALF + 8192);
+    };
+    auto stage_b = [&](int buf, int h, int kt) __attribute__((always_inline)) {
+        const char* src = w_blk + kt * w_step + (h ? w_h1 : 0);
+        pv_glds16(src + ow, lds_piece + (2 + h) * SLOT + buf * G2_HALF);
+        pv_glds16(src + (w_step >> 1) + ow, lds_piece + (2 + h) * SLOT + buf * G2_HALF + 8192);
+    };
+
+    // ---- transposed fragment read bases ------------------------------------------------------------------------------
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int rl = 4 * g + tq;
+    const int sw_l = (tq << 2) | ((g & 1) << 1);
+    lds_cc* const lds0 = (lds_cc*)smem;
+    lds_cc* a_rd[8];
+    lds_cc* b_rd[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        a_rd[t] = lds0 + wr * SLOT + rl * 256 + (((2 * t + (tp >> 1)) ^ sw_l) << 4) + ((tp & 1) << 3);
+        asm volatile("" : "+v"(a_rd[t]));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        b_rd[t] = lds0 + (2 + (wc >> 1)) * SLOT + rl * 256 + (((2 * ((wc & 1) * 4 + t) + (tp >> 1)) ^ sw_l) << 4) + ((tp & 1) << 3);
+        asm volatile("" : "+v"(b_rd[t]));
+    }
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][4][2];
+    bf16x8 bfr[2][2];
+    typedef __attribute__((address_space(3))) s16x4 lds_s4;
+
+    // transposed reads as inline asm: the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of every ds_read_tr builtin
+    // while LDS-DMA is in flight (it cannot see that the pieces being staged are not the ones being read); the asm results are
+    // consumed only after the explicit s_waitcnt lgkmcnt(0) + barrier of TN_SYNC_LOADS.
+#define TN_FRAG(DST, BASE, OFF)                                                                                              \
+    do {                                                                                                                     \
+        s16x4 lo_, hi_;                                                                                                      \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(BASE), "n"(OFF));                               \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(BASE), "n"((OFF) + 4096));                      \
+        DST = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));                         \
+    } while (0)
+#define TN_READ_A(BUF, MH)                                                                                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)  \
+        TN_FRAG(af[MH][t_][ks_], a_rd[(MH) * 4 + t_], (BUF) * G2_HALF + ks_ * 8192);
+#define TN_READ_B(BUF, NH)                                                                                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)  \
+        TN_FRAG(bfr[t_][ks_], b_rd[(NH) * 2 + t_], (BUF) * G2_HALF + ks_ * 8192);
+#define TN_SYNC_LOADS()                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);
+#define TN_MFMA(MH, NH)                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)            \
+        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                            \
+            acc[(NH) * 2 + n_][(MH) * 4 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+                bfr[n_][ks_], af[MH][m_][ks_], acc[(NH) * 2 + n_][(MH) * 4 + m_], 0, 0, 0);                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto ktile = [&](auto buf_c, auto sb_c, auto sa_c, int kt) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool SB = decltype(sb_c)::value, SA = decltype(sa_c)::value;
+        TN_READ_B(BUF, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        TN_READ_A(BUF, 0)
+        if (SB) stage_b(BUF ^ 1, 0, kt + 1);
+        TN_SYNC_LOADS()
+        TN_MFMA(0, 0)
+        TN_READ_A(BUF, 1)
+        if (SB) stage_b(BUF ^ 1, 1, kt + 1);
+        TN_SYNC_LOADS()
+        TN_MFMA(1, 0)
+        TN_READ_B(BUF, 1)
+        if (SA) stage_a(BUF, 0, kt + 2);
+        TN_SYNC_LOADS()
+        TN_MFMA(1, 1)
+        if (SA) {
+            stage_a(BUF, 1, kt + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        TN_SYNC_LOADS()
+        TN_MFMA(0, 1)
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
+    stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
+    stage_a(1, 0, 1); stage_a(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 2) {
+        ktile(B0{}, T{}, T{}, kt);
+        ktile(B1{}, T{}, T{}, kt + 1);
+    }
+    ktile(B0{}, T{}, F{}, kt);
+    ktile(B1{}, F{}, F{}, kt + 1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef TN_FRAG
+#undef TN_READ_A
+#undef TN_READ_B
+#undef TN_SYNC_LOADS
+#undef TN_MFMA
+
+    // ---- epilogue: fp32 image (128 rows x 1 KiB per pass) so that every global store is a whole 1-KiB row segment ---------
+    typedef __attribute__((address_space(3))) char lds_c;
+    lds_c* const cimg = (lds_c*)smem;
+    const bool col_ok = n0 + lane * 4 < p.N;
+    const int ncol = col_ok ? n0 + lane * 4 : 0;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        if (ps == 1) __builtin_amdgcn_s_barrier();
+        if (wr == ps) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int row = mt * 16 + i16;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c = wc * 16 + nt * 4 + g;             // lane holds n = wc*64 + nt*16 + 4g + 0..3 of row m = mt*16 + i16
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = wid * 16 + j;
+            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((lane ^ (row & 7)) << 4));
+            const int m = m0 + ps * 128 + row;
+            if (m < p.M && col_ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + ncol) = v;
+        }
+    }
+}
+
+// out fp32 [ksplit][M][ldo] partial products of A^T . B over K slices; A bf16 [K, M] (row stride lda), B = args->W bf16 [K, N]
+// (row stride ldw).  M, N multiples of 128, K a multiple of 128 * ksplit.
+extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->W || !a->out || a->M < 8 || a->N < 8 || a->K <= 0) return PV_ERR_INVALID_ARG;
+    const int ks = a->ksplit > 1 ? a->ksplit : 1;
+    if (a->M % 128 || a->N % 128 || a->K % (ks * 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+    if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->M || a->ldw < a->N || a->ldo < a->N) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) || ((uintptr_t)a->out & 15)) return PV_ERR_INVALID_ARG;
+    if (a->epilogue != PV_EPI_BIAS_F32 || a->bias || a->qcols) return PV_ERR_INVALID_ARG;
+    if (a->M > 0x7fffffff || a->N > 0x7fffffff || a->K > 0x7fffffff || 64 * a->lda * 2 > 0x7fffffff || 64 * a->ldw * 2 > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    GemmDev p = {};
+    p.A = a->A; p.W = a->W; p.out = a->out;
+    p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+    p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
+    p.ksplit = ks; p.k_slice = (int)(a->K / ks); p.split_stride = a->M * a->ldo;
+    p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = 1;
+    if ((int64_t)p.tiles_m * p.tiles_n * ks > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    PV_LAUNCH(pv_gemm256_tn_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n * ks)), dim3(512), G2_LDS, (hipStream_t)stream, p);
+    return pv_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------

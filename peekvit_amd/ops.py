@@ -169,6 +169,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, part: torch.Tensor, ksplit: int, tag: str = "[wgrad]"):
+    """part[t] = (a[K_t, M])^T . b[K_t, N] over ksplit row slices: weight gradient straight from row-major bf16 activations
+    (row-strided 2-D views allowed).  part fp32 [ksplit, M, N]; reduce with sum_slices()."""
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and part.shape == (max(ksplit, 1), M, N) and part.is_contiguous()
+    args = GemmArgs(A=a.data_ptr(), W=b.data_ptr(), bias=0, out=part.data_ptr(), res=0, row_scale=0, pos=0, M=M, N=N, K=K,
+                    lda=a.stride(0), ldw=b.stride(0), ldo=N, ldr=0, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0,
+                    qscale=1.0, epilogue=_lib.PV_EPI_BIAS_F32, ln_gamma=0, ln_beta=0, ln_row_scale=0, ln_out=0, ln_eps=0.0,
+                    ksplit=int(ksplit))
+    with _timed("pv_gemm_tn_bf16" + tag, a.device, 2.0 * M * N * K, 2.0 * K * (M + N) + 4.0 * max(ksplit, 1) * M * N):
+        check(_lib.load().pv_gemm_tn_bf16(C.byref(args), _stream(a)), "pv_gemm_tn_bf16")
+    _count()
+    return part
+
+
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
     with _timed("pv_attention_bf16", qkv.device, 4.0 * B * H * S * S * dh, 8.0 * B * S * H * dh):
         check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_bf16")

@@ -59,26 +59,53 @@ def _pad_rows(R: int) -> int:
     return (R + q - 1) // q * q
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
-    """(dW fp32 [No, Ni] = dy^T . x,  db fp32 [No] = column sums of dy) for bf16 dy [R, No], x [R, Ni]; db falls out of the
-    transposition pass over dy."""
+def _wgrad_transposed(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, accumulate: bool, db=None):
+    """out (+)= dy^T . x through transposed copies (any shape): pv_transpose_bf16 x 2 -> NT GEMM with split-K -> slice sum.
+    db (optional fp32 [No]): column sums of dy from the same transposition pass."""
     R, No = dy.shape
     Ni = x.shape[1]
     Rp = _pad_rows(R)
     dev = dy.device
-    db = torch.empty((No,), dtype=torch.float32, device=dev) if bias_grad else None
     dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), torch.bfloat16, dev), pad_to=Rp, colsum_out=db)
     x_t = ops.transpose(x, workspace.get("wg_b", (Ni, Rp), torch.bfloat16, dev), pad_to=Rp)
     tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
     ksplit = 1
     while ksplit < 32 and tiles * ksplit < 512 and Rp % (ksplit * 2 * 128) == 0:
         ksplit *= 2
-    out = torch.empty((No, Ni), dtype=torch.float32, device=dev)
-    if ksplit == 1:
-        return ops.gemm(dy_t, x_t, None, out, PV_EPI_BIAS_F32, tag="[wgrad]"), db
     part = workspace.get("wg_part", (ksplit, No, Ni), torch.float32, dev)
     ops.gemm(dy_t, x_t, None, part, PV_EPI_BIAS_F32, ksplit=ksplit, tag="[wgrad]")
-    return ops.sum_slices(part, out), db
+    return ops.sum_slices(part, out, accumulate)
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
+    """(dW fp32 [No, Ni] = dy^T . x,  db fp32 [No] = column sums of dy) for bf16 dy [R, No], x [R, Ni] (row-strided views
+    allowed).  128-multiples of features: the TN kernel reads the row-major activations directly, split-K over the rows; the
+    < 128 * ksplit tail rows (and every other shape) go through the transposed-copy path."""
+    R, No = dy.shape
+    Ni = x.shape[1]
+    dev = dy.device
+    out = torch.empty((No, Ni), dtype=torch.float32, device=dev)
+    db = torch.empty((No,), dtype=torch.float32, device=dev) if bias_grad else None
+    if No % 128 == 0 and Ni % 128 == 0 and R >= 256 and not _NO_TN:
+        tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
+        s_ = 1
+        while s_ < 32 and tiles * s_ < 512 and R // (s_ * 2) >= 256:
+            s_ *= 2
+        k_slice = R // (128 * s_) * 128
+        r_main = k_slice * s_
+        part = workspace.get("wg_part", (s_, No, Ni), torch.float32, dev)
+        ops.gemm_tn(dy[:r_main], x[:r_main], part, s_)
+        ops.sum_slices(part, out)
+        if r_main < R:
+            _wgrad_transposed(dy[r_main:], x[r_main:], out, True)
+        if bias_grad:
+            ops.colsum(dy, db)
+        return out, db
+    _wgrad_transposed(dy, x, out, False, db)
+    return out, db
+
+
+_NO_TN = os.environ.get("PEEKVIT_AMD_WGRAD", "tn") != "tn"
 
 
 def _bf16_grad(dout: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:

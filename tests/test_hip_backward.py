@@ -206,3 +206,20 @@ def test_gemm_training_epilogues(ops, M, N, K):
     ops.gemm(a, w, None, out, PV_EPI_GELU_GRAD_BF16, res=x)
     ref = (a.float() @ w.float().t()) * xr.grad
     assert rel_l2(out.float(), ref) < 3e-3
+
+
+@pytest.mark.parametrize("K,M,N,ks,lda_pad", [(256, 128, 128, 1, 0), (1024, 256, 256, 4, 0), (4096, 768, 768, 8, 0), (2048, 384, 1536, 2, 0),
+                                              (3072, 2304, 768, 4, 0), (1024, 3072, 768, 2, 3072), (512, 128, 640, 2, 0)])
+def test_gemm_tn_weight_gradient(ops, K, M, N, ks, lda_pad):
+    """pv_gemm_tn_bf16: dW slices straight from row-major dY [K,M], X [K,N] (no transposed copies) vs fp32 matmul."""
+    dy_full = _bf(K, M + lda_pad, seed=K + M, scale=0.1)
+    dy = dy_full[:, :M]                                       # row-strided view when lda_pad > 0
+    x = _bf(K, N, seed=N + 3)
+    part = torch.full((ks, M, N), float("nan"), device="cuda")
+    ops.gemm_tn(dy, x, part, ks)
+    out = torch.empty(M, N, device="cuda")
+    ops.sum_slices(part, out)
+    ref = dy.float().t() @ x.float()
+    assert rel_l2(out, ref) < 2e-6
+    kslice = K // ks
+    assert rel_l2(part[ks - 1], dy[-kslice:].float().t() @ x[-kslice:].float()) < 2e-6
