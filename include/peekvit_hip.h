@@ -156,8 +156,9 @@ int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R
                       float* colsum_ws, void* stream);
 /* LayerNorm backward (models/blocks.py:60,77): x fp32 [rows,D] (the saved LN input), dy bf16 [rows,D], gamma fp32 [D];
  * dx_out = (dres_in or 0) + dL/dx, fp32 [rows,D] (may alias dres_in); dx_bf16 (optional): the same values as bf16 (the
- * operand of the next data/weight-gradient GEMMs); dgb fp32 [2,D] (+)= (dgamma, dbeta).
- * ws: fp32 scratch of >= min(ceil(rows/4),1024)*2*D floats.  D % 4 == 0, D <= 1024. */
+ * operand of the next data/weight-gradient GEMMs); dgb fp32 [3,D] (+)= (dgamma, dbeta, column sums of dx - of its bf16
+ * values when dx_bf16 is given: the bias gradient of the linear layer that produced the LN input's branch).
+ * ws: fp32 scratch of >= min(ceil(rows/4),1024)*3*D floats.  D % 4 == 0, D <= 1024. */
 int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, uint16_t* dx_bf16,
                      float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
 /* Training-path GELU (models/blocks.py:82) on bf16 streams: out = gelu(pre);  dpre = dg * gelu'(pre) (may alias dg). n % 8 == 0. */

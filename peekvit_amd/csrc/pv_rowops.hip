@@ -450,12 +450,11 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ dres_in,
                                                                float* __restrict__ dx_out, uint16_t* __restrict__ dx_bf16, float* __restrict__ ws,
                                                                int64_t rows, int D, float eps) {
-    __shared__ float red[4][2][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
-    float4 ag[NCH], ab[NCH], gm[NCH];
+    float4 ag[NCH], ab[NCH], ac[NCH], gm[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
+        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j]; ac[j] = ag[j];
         const int idx = lane + 64 * j;
         gm[j] = idx < nvec ? reinterpret_cast<const float4*>(gamma)[idx] : ag[j];
     }
@@ -496,8 +495,10 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
                 s2 += (d[j].x * v.x + d[j].y * v.y) + (d[j].z * v.z + d[j].w * v.w);
             }
-        s1 = pv_wave_sum(s1) * invD;
-        s2 = pv_wave_sum(s2) * invD;
+        // the two sums travel together through the butterfly
+        s1 *= invD; s2 *= invD;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = lane + 64 * j;
@@ -508,21 +509,34 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 o.z += rstd * (d[j].z - s1 - r.v[j].z * s2);
                 o.w += rstd * (d[j].w - s1 - r.v[j].w * s2);
                 reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
-                if (dx_bf16) reinterpret_cast<u32x2*>(dx_bf16 + row * D)[idx] = (u32x2){pv_pack_bf16x2(o.x, o.y), pv_pack_bf16x2(o.z, o.w)};
+                if (dx_bf16) {
+                    const u32x2 pk = {pv_pack_bf16x2(o.x, o.y), pv_pack_bf16x2(o.z, o.w)};
+                    reinterpret_cast<u32x2*>(dx_bf16 + row * D)[idx] = pk;
+                    // column sums of the bf16 values the downstream GEMMs consume (their bias gradient)
+                    ac[j].x += __builtin_bit_cast(float, pk[0] << 16); ac[j].y += __builtin_bit_cast(float, pk[0] & 0xffff0000u);
+                    ac[j].z += __builtin_bit_cast(float, pk[1] << 16); ac[j].w += __builtin_bit_cast(float, pk[1] & 0xffff0000u);
+                } else {
+                    ac[j].x += o.x; ac[j].y += o.y; ac[j].z += o.z; ac[j].w += o.w;
+                }
             }
         }
     }
+    // per-block partial sums through LDS: ws[block][3][D] (dgamma, dbeta, colsum dx); pv_colsum stage 2 adds the blocks up
+    __shared__ float red[4][3][NCH * 256];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         reinterpret_cast<float4*>(red[wave][0])[lane + 64 * j] = ag[j];
         reinterpret_cast<float4*>(red[wave][1])[lane + 64 * j] = ab[j];
+        reinterpret_cast<float4*>(red[wave][2])[lane + 64 * j] = ac[j];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * D; e += 256) {
-        const int which = e >= D, c = e - which * D;
-        ws[(int64_t)blockIdx.x * 2 * D + e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    for (int e = threadIdx.x; e < 3 * D; e += 256) {
+        const int which = e / D, c = e - which * D;
+        ws[(int64_t)blockIdx.x * 3 * D + e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
     }
 }
+
+__global__ __launch_bounds__(256) void pv_colsum_stage2_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t chunks, int C, int accumulate);
 
 extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out,
                                 uint16_t* dx_bf16, float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream) {
@@ -532,13 +546,14 @@ extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float*
         ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15)) || (dx_bf16 && ((uintptr_t)dx_bf16 & 7))) return PV_ERR_INVALID_ARG;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    if (ws_floats < blocks * 2 * D) return PV_ERR_INVALID_ARG;
+    if (ws_floats < blocks * 3 * D) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)blocks);
 #define LNB_LAUNCH(N) PV_LAUNCH(pv_layernorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps)
     { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
 #undef LNB_LAUNCH
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
-    return pv_sum_slices_f32(ws, dgb, 2 * D, blocks, accumulate, stream);
+    PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgb, blocks, (int)(3 * D), accumulate);
+    return pv_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -255,12 +255,12 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: torch.Tensor, dgb: torch.Tensor, eps: float,
                   accumulate: bool = False, dx_bf16: Optional[torch.Tensor] = None):
-    """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [2,D] (+)= (dgamma, dbeta).  x fp32 [rows,D], dy bf16 [rows,D]."""
+    """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [3,D] (+)= (dgamma, dbeta, colsum(dx)).  x fp32 [rows,D], dy bf16 [rows,D]."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
     D = x.shape[-1]
     rows = x.numel() // D
     blocks = min((rows + 3) // 4, 1024)
-    ws = torch.empty((blocks, 2 * D), dtype=torch.float32, device=x.device)
+    ws = torch.empty((blocks, 3 * D), dtype=torch.float32, device=x.device)
     with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0)) * x.numel()):
         check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dx_bf16), _ptr(dgb),
                                            _ptr(ws), ws.numel(), rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd")

@@ -108,13 +108,13 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
 _NO_TN = os.environ.get("PEEKVIT_AMD_WGRAD", "tn") != "tn"
 
 
-def _bf16_grad(dout: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of an incoming fp32 gradient: the producer's LayerNorm-backward kernel already wrote one (attached to the
+def _bf16_grad(dout: torch.Tensor, buf: torch.Tensor):
+    """(bf16 copy of an incoming fp32 gradient, its column sums or None): the producer's LayerNorm-backward kernel already wrote one (attached to the
     very tensor object autograd hands over) unless the gradient comes from stock ops (the head) or was touched since."""
     hand = getattr(dout, "_pv_bf16", None)
     if hand is not None and hand[1] == dout._version and hand[0].numel() == buf.numel():
-        return hand[0].view(buf.shape)
-    return ops.cast_bf16((dout if dout.is_contiguous() else dout.contiguous()).view(buf.shape), buf)
+        return hand[0].view(buf.shape), hand[2]
+    return ops.cast_bf16((dout if dout.is_contiguous() else dout.contiguous()).view(buf.shape), buf), None
 
 
 class BlockFn(torch.autograd.Function):
@@ -165,19 +165,21 @@ class BlockFn(torch.autograd.Function):
         # ---- MLP branch ------------------------------------------------------------------------------------
         dout3 = dout
         dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
-        d2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
-        dw2, db2 = _wgrad(d2, gl, "fc2")
+        d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
+        dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
+        db2 = db2c if db2 is None else db2
         dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]")
         dw1, db1 = _wgrad(dpre, h2, "fc1")
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
-        dgb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
+        dgb2 = torch.empty((3, D), dtype=torch.float32, device=dev)
         d1 = ws.get("bw_d1", (R, D), bf, dev)
         ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
         # ---- attention branch ------------------------------------------------------------------------------
-        dwo, dbo = _wgrad(d1, att, "proj")
+        dwo, _ = _wgrad(d1, att, "proj", bias_grad=False)
+        dbo = dgb2[2]                                                           # column sums of d1, from the LN2 backward pass
         datt = ws.get("bw_datt", (R, D), bf, dev)
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
@@ -185,10 +187,10 @@ class BlockFn(torch.autograd.Function):
         dwin, dbin = _wgrad(dqkv, h1, "qkv")
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
-        dgb1 = torch.empty((2, D), dtype=torch.float32, device=dev)
+        dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
         dxb = torch.empty((B, S, D), dtype=bf, device=dev)
         ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
-        dx._pv_bf16 = (dxb, dx._version)             # hand-off to the previous block's backward (see _bf16_grad)
+        dx._pv_bf16 = (dxb, dx._version, dgb1[2])    # hand-off to the previous block's backward (see _bf16_grad)
         return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
 

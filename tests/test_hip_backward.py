@@ -124,12 +124,13 @@ def test_layernorm_backward(ops, rows, D):
     xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
     dx = torch.empty_like(x)
-    dgb = torch.full((2, D), 7.0, device="cuda")
+    dgb = torch.full((3, D), 7.0, device="cuda")
     dxb = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
     ops.layernorm_bwd(x, dy, gamma, dres, dx, dgb, 1e-6, dx_bf16=dxb)
     assert torch.equal(dxb, dx.to(torch.bfloat16))
     assert rel_l2(dx, dres + xr.grad) < 5e-6
     assert rel_l2(dgb[0], gr.grad) < 5e-6 and rel_l2(dgb[1], br.grad) < 5e-6
+    assert rel_l2(dgb[2], dxb.double().sum(0)) < 5e-6              # column sums of the bf16 dx (downstream bias gradient)
     ops.layernorm_bwd(x, dy, gamma, None, dx, dgb, 1e-6, accumulate=True)
     assert rel_l2(dx, xr.grad) < 5e-6
     assert rel_l2(dgb[0], 2 * gr.grad) < 5e-6
