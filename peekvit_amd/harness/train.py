@@ -1,6 +1,7 @@
 """Training entry point, counterpart of train/train.py:34-211: epochs of forward -> CrossEntropy -> backward ->
 [data-parallel gradient all-reduce] -> clip_grad_norm_(1.0) -> Adam step, validation and reference-format checkpoints.
-The forward/backward of a training step runs on the stock-op composite (autograd); the MI355X kernels serve evaluation.
+On a GPU the step runs on the MI355X kernels end to end: forward with saved activations and the hand-written backward
+(peekvit_amd.train_engine, autograd Functions), parameter gradients in fp32; PEEKVIT_AMD_TRAIN=torch selects the stock-op composite.
 
     python -m peekvit_amd.harness.train model=vit_tiny training.num_epochs=1 device=cpu
     torchrun --nproc-per-node 8 -m peekvit_amd.harness.train model=vit_b_16 training.train_batch_size=1024 device=cuda
