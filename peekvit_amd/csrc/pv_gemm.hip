@@ -27,7 +27,7 @@ __device__ __forceinline__ float pv_gelu_lut(float x, TabPtr tab) {
     return x * fmaf(fr, e[1], e[0]);
 }
 
-// gelu'(x) = Phi(x) + x * phi(x): Phi from the same table, phi(x) = exp(-x^2/2)/sqrt(2 pi) by one v_exp
+// gelu'(x) = Phi(x) + x * phi(x) from its own table on the same grid (pv_gelu_grad_tab): the same 7 VALU + one gather
 template <typename TabPtr>
 __device__ __forceinline__ float pv_gelu_grad_lut(float x, TabPtr tab) {
     float t = fmaf(x, 256.0f, 2048.0f);
@@ -35,8 +35,7 @@ __device__ __forceinline__ float pv_gelu_grad_lut(float x, TabPtr tab) {
     const int i = (int)t;
     const float fr = t - (float)i;
     const pv_f32x2_t e = tab[i];
-    const float u = x * 0.84932180028801904f;                      // sqrt(0.5*log2(e)): exp(-x^2/2) = exp2(-u*u)
-    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(-(u * u)), fmaf(fr, e[1], e[0]));
+    return fmaf(fr, e[1], e[0]);
 }
 
 struct GemmDev {
@@ -128,7 +127,7 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
     } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
-        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_grad_tab);
         const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + n);
         const float x0 = __builtin_bit_cast(float, w[0] << 16), x1 = __builtin_bit_cast(float, w[0] & 0xffff0000u);
         const float x2 = __builtin_bit_cast(float, w[1] << 16), x3 = __builtin_bit_cast(float, w[1] & 0xffff0000u);
@@ -421,7 +420,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // counted wait covers them and nothing else changes
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            pv_glds16(reinterpret_cast<const char*>(pv_gelu_tab) + (i * 512 + tid) * 16, smem + G2_LDS + (i * 512 + wid * 64) * 16);
+            pv_glds16(reinterpret_cast<const char*>(EPI == PV_EPI_GELU_GRAD_BF16 ? pv_gelu_grad_tab : pv_gelu_tab) + (i * 512 + tid) * 16,
+                      smem + G2_LDS + (i * 512 + wid * 64) * 16);
     }
     stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
     stage_a(1, 0, 1); stage_a(1, 1, 1);
