@@ -168,6 +168,10 @@ int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, in
  * ws: fp32 scratch [ceil(R/1024)*C]. */
 int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 
+/* Backward of pv_gather_tokens (models/rankvit.py:55-77 under loss.backward()): dy fp32 [B,1+k,D], keep int32 [B,k] ->
+ * dx fp32 [B,S_in,D] with dx[b,0] = dy[b,0], dx[b,1+keep[b,i]] = dy[b,1+i], zeros elsewhere (every row written). */
+int pv_scatter_tokens(const float* dy, const int32_t* keep, float* dx, int64_t B, int64_t S_in, int64_t k, int64_t D, void* stream);
+
 /* Attention backward for one block (models/blocks.py:32-37 under train/train.py:118 loss.backward()):
  * qkv bf16 [B,S,3D] as the forward in-proj wrote it (q columns pre-scaled by qscale), dout bf16 [B,S,D] = dL/d(attention
  * output); dqkv bf16 [B,S,3D] = dL/d(in-proj output before the q pre-scale).  Probabilities are recomputed.

@@ -766,6 +766,36 @@ extern "C" int pv_gather_tokens(const float* x, const int32_t* keep, float* out,
     return pv_check_launch();
 }
 
+// Backward of the compaction (models/rankvit.py:55-77 under loss.backward()): dx[b, 0] = dy[b, 0], dx[b, 1 + keep[b,i]] = dy[b, 1 + i],
+// every dropped row = 0.  One workgroup per image: the inverse map is built in LDS, then every output row is written once.
+__global__ __launch_bounds__(256) void pv_scatter_tokens_kernel(const float* __restrict__ dy, const int32_t* __restrict__ keep, float* __restrict__ dx,
+                                                                int64_t S_in, int64_t k, int D) {
+    extern __shared__ int inv[];                     // inv[n] = position of token n in the kept list, or -1
+    const int64_t b = blockIdx.x, N = S_in - 1;
+    for (int n = threadIdx.x; n < N; n += 256) inv[n] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += 256) inv[keep[b * k + i]] = i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    for (int64_t r = wave; r < S_in; r += 4) {
+        const int src = r == 0 ? 0 : (inv[r - 1] < 0 ? -1 : 1 + inv[r - 1]);
+        float4* d = reinterpret_cast<float4*>(dx + (b * S_in + r) * (int64_t)D);
+        if (src < 0) {
+            for (int idx = lane; idx < nvec; idx += 64) d[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float4* sp = reinterpret_cast<const float4*>(dy + (b * (k + 1) + src) * (int64_t)D);
+            for (int idx = lane; idx < nvec; idx += 64) d[idx] = sp[idx];
+        }
+    }
+}
+
+extern "C" int pv_scatter_tokens(const float* dy, const int32_t* keep, float* dx, int64_t B, int64_t S_in, int64_t k, int64_t D, void* stream) {
+    if (!dy || !dx || B <= 0 || S_in < 1 || k < 0 || k > S_in - 1 || D <= 0 || (k > 0 && !keep)) return PV_ERR_INVALID_ARG;
+    if (D % 4 || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || S_in > 16384 || B > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_scatter_tokens_kernel, dim3((unsigned)B), dim3(256), (size_t)S_in * sizeof(int), (hipStream_t)stream, dy, keep, dx, S_in, k, (int)D);
+    return pv_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------
 // ResidualViT gate + in-place masking (models/residualvit.py:197-235, eval, sigmoid gate, learnable budget token)
 // ------------------------------------------------------------------------------------------------

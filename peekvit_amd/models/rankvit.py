@@ -14,7 +14,7 @@ from typing import List, Optional, Union
 import torch
 from torch import nn
 
-from .. import engine
+from .. import engine, train_engine
 from .vit import ViTBlock, _ViTBase, _make_layers
 
 
@@ -29,6 +29,9 @@ class RankViTBlock(ViTBlock):
 
     def sort_and_drop(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        if train_engine.train_eligible(input, self, self._p_drop):
+            out, self.last_keep = train_engine.sort_and_drop_train(input, self.current_budget)    # HIP ranking, scatter backward
+            return out
         if engine.backend_for(input, self, self._p_drop) == "hip":
             out, self.last_keep = engine.sort_and_drop(input, self.current_budget)
             return out
@@ -95,6 +98,10 @@ class RankVisionTransformer(_ViTBase):
 
     def forward(self, x: torch.Tensor):
         self._check_image(x)
+        if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
+                train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
+            tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True)
+            return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             tokens = self.encoder(engine.embed_tokens(self, x), _pos_added=True)
             return engine.pool_and_head(self, tokens)

@@ -378,6 +378,17 @@ def gather_tokens(x: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def scatter_tokens(dy: torch.Tensor, keep: torch.Tensor, S_in: int) -> torch.Tensor:
+    """Backward of gather_tokens: dy fp32 [B,1+k,D] -> dx fp32 [B,S_in,D] (zeros at dropped tokens)."""
+    _chk(dy, torch.float32, "dy")
+    B, k1, D = dy.shape
+    dx = torch.empty((B, S_in, D), dtype=torch.float32, device=dy.device)
+    with _timed("pv_scatter_tokens", dy.device, 0.0, 4.0 * B * (k1 + S_in) * D):
+        check(_lib.load().pv_scatter_tokens(_ptr(dy), _ptr(keep), _ptr(dx), B, S_in, k1 - 1, D, _stream(dy)), "pv_scatter_tokens")
+    _count()
+    return dx
+
+
 def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float):
     """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]."""
     B, S, D = x.shape

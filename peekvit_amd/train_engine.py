@@ -250,6 +250,31 @@ def embed_tokens_train(model: nn.Module, img: torch.Tensor) -> torch.Tensor:
     return EmbedFn.apply(model, img, model.conv_proj.weight, model.conv_proj.bias, model.encoder.pos_embedding, model.class_tokens, reg)
 
 
+class SortDropFn(torch.autograd.Function):
+    """RankViT ranking + compaction (models/rankvit.py:55-77) with the same HIP kernels as inference (bit-exact keep indices);
+    backward scatters the gradient rows back to the kept positions (indices carry no gradient, as with torch.gather)."""
+
+    @staticmethod
+    def forward(ctx, x, budget):
+        from . import engine
+        x = x.float() if x.dtype != torch.float32 else x
+        out, keep = engine.sort_and_drop(x, budget)
+        ctx.s_in = x.shape[1]
+        ctx.save_for_backward(keep)
+        ctx.mark_non_differentiable(keep)
+        return out, keep
+
+    @staticmethod
+    def backward(ctx, dout, _dkeep):
+        (keep,) = ctx.saved_tensors
+        dout = dout.float() if dout.dtype != torch.float32 else dout
+        return ops.scatter_tokens(dout if dout.is_contiguous() else dout.contiguous(), keep, ctx.s_in), None
+
+
+def sort_and_drop_train(x: torch.Tensor, budget: float):
+    return SortDropFn.apply(x, budget)
+
+
 def pool_and_head_train(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
     """Final LayerNorm on the class-token rows, sum, head: [B, n_cls, D] fp32 stock ops under autograd (0.02 % of the
     step's FLOPs; the gradient re-enters the HIP backward as dL/d(tokens), zero outside the class rows)."""
