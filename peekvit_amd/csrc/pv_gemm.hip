@@ -415,6 +415,9 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
     PV_STAMP(0);
+#ifdef PV_STAMPS
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 8 + 6] = rt_; }
+#endif
     if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) {
         // GELU table (32 KiB) into the LDS above the staging buffers: the OLDEST operations of the kernel, so every later
         // counted wait covers them and nothing else changes
@@ -593,8 +596,15 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     }
     PV_STAMP(3);
 #ifdef PV_STAMPS
+    if (threadIdx.x == 0 && p.dbg) {          // slot 5: which CU ran this workgroup; slot 6/7: constant-rate (100 MHz) wall clock at start / end
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.dbg[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PV_STAMP(4);
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 8 + 7] = rt_; }
 #endif
 }
 

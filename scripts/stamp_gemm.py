@@ -31,6 +31,25 @@ for name, N, K, epi in [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 307
     d = dbg.view(nblk, 8).cpu().double()
     seg = lambda i, j: (d[:, j] - d[:, i])
     tot = seg(0, 4)
+    # per-CU timeline from the 100 MHz wall clock: busy = sum of workgroup lifetimes, span = first start .. last end
+    import collections
+    raw = dbg.view(nblk, 8).cpu()
+    hw, t0, t1 = raw[:, 5], raw[:, 6].double(), raw[:, 7].double()
+    cu_key = ((hw >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xf) + (((hw >> 12) & 0x1) << 4) + (((hw >> 13) & 0x7) << 5)   # xcc | cu_id, sh_id, se_id
+    per = collections.defaultdict(list)
+    for k_, a_, b_ in zip(cu_key.tolist(), t0.tolist(), t1.tolist()):
+        per[k_].append((a_, b_))
+    utils, gaps, lifes = [], [], []
+    for k_, iv in per.items():
+        iv.sort()
+        busy = sum(b_ - a_ for a_, b_ in iv)
+        utils.append(busy / max(iv[-1][1] - iv[0][0], 1))
+        gaps += [iv[i + 1][0] - iv[i][1] for i in range(len(iv) - 1)]
+        lifes += [b_ - a_ for a_, b_ in iv]
+    gaps_t = torch.tensor(gaps) if gaps else torch.zeros(1)
+    print(f"   CUs seen {len(per)}  workgroups/CU {nblk / max(len(per), 1):.1f}  lifetime median {torch.tensor(lifes).median() * 10:.0f} ns  "
+          f"gap between consecutive workgroups on a CU: median {gaps_t.median() * 10:.0f} ns, mean {gaps_t.mean() * 10:.0f} ns  CU busy fraction {sum(utils) / len(utils):.3f}  "
+          f"kernel span {(t1.max() - t0.min()) * 10 / 1e3:.1f} us")
     print(f"{name}: blocks {nblk}  (s_memtime ticks, median per block) prologue {seg(0,1).median():.0f}  kloop {seg(1,2).median():.0f} "
           f"({seg(1,2).median() / (K // 64):.0f}/ktile)  epilogue-issue {seg(2,3).median():.0f}  store-drain {seg(3,4).median():.0f}  total {tot.median():.0f}"
           f"   span first-start..last-end {(d[:,4].max() - d[:,0].min()):.0f}")
