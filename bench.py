@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
-                    help="operand precision of the MFMA products: bf16 (headline) or split bf16x3 (meets the 1e-3 logits tolerance)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"],
+                    help="operand precision of the MFMA products: bf16 (headline), f16 (IEEE fp16 operands, same speed, meets the 1e-3 "
+                         "logits tolerance) or split bf16x3 (1e-5)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     return ap.parse_args()
 

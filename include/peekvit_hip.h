@@ -32,6 +32,9 @@ extern "C" {
 /* ABI version (bumped on any signature change) and build target ("gfx950"). */
 int pv_version(void);
 const char* pv_arch(void);
+/* 16-bit operand type this library was built for: 0 = bf16 (libpeekvit_hip.so), 1 = IEEE fp16 (libpeekvit_hip_f16.so, built
+ * from the same sources with -DPV_OPERAND_F16).  Every "bf16" tensor in the signatures below is of that type. */
+int pv_operand_type(void);
 const char* pv_error_string(int code);
 
 /* fp32 -> bf16 cast of a contiguous buffer (weights packing at load time). n elements. */

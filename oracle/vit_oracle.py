@@ -28,8 +28,12 @@ Tensor = torch.Tensor
 
 
 def rb(x: Tensor, mode: str) -> Tensor:
-    """Round to bf16 (nearest-even) and return fp32 - identity in fp32 mode."""
-    return x.to(torch.bfloat16).to(torch.float32) if mode == "bf16" else x
+    """Round to the 16-bit operand type of the mode (bf16 or IEEE fp16, nearest-even) and return fp32 - identity in fp32 mode."""
+    if mode == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    if mode == "f16":
+        return x.to(torch.float16).to(torch.float32)
+    return x
 
 
 def _t(sd: Dict[str, object], key: str) -> Tensor:
@@ -45,7 +49,7 @@ def _t(sd: Dict[str, object], key: str) -> Tensor:
 def patch_embed(x: Tensor, w: Tensor, b: Tensor, patch: int, mode: str = "fp32") -> Tensor:
     """models/vit.py:203-222 `_process_input`: stride-P conv -> [B,D,Np] -> permute -> [B,Np,D]."""
     n = x.shape[0]
-    if mode == "bf16":
+    if mode != "fp32":
         # im2col + GEMM with bf16 operands, fp32 accumulate; K order (c, kh, kw) = conv weight layout
         cols = F.unfold(rb(x, mode), kernel_size=patch, stride=patch)          # [B, 3PP, Np]
         t = cols.transpose(1, 2) @ rb(w, mode).reshape(w.shape[0], -1).t() + b
@@ -74,7 +78,7 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, mode: str = "fp32") -> Tenso
     P.V (fp32 acc), normalised afterwards by the fp32 row sum of the UNROUNDED exponentials.
     """
     s = q @ k.transpose(-1, -2)
-    if mode == "bf16":
+    if mode != "fp32":
         m = s.max(dim=-1, keepdim=True).values
         p = torch.exp(s - m)
         l = p.sum(dim=-1, keepdim=True)

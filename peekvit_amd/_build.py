@@ -9,6 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpeekvit_hip.so")
+LIB_F16 = os.path.join(HERE, "libpeekvit_hip_f16.so")      # same sources, -DPV_OPERAND_F16: fp16 operands (precision mode "f16")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -18,9 +19,9 @@ def sources():
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_F16):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_F16))
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "peekvit_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -29,25 +30,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every .hip source to an object (in parallel) and link the shared library."""
     if not force and not _stale():
         return LIB
-    objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
     procs = []
-    objs = []
-    for src in sources():
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        objs.append(obj)
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    variants = [("build", [], LIB), ("build_f16", ["-DPV_OPERAND_F16"], LIB_F16)]
+    objs = {lib: [] for _, _, lib in variants}
+    for sub, defs, lib in variants:
+        objdir = os.path.join(HERE, sub)
+        os.makedirs(objdir, exist_ok=True)
+        for src in sources():
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+            objs[lib].append(obj)
+            cmd = [HIPCC, *FLAGS, *defs, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
+    for _, _, lib in variants:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs[lib]]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
     return LIB
 
 

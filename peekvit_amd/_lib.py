@@ -57,6 +57,7 @@ SIGNATURES = {
     "pv_attention_bwd_bf16": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
+    "pv_operand_type": (C.c_int, []),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_cls_pool": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
@@ -68,35 +69,50 @@ SIGNATURES = {
 }
 
 _lock = threading.Lock()
-_lib = None
+_libs: dict = {}
+
+# 16-bit operand type of the MFMA products (engine.precision): "bf16" -> libpeekvit_hip.so, "f16" -> libpeekvit_hip_f16.so (the
+# same sources built with -DPV_OPERAND_F16).  ops.py / engine.py allocate operand tensors with operand_dtype().
+OPERAND = "bf16"
+LIB_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpeekvit_hip_f16.so")
+
+
+def operand_dtype():
+    import torch as _t
+    return _t.float16 if OPERAND == "f16" else _t.bfloat16
 
 
 class PeekvitHipError(RuntimeError):
     pass
 
 
-def lib_path() -> str:
-    return LIB
+def lib_path(operand: str = "bf16") -> str:
+    return LIB_F16 if operand == "f16" else LIB
 
 
-def load():
-    """Load the shared library (once) and attach the declared signatures.  Raises if it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(operand=None):
+    """Load the shared library of the current (or given) operand type once and attach the declared signatures.  Raises if missing."""
+    op = OPERAND if operand is None else operand
+    lib = _libs.get(op)
+    if lib is not None:
+        return lib
     with _lock:
-        if _lib is not None:
-            return _lib
-        if not os.path.exists(LIB):
+        lib = _libs.get(op)
+        if lib is not None:
+            return lib
+        path = lib_path(op)
+        if not os.path.exists(path):
             raise PeekvitHipError(
-                f"{LIB} not found: the MI355X kernels are not built. Run `python -m peekvit_amd._build` "
+                f"{path} not found: the MI355X kernels are not built. Run `python -m peekvit_amd._build` "
                 "(or __graft_entry__.build()); there is no fallback path.")
-        lib = C.CDLL(LIB)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        _lib = lib
-    return _lib
+        if lib.pv_operand_type() != (1 if op == "f16" else 0):
+            raise PeekvitHipError(f"{path} was built for a different operand type")
+        _libs[op] = lib
+    return lib
 
 
 def check(code: int, what: str = "") -> None:

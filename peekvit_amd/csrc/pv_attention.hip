@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
             for (int ks = 0; ks < KS; ++ks) {
                 // rows kt*16 + i16: 16 rows = 16*DHP*2 bytes further, and (row & 7) / the line parity are unchanged
                 const bf16x8 kf = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kbase[ks] + kt * (16 * DHP * 2));
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], a, 0, 0, 0);
+                a = PV_MFMA_16x16x32(kf, qf[t][ks], a, 0, 0, 0);
             }
             sc[kt] = a;
         }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
                 s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + tt * (32 * DHP * 2)));
                 s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + tt * (32 * DHP * 2) + 16 * DHP * 2));
                 const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+                o[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
             }
         }
         if (NKT & 1) {             // odd last 16-key tile: K = 16 MFMA, lane group g contributes keys 4g..4g+3 directly
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbase[dt] + kt * (16 * DHP * 2)));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(v0, pf, o[dt], 0, 0, 0);
+                o[dt] = PV_MFMA_16x16x16(v0, pf, o[dt], 0, 0, 0);
             }
         }
         // ---- normalise and store: lane holds out[q0+i16][h*DH + dt*16 + 4g + 0..3] -----------------------------
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Ks, kt, ks), qf[ks], a, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Vs, kt, ks), of[ks], c, 0, 0, 0);
+                a = PV_MFMA_16x16x32(frag(Ks, kt, ks), qf[ks], a, 0, 0, 0);
+                c = PV_MFMA_16x16x32(frag(Vs, kt, ks), of[ks], c, 0, 0, 0);
             }
             sc[kt] = a; dp[kt] = c;
         }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
                               pv_pack_bf16x2(sc[kt][2] * (dp[kt][2] - dd), sc[kt][3] * (dp[kt][3] - dd))};
             const s16x4 dsf = __builtin_bit_cast(s16x4, dw);
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Ks, kt, dt), dsf, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(tfrag(Ks, kt, dt), dsf, dq[dt], 0, 0, 0);
         }
         if (q0 + i16 < S) {       // dq[dt][r] = dL/dq'[q0+i16][dt*16 + 4g + r]; the in-proj output is q'/qscale
             uint16_t* op = gb + (int64_t)(q0 + i16) * ld + 4 * g;
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Qs, qt, ks), kf[ks], s, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(Os, qt, ks), vf[ks], c, 0, 0, 0);
+                s = PV_MFMA_16x16x32(frag(Qs, qt, ks), kf[ks], s, 0, 0, 0);
+                c = PV_MFMA_16x16x32(frag(Os, qt, ks), vf[ks], c, 0, 0, 0);
             }
             const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
             const float4 i4 = *reinterpret_cast<const float4*>(st_i + qt * 16 + 4 * g);
@@ -566,8 +566,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             const s16x4 pf = __builtin_bit_cast(s16x4, pw), dsf = __builtin_bit_cast(s16x4, dw);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Os, qt, dt), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tfrag(Qs, qt, dt), dsf, dk[dt], 0, 0, 0);
+                dv[dt] = PV_MFMA_16x16x16(tfrag(Os, qt, dt), pf, dv[dt], 0, 0, 0);
+                dk[dt] = PV_MFMA_16x16x16(tfrag(Qs, qt, dt), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (key_ok) {             // d*[dt][r] = dL/d{k,v}[k0+i16][dt*16 + 4g + r]

@@ -14,31 +14,56 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define PV_WAVE 64
 
+// ---- the 16-bit OPERAND type of the MFMA products -----------------------------------------------------------------------
+// Default: bf16.  Built with -DPV_OPERAND_F16 (libpeekvit_hip_f16.so, precision mode "f16") every operand tensor the kernels
+// write or read - LayerNorm / GELU / attention outputs, q|k|v, weights, patch columns - is IEEE fp16 instead: same MFMA rate,
+// 3 more mantissa bits (2^-11 vs 2^-8 rounding), range 6e-5 .. 65504 (activations after LayerNorm, weights and attention
+// operands of a ViT sit well inside).  Accumulation, residual stream, LayerNorm / softmax / GELU arithmetic stay fp32.
+// The helper names keep their "bf16" spelling; they convert to / from the operand type of the build.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float pv_f32x2_t;
+#ifdef PV_OPERAND_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 pv_h2_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 pv_h4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 pv_h8_t;
+#define PV_OPERAND_CODE 1
+#define PV_MFMA_16x16x32(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pv_h8_t, a), __builtin_bit_cast(pv_h8_t, b), c, 0, 0, 0)
+#define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pv_h4_t, a), __builtin_bit_cast(pv_h4_t, b), c, 0, 0, 0)
+__device__ __forceinline__ uint16_t pv_f2bf(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
+    const pv_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pv_h2_t));      // round-to-nearest-even
+}
+__device__ __forceinline__ float pv_unpack_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float pv_unpack_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
+#define PV_OPERAND_CODE 0
+#define PV_MFMA_16x16x32(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+#define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0)
 // fp32 -> bf16 bits, round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.
 __device__ __forceinline__ uint16_t pv_f2bf(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float pv_f32x2_t;
 // two fp32 -> one dword of two bf16 (lo in bits 0-15): a vector convert lowers to ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
     const pv_f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ float pv_unpack_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float pv_unpack_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+#endif
 // split-precision helpers (precision mode "bf16x3"): v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi)
 struct PvHiLo { uint32_t hi, lo; };
 __device__ __forceinline__ PvHiLo pv_split2(float a, float b) {
     PvHiLo r;
     r.hi = pv_pack_bf16x2(a, b);
-    const float ah = __builtin_bit_cast(float, r.hi << 16), bh = __builtin_bit_cast(float, r.hi & 0xffff0000u);
+    const float ah = pv_unpack_lo(r.hi), bh = pv_unpack_hi(r.hi);
     r.lo = pv_pack_bf16x2(a - ah, b - bh);
     return r;
 }
 
-__device__ __forceinline__ float pv_bf2f(uint16_t b) {
-    return __builtin_bit_cast(float, (uint32_t)b << 16);
-}
+__device__ __forceinline__ float pv_bf2f(uint16_t b) { return pv_unpack_lo((uint32_t)b); }
 
 __device__ __forceinline__ float pv_wave_sum(float v) {
 #pragma unroll

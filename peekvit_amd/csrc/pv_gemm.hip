@@ -129,8 +129,8 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
     } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
         const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_grad_tab);
         const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + n);
-        const float x0 = __builtin_bit_cast(float, w[0] << 16), x1 = __builtin_bit_cast(float, w[0] & 0xffff0000u);
-        const float x2 = __builtin_bit_cast(float, w[1] << 16), x3 = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+        const float x0 = pv_unpack_lo(w[0]), x1 = pv_unpack_hi(w[0]);
+        const float x2 = pv_unpack_lo(w[1]), x3 = pv_unpack_hi(w[1]);
         u32x2 o = {pv_pack_bf16x2(v0 * pv_gelu_grad_lut(x0, tab), v1 * pv_gelu_grad_lut(x1, tab)),
                    pv_pack_bf16x2(v2 * pv_gelu_grad_lut(x2, tab), v3 * pv_gelu_grad_lut(x3, tab))};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p_in) 
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = PV_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -368,7 +368,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     __builtin_amdgcn_s_setprio(1);                                                                                   \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)            \
         _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                            \
-            acc[(NH) * 2 + n_][(MH) * 4 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+            acc[(NH) * 2 + n_][(MH) * 4 + m_] = PV_MFMA_16x16x32(                            \
                 bfr[n_][ks_], af[MH][m_][ks_], acc[(NH) * 2 + n_][(MH) * 4 + m_], 0, 0, 0);                     \
     __builtin_amdgcn_s_setprio(0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -544,8 +544,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved bf16 pre-activation row, 512 B per instruction
                     orow[j] = m;
                     const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + ncol);
-                    rr[j] = (f32x4){__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
-                                    __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+                    rr[j] = (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]),
+                                    pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     orow[j] = m;
                     rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) 
     __builtin_amdgcn_s_setprio(1);                                                                                   \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)            \
         _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                            \
-            acc[(NH) * 2 + n_][(MH) * 4 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+            acc[(NH) * 2 + n_][(MH) * 4 + m_] = PV_MFMA_16x16x32(                            \
                 bfr[n_][ks_], af[MH][m_][ks_], acc[(NH) * 2 + n_][(MH) * 4 + m_], 0, 0, 0);                     \
     __builtin_amdgcn_s_setprio(0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                               \

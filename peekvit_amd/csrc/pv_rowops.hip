@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __res
                 if (CSUM) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        cs[2 * k] += __builtin_bit_cast(float, v[k] << 16);
-                        cs[2 * k + 1] += __builtin_bit_cast(float, v[k] & 0xffff0000u);
+                        cs[2 * k] += pv_unpack_lo(v[k]);
+                        cs[2 * k + 1] += pv_unpack_hi(v[k]);
                     }
                 }
             }
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void pv_colsum_kernel(const void* __restrict__
                 const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(src) + r * C + c);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    acc[2 * k] += __builtin_bit_cast(float, w[k] << 16);
-                    acc[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xffff0000u);
+                    acc[2 * k] += pv_unpack_lo(w[k]);
+                    acc[2 * k + 1] += pv_unpack_hi(w[k]);
                 }
             } else {
                 const float4 w = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + r * C + c);
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
             const int idx = lane + 64 * j;
             u32x2 w = {0u, 0u};
             if (idx < nvec) w = reinterpret_cast<const u32x2*>(dy + row * D)[idx];
-            d[j] = make_float4(__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
-                               __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u));
+            d[j] = make_float4(pv_unpack_lo(w[0]), pv_unpack_hi(w[0]),
+                               pv_unpack_lo(w[1]), pv_unpack_hi(w[1]));
         }
         float s = 0.f;
 #pragma unroll
@@ -513,8 +513,8 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                     const u32x2 pk = {pv_pack_bf16x2(o.x, o.y), pv_pack_bf16x2(o.z, o.w)};
                     reinterpret_cast<u32x2*>(dx_bf16 + row * D)[idx] = pk;
                     // column sums of the bf16 values the downstream GEMMs consume (their bias gradient)
-                    ac[j].x += __builtin_bit_cast(float, pk[0] << 16); ac[j].y += __builtin_bit_cast(float, pk[0] & 0xffff0000u);
-                    ac[j].z += __builtin_bit_cast(float, pk[1] << 16); ac[j].w += __builtin_bit_cast(float, pk[1] & 0xffff0000u);
+                    ac[j].x += pv_unpack_lo(pk[0]); ac[j].y += pv_unpack_hi(pk[0]);
+                    ac[j].z += pv_unpack_lo(pk[1]); ac[j].w += pv_unpack_hi(pk[1]);
                 } else {
                     ac[j].x += o.x; ac[j].y += o.y; ac[j].z += o.z; ac[j].w += o.w;
                 }
@@ -569,10 +569,10 @@ __global__ __launch_bounds__(256) void pv_gelu_kernel(const uint16_t* __restrict
         u32x4 ow;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float x0 = __builtin_bit_cast(float, pw[k] << 16), x1 = __builtin_bit_cast(float, pw[k] & 0xffff0000u);
+            const float x0 = pv_unpack_lo(pw[k]), x1 = pv_unpack_hi(pw[k]);
             float y0, y1;
             if (BWD) {
-                const float g0 = __builtin_bit_cast(float, gw[k] << 16), g1 = __builtin_bit_cast(float, gw[k] & 0xffff0000u);
+                const float g0 = pv_unpack_lo(gw[k]), g1 = pv_unpack_hi(gw[k]);
                 y0 = g0 * (0.5f * (1.0f + erff(x0 * 0.70710678118654752440f)) + x0 * 0.3989422804014327f * __expf(-0.5f * x0 * x0));
                 y1 = g1 * (0.5f * (1.0f + erff(x1 * 0.70710678118654752440f)) + x1 * 0.3989422804014327f * __expf(-0.5f * x1 * x1));
             } else {

@@ -18,7 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 import contextlib
 
 from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_GELU_SPLIT_BF16, PV_EPI_BIAS_POS_F32,
@@ -26,21 +26,28 @@ from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_
 
 # Operand precision of the MFMA products:
 #   "bf16"   (default) bf16 operands, fp32 accumulate: 4e-3 relative logits error vs the fp32 reference at random init
+#   "f16"    IEEE fp16 operands (libpeekvit_hip_f16.so: same kernels, same MFMA rate, 2^-11 instead of 2^-8 operand rounding),
+#            fp32 accumulate: 5e-4 relative logits error - meets BASELINE's 1e-3 at the speed of "bf16"; operand range 6e-5..65504
 #   "bf16x3" every GEMM operand split v = hi + lo and concatenated along K ([a_hi|a_lo|a_hi] . [w_hi|w_hi|w_lo]^T on the same
 #            MFMA kernel), exact-fp32 attention: meets BASELINE's 1e-3 (measured ~1e-5) at ~3x the GEMM work
 _PRECISION = os.environ.get("PEEKVIT_AMD_PRECISION", "bf16")
+_MODES = ("bf16", "f16", "bf16x3")
+if _PRECISION not in _MODES:
+    raise ValueError(f"PEEKVIT_AMD_PRECISION={_PRECISION!r}: expected one of {_MODES}")
+_lib.OPERAND = "f16" if _PRECISION == "f16" else "bf16"
 
 
 @contextlib.contextmanager
 def precision(mode: str):
     global _PRECISION
-    if mode not in ("bf16", "bf16x3"):
+    if mode not in _MODES:
         raise ValueError(f"unknown precision {mode!r}")
     old, _PRECISION = _PRECISION, mode
+    old_op, _lib.OPERAND = _lib.OPERAND, ("f16" if mode == "f16" else "bf16")
     try:
         yield
     finally:
-        _PRECISION = old
+        _PRECISION, _lib.OPERAND = old, old_op
 
 
 def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> str:
@@ -90,7 +97,7 @@ _wcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
 
 def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes."""
-    key = id(p)
+    key = (id(p), _lib.OPERAND)
     ent = _wcache.get(key)
     if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
         return ent[3]
@@ -174,17 +181,17 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     dev = x.device
     R = B * S
 
-    h2 = workspace.get("h2", (R, D), torch.bfloat16, dev)
-    qkv = workspace.get("qkv", (R, 3 * D), torch.bfloat16, dev)
-    att = workspace.get("att", (R, D), torch.bfloat16, dev)
-    g = workspace.get("g", (R, M), torch.bfloat16, dev)
+    h2 = workspace.get("h2", (R, D), _lib.operand_dtype(), dev)
+    qkv = workspace.get("qkv", (R, 3 * D), _lib.operand_dtype(), dev)
+    att = workspace.get("att", (R, D), _lib.operand_dtype(), dev)
+    g = workspace.get("g", (R, M), _lib.operand_dtype(), dev)
     x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
     out = torch.empty_like(x)
 
     if handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
         h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue
     else:
-        h = workspace.get("h", (R, D), torch.bfloat16, dev)
+        h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
         ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
     ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
              qcols=D, qscale=float(dh) ** -0.5)
@@ -197,7 +204,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
         ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
     ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
     fuse_next = next_ln is not None and _ln_fusable(D, M) and next_ln.normalized_shape == (D,)
-    hn = workspace.get("h", (R, D), torch.bfloat16, dev) if fuse_next else None      # "h" is dead once QKV has consumed it
+    hn = workspace.get("h", (R, D), _lib.operand_dtype(), dev) if fuse_next else None      # "h" is dead once QKV has consumed it
     ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
              res=x1.view(R, D),
              ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
@@ -217,10 +224,10 @@ def _block_forward_x3(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Op
     dh = D // H
     M = blk.mlp.fc1.out_features
     dev, R = x.device, B * S
-    h3 = workspace.get("h3", (R, 3 * D), torch.bfloat16, dev)
+    h3 = workspace.get("h3", (R, 3 * D), _lib.operand_dtype(), dev)
     qkv32 = workspace.get("qkv32", (R, 3 * D), torch.float32, dev)
-    att3 = workspace.get("att3", (R, 3 * D), torch.bfloat16, dev)
-    g3 = workspace.get("g3", (R, 3 * M), torch.bfloat16, dev)
+    att3 = workspace.get("att3", (R, 3 * D), _lib.operand_dtype(), dev)
+    g3 = workspace.get("g3", (R, 3 * M), _lib.operand_dtype(), dev)
     x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
     out = torch.empty_like(x)
     ops.layernorm_split(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h3, row_scale)
@@ -273,7 +280,7 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
     dev = img.device
 
     x3 = _PRECISION == "bf16x3" and not u8
-    cols = workspace.get("cols", (B * Np, 3 * K if x3 else K), torch.bfloat16, dev)
+    cols = workspace.get("cols", (B * Np, 3 * K if x3 else K), _lib.operand_dtype(), dev)
     if x3:
         ops.im2col_split(img, P, cols)
     elif u8:

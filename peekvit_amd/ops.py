@@ -94,7 +94,7 @@ def _count():
 def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(src, torch.float32, "src")
     if out is None:
-        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+        out = torch.empty(src.shape, dtype=_lib.operand_dtype(), device=src.device)
     with _timed("pv_cast_f32_bf16", src.device, 0.0, 6.0 * src.numel()):
         check(_lib.load().pv_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "pv_cast_f32_bf16")
     _count()
@@ -225,12 +225,12 @@ def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = Fal
 
 def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1, colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 [R,C] (row-strided view allowed) -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
-    if not (src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1):
+    if not (src.is_cuda and src.dtype == _lib.operand_dtype() and src.dim() == 2 and src.stride(1) == 1):
         raise _lib.PeekvitHipError("transpose: expected a 2-D bf16 GPU tensor with unit column stride")
     R, Cc = src.shape
     ldd = (R + pad_to - 1) // pad_to * pad_to
     if out is None:
-        out = torch.empty((Cc, ldd), dtype=torch.bfloat16, device=src.device)
+        out = torch.empty((Cc, ldd), dtype=_lib.operand_dtype(), device=src.device)
     assert out.shape == (Cc, ldd) and out.is_contiguous()
     ws = torch.empty(((ldd + 1023) // 1024, Cc), dtype=torch.float32, device=src.device) if colsum_out is not None else None
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
@@ -242,12 +242,12 @@ def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int
 
 def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
     """out[C] (+)= src[R,C].sum(0) in fp32; src bf16 or fp32."""
-    assert src.dtype in (torch.bfloat16, torch.float32) and src.is_contiguous()
+    assert src.dtype in (_lib.operand_dtype(), torch.float32) and src.is_contiguous()
     _chk(out, torch.float32, "out")
     R, Cc = src.shape
     ws = torch.empty(((R + 1023) // 1024, Cc), dtype=torch.float32, device=src.device)
     with _timed("pv_colsum_f32", src.device, 0.0, float(src.element_size() * src.numel())):
-        check(_lib.load().pv_colsum_f32(_ptr(src), int(src.dtype == torch.bfloat16), _ptr(out), _ptr(ws), R, Cc, int(accumulate),
+        check(_lib.load().pv_colsum_f32(_ptr(src), int(src.dtype == _lib.operand_dtype()), _ptr(out), _ptr(ws), R, Cc, int(accumulate),
                                         _stream(src)), "pv_colsum_f32")
     _count()
     return out
@@ -256,7 +256,7 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: torch.Tensor, dgb: torch.Tensor, eps: float,
                   accumulate: bool = False, dx_bf16: Optional[torch.Tensor] = None):
     """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [3,D] (+)= (dgamma, dbeta, colsum(dx)).  x fp32 [rows,D], dy bf16 [rows,D]."""
-    _chk(x, torch.float32, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
+    _chk(x, torch.float32, "x"); _chk(dy, _lib.operand_dtype(), "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
     D = x.shape[-1]
     rows = x.numel() // D
     blocks = min((rows + 3) // 4, 1024)
@@ -269,7 +269,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_i
 
 
 def gelu(pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(pre, torch.bfloat16, "pre")
+    _chk(pre, _lib.operand_dtype(), "pre")
     if out is None:
         out = torch.empty_like(pre)
     with _timed("pv_gelu_bf16", pre.device, 0.0, 4.0 * pre.numel()):
@@ -279,7 +279,7 @@ def gelu(pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 
 
 def gelu_bwd(pre: torch.Tensor, dg: torch.Tensor, dpre: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(pre, torch.bfloat16, "pre"); _chk(dg, torch.bfloat16, "dg")
+    _chk(pre, _lib.operand_dtype(), "pre"); _chk(dg, _lib.operand_dtype(), "dg")
     if dpre is None:
         dpre = dg
     with _timed("pv_gelu_bwd_bf16", pre.device, 0.0, 6.0 * pre.numel()):
@@ -316,7 +316,7 @@ def split3(src: torch.Tensor, order: int, out: Optional[torch.Tensor] = None) ->
     _chk(src, torch.float32, "src")
     rows, K = src.shape
     if out is None:
-        out = torch.empty((rows, 3 * K), dtype=torch.bfloat16, device=src.device)
+        out = torch.empty((rows, 3 * K), dtype=_lib.operand_dtype(), device=src.device)
     with _timed("pv_split3_f32_bf16", src.device, 0.0, 10.0 * src.numel()):
         check(_lib.load().pv_split3_f32_bf16(_ptr(src), _ptr(out), rows, K, order, _stream(src)), "pv_split3_f32_bf16")
     _count()
