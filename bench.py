@@ -52,8 +52,9 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, batch, iters):
-    """The CPU oracle (bit-equal to the reference on CPU, tests/test_oracle_golden.py) on a bounded sample."""
+def cpu_baseline(cfg, batch, iters, gpu_model=None, dev=None):
+    """The CPU oracle (bit-equal to the reference on CPU, tests/test_oracle_golden.py) on a bounded sample.  As the checker it
+    also scores the GPU path on the same sample: relative L2 of the logits per operand-precision mode."""
     from oracle import vit_oracle as O
     from peekvit_amd import synth
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg).items()}
@@ -66,13 +67,23 @@ def cpu_baseline(cfg, batch, iters):
     cores = max(1, min(cores, int(os.environ.get("PV_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     with torch.no_grad():
-        O.vit_forward(x, sd, cfg, "fp32")                       # warm-up
+        ref = O.vit_forward(x, sd, cfg, "fp32")                 # warm-up
         t0 = time.perf_counter()
         for _ in range(iters):
             O.vit_forward(x, sd, cfg, "fp32")
         dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} forwards of batch {batch} (fp32, torch CPU, oracle/vit_oracle.py), {dt:.1f} s"}
+    out = {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{iters} forwards of batch {batch} (fp32, torch CPU, oracle/vit_oracle.py), {dt:.1f} s"}
+    if gpu_model is not None:
+        from peekvit_amd import engine
+        err = {}
+        with torch.no_grad():
+            for mode in ("bf16", "f16"):
+                with engine.precision(mode):
+                    got = gpu_model(x.to(dev)).float().cpu()
+                err[mode] = float(f"{((got - ref).norm() / ref.norm()).item():.3e}")
+        out["gpu_logits_rel_l2_vs_oracle"] = err       # tolerance of BASELINE.json: 1e-3
+    return out
 
 
 def main():
@@ -116,6 +127,7 @@ def main():
         workload = f"rank{args.model} layers={layers} budget={args.rank_budget} forward, batch {args.batch}/GPU"
     synth.load_synth_weights(model, cfg)
     model = (model.train() if args.train else model.eval()).to(dev)
+    infer_model = model
     flops_img = synth.fwd_flops_per_image(cfg, seqs) * (3 if args.train else 1)      # backward = dgrad + wgrad = 2x forward
     if args.train:
         workload = workload.replace("forward", "fwd+bwd (cross-entropy, parameter gradients" + (", RCCL all-reduce)" if world > 1 else ")"))
@@ -217,7 +229,21 @@ def main():
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters)
+            plain = args.rank_budget is None and not args.train
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters, infer_model if plain else None, dev)
+            if plain and args.precision == "bf16":
+                # the same forward with IEEE fp16 operands (libpeekvit_hip_f16.so): the mode that meets the 1e-3 logits tolerance
+                with torch.no_grad(), engine.precision("f16"):
+                    for _ in range(2):
+                        infer_model(x)
+                    torch.cuda.synchronize(dev)
+                    t2 = time.perf_counter()
+                    for _ in range(args.steps):
+                        infer_model(x)
+                    torch.cuda.synchronize(dev)
+                    dt16 = time.perf_counter() - t2
+                line["f16_mode"] = {"value": round(args.batch * args.steps / dt16, 1), "unit": "images/sec",
+                                    "ms_per_step": round(dt16 / args.steps * 1e3, 3), "dtype": "f16"}
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

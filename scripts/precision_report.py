@@ -1,4 +1,4 @@
-"""Accuracy / throughput of the two operand-precision modes against the reference's golden fp32 logits."""
+"""Accuracy / throughput of the three operand-precision modes against the reference's golden fp32 logits."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,13 +13,15 @@ for name in ("vit_micro", "vit_tiny", "vit_small", "vit_b_16"):
     g = np.load(os.path.join(gold, name + ".npz"))["logits"]
     with torch.no_grad():
         a = m(x).cpu().numpy()
+        with engine.precision("f16"):
+            h = m(x).cpu().numpy()
         with engine.precision("bf16x3"):
             b = m(x).cpu().numpy()
-    print(f"{name:10s} rel-L2 logits error vs reference fp32:  bf16 {rel(a, g):.2e}   bf16x3 {rel(b, g):.2e}")
+    print(f"{name:10s} rel-L2 logits error vs reference fp32:  bf16 {rel(a, g):.2e}   f16 {rel(h, g):.2e}   bf16x3 {rel(b, g):.2e}")
 cfg = synth.MODEL_CONFIGS["vit_b_16"]
 m = VisionTransformer(**cfg); synth.load_synth_weights(m, cfg); m = m.eval().cuda()
 x = torch.randn(2048, 3, 224, 224, device="cuda")
-for mode in ("bf16", "bf16x3"):
+for mode in ("bf16", "f16", "bf16x3"):
     with torch.no_grad(), engine.precision(mode):
         for _ in range(2): m(x)
         torch.cuda.synchronize(); t0 = time.perf_counter()
