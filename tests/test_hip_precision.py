@@ -127,6 +127,28 @@ def test_rankvit_and_residualvit_within_tolerance(golden):
     assert rel_l2(logits, golden("residualvit")["vit_b_16_b0.5_logits"]) < TOL_NORTH_STAR
 
 
+def test_rankvit_and_residualvit_f16_within_tolerance(golden):
+    """fp16 operands: pruned / gated models also land within 1e-3 of the reference (near-tied token norms may rank differently
+    than in fp32, so the keep sets are compared by overlap, not bit for bit)."""
+    from peekvit_amd import engine
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    m.set_budget(0.5)
+    with torch.no_grad(), engine.precision("f16"):
+        logits = m(x).cpu().numpy()
+    g = golden("rankvit")
+    for li in (3, 6, 9):
+        got = np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1)
+        assert (got == np.sort(g[f"vit_b_16_b0.5_keep{li}"], axis=1)).mean() > 0.97
+    assert rel_l2(logits, g["vit_b_16_b0.5_logits"]) < 3 * TOL_NORTH_STAR       # a swapped near-tie changes which token survives
+    extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5)
+    cfg, m = _model("res", "vit_b_16", **extra)
+    m.set_budget(0.5)
+    with torch.no_grad(), engine.precision("f16"):
+        logits = m(x).cpu().numpy()
+    assert rel_l2(logits, golden("residualvit")["vit_b_16_b0.5_logits"]) < TOL_NORTH_STAR
+
+
 def test_f16_mode_matches_its_oracle_restatement():
     """Same rounding points as the bf16 path, fp16 instead of bf16: the HIP result tracks oracle mode "f16" closely."""
     from oracle import vit_oracle as O
