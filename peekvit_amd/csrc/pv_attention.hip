@@ -1,4 +1,4 @@
-// Fused multi-head self-attention core for ViT-length sequences (S <= 416) on gfx950.
+// Fused multi-head self-attention core for ViT-length sequences on gfx950 (S <= 416: LDS-resident K/V; longer: pv_attn_stream_kernel).
 //   out[b,s,h*dh:(h+1)*dh] = softmax(q k^T) v          q pre-scaled by dh^-0.5 in the in-proj epilogue
 // One workgroup (4 waves) per (image, head).  The whole K and V of the head live in LDS (<= 53 KiB each), so
 // softmax is single pass: no online rescale.  Per 16-query tile a wave computes
@@ -253,6 +253,131 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
     return pv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long sequences (S > 416: larger images / smaller patches than the LDS-resident kernel above can hold): the same swapped
+// S^T = K.Q^T / O^T = V^T.P^T products, streamed over 64-key blocks with an online softmax.  One workgroup = 64 queries of one
+// (image, head) (a 16-query tile per wave); K and V blocks pass through one 16-KiB LDS buffer.  A lane holds ONE query in every
+// accumulator (scores and O^T alike), so the running max / rescale are per-lane scalars; the row sum is kept per lane group and
+// combined once at the end.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int nqb) {
+    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, KS = DHP / 32, NDT = DH / 16, KB = 64;
+    __shared__ __attribute__((aligned(16))) char Ks[KB * DHP * 2];
+    __shared__ __attribute__((aligned(16))) char Vs[KB * DHP * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+    const int b = bh / H, h = bh - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const uint16_t* base = qkv + (int64_t)b * S * ld + h * DH;
+    const int q0 = qb * 64 + wid * 16;
+    bf16x8 qf[KS];
+    {
+        int qr = q0 + i16; qr = qr < S ? qr : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dcol = ks * 32 + 8 * g;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (dcol < DH) v = *reinterpret_cast<const u32x4*>(base + (int64_t)qr * ld + dcol);
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    const int tq_ = i16 >> 2, tp_ = i16 & 3;
+    int koff[KS], voff[NDT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) voff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+    f32x4 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;                  // l: this lane group's share of the row sum
+    constexpr float LOG2E = 1.44269504088896340736f;
+    for (int k0 = 0; k0 < S; k0 += KB) {
+        __syncthreads();                           // the previous block has been consumed
+        for (int e = tid; e < KB * CPR; e += 256) {
+            const int row = e / CPR, c = e - row * CPR;
+            int kr = k0 + row; kr = kr < S ? kr : S - 1;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
+            if (c * 8 < DH) {
+                kv = *reinterpret_cast<const u32x4*>(base + (int64_t)kr * ld + D + c * 8);
+                vv = *reinterpret_cast<const u32x4*>(base + (int64_t)kr * ld + 2 * D + c * 8);
+            }
+            const int off = pv_swz<CPR>(row, c);
+            *reinterpret_cast<u32x4*>(Ks + off) = kv;
+            *reinterpret_cast<u32x4*>(Vs + off) = vv;
+        }
+        __syncthreads();
+        f32x4 sc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                a = PV_MFMA_16x16x32(*reinterpret_cast<const bf16x8*>(Ks + koff[ks] + kt * (16 * DHP * 2)), qf[ks], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + kt * 16 + 4 * g + r >= S) a[r] = -INFINITY;
+            sc[kt] = a;
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bm = fmaxf(fmaxf(bm, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);             // finite from the first block on (key 0 is never masked)
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+        const float nm = -mn * LOG2E;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], LOG2E, nm));
+                sc[kt][r] = pe;
+                ps += pe;
+            }
+        l = fmaf(l, alpha, ps);
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = o[dt] * alpha;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            u32x4 pw = {pv_pack_bf16x2(sc[2 * tt][0], sc[2 * tt][1]), pv_pack_bf16x2(sc[2 * tt][2], sc[2 * tt][3]),
+                        pv_pack_bf16x2(sc[2 * tt + 1][0], sc[2 * tt + 1][1]), pv_pack_bf16x2(sc[2 * tt + 1][2], sc[2 * tt + 1][3])};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff[dt] + tt * (32 * DHP * 2)));
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff[dt] + tt * (32 * DHP * 2) + 16 * DHP * 2));
+                const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q0 + i16 < S) {
+        const float inv = 1.0f / l;
+        uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            u32x2 ov = {pv_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pv_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+            *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+        }
+    }
+}
+
+template <int DH>
+static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    const int nqb = (S + 63) / 64;
+    if (B * H * nqb > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_attn_stream_kernel<DH>, dim3((unsigned)(B * H * nqb)), dim3(256), 0, stream, qkv, out, S, H, nqb);
+    return pv_check_launch();
+}
+
 template <int DH>
 static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
     switch ((S + 15) / 16) {
@@ -262,7 +387,7 @@ static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S
         PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20) PV_ATTN_CASE(21)
         PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
-        default: return PV_ERR_UNSUPPORTED;
+        default: return pv_launch_attn_stream<DH>(qkv, out, B, S, H, stream);
     }
 }
 
@@ -649,7 +774,7 @@ extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B
 extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return PV_ERR_INVALID_ARG;
-    if (S > 416 || B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    if (B * H > 0x7fffffff || S > 0x3fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
         case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, s);

@@ -219,3 +219,17 @@ def test_uint8_nhwc_input_is_bit_identical_to_normalised_fp32_nchw():
         a = m(x.contiguous().to(DEV)).cpu()
         b = m(raw.to(DEV)).cpu()
     assert torch.equal(a, b)
+
+
+def test_vit_384_long_sequence_forward():
+    """384x384 at patch 16 -> S = 577 (> the 416 tokens the LDS-resident attention holds): whole forward vs the stock-op composite."""
+    from peekvit_amd.models.vit import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(image_size=384, patch_size=16, num_layers=2, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=10)
+    torch.nn.init.normal_(m.head.weight, std=0.05)
+    m = m.eval().to("cuda:0")
+    x = torch.randn(3, 3, 384, 384, device="cuda:0")
+    with torch.no_grad():
+        got = m(x)
+        ref = m._composite_head(m.encoder(m._composite_tokens(x)))
+    assert rel_l2(got.cpu(), ref.cpu()) < 1.2e-2

@@ -195,6 +195,23 @@ def test_attention(ops, B, S, H, dh):
     assert rel_l2(out.float().cpu(), exact.transpose(1, 2).reshape(B, S, D)) < 6e-3
 
 
+@pytest.mark.parametrize("B,S,H,dh", [(1, 417, 2, 64), (2, 577, 12, 64), (1, 785, 3, 32), (1, 1025, 2, 48), (1, 2000, 1, 64)])
+def test_attention_long_sequences(ops, B, S, H, dh):
+    """S > 416 (e.g. 384x384 images at patch 16: S = 577): the streaming kernel with the online softmax."""
+    D = H * dh
+    qkv = T(f"lqkv{S}{H}{dh}", (B, S, 3 * D), scale=1.0)
+    qkv[..., :D] *= dh ** -0.5
+    qkv[0, 5, :dh] = 3.0                   # one query with a few dominant keys: exercises the running-max rescale across blocks
+    qkv[0, S - 3, D:D + dh] = 3.0
+    qkv = qkv.to(torch.bfloat16).float()
+    out = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(torch.bfloat16).to(DEV), out, B, S, H, dh)
+    q, k, v = (t.reshape(B, S, H, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    exact = (torch.softmax(q.double() @ k.double().transpose(-1, -2), -1) @ v.double()).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), exact) < 6e-3
+
+
 def test_attention_spiked_scores(ops):
     """One key dominates a query row (softmax ~ one-hot) and one row has huge negative scores."""
     B, S, H, dh = 1, 197, 1, 64
