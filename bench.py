@@ -178,6 +178,9 @@ def main():
             barrier()
             elapsed_instr = time.perf_counter() - t1
     assert torch.isfinite(out).all()
+    if args.train:
+        grads = [p.grad for p in infer_model.parameters()]
+        assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads), "non-finite parameter gradient"
     if dist:
         t = torch.tensor([elapsed, elapsed_instr], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
