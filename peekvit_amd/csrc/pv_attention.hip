@@ -640,13 +640,26 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // pairs of key tiles feed the K = 32 MFMA (twice the rate of the K = 16 form): slot j < 4 of lane group g = key 32t + 4g + j,
+        // slot j >= 4 = key 32t + 16 + 4g + j - 4, the same order on both operands; an odd last tile uses the K = 16 MFMA
+        auto ds_pack = [&](int kt) __attribute__((always_inline)) {
+            return (u32x2){pv_pack_bf16x2(sc[kt][0] * (dp[kt][0] - dd), sc[kt][1] * (dp[kt][1] - dd)),
+                           pv_pack_bf16x2(sc[kt][2] * (dp[kt][2] - dd), sc[kt][3] * (dp[kt][3] - dd))};
+        };
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const u32x2 dw = {pv_pack_bf16x2(sc[kt][0] * (dp[kt][0] - dd), sc[kt][1] * (dp[kt][1] - dd)),
-                              pv_pack_bf16x2(sc[kt][2] * (dp[kt][2] - dd), sc[kt][3] * (dp[kt][3] - dd))};
-            const s16x4 dsf = __builtin_bit_cast(s16x4, dw);
+        for (int tt = 0; tt < NKT / 2; ++tt) {
+            const u32x2 d0 = ds_pack(2 * tt), d1 = ds_pack(2 * tt + 1);
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(tfrag(Ks, kt, dt), dsf, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const s16x8 kk = __builtin_shufflevector(tfrag(Ks, 2 * tt, dt), tfrag(Ks, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+                dq[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, kk), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (NKT & 1) {
+            const s16x4 dsf = __builtin_bit_cast(s16x4, ds_pack(NKT - 1));
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(tfrag(Ks, NKT - 1, dt), dsf, dq[dt], 0, 0, 0);
         }
         if (q0 + i16 < S) {       // dq[dt][r] = dL/dq'[q0+i16][dt*16 + 4g + r]; the in-proj output is q'/qscale
             uint16_t* op = gb + (int64_t)(q0 + i16) * ld + 4 * g;
@@ -669,7 +682,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
         f32x4 dv[NDT], dk[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
-        for (int qt = 0; qt < nqt; ++qt) {
+        // probabilities / dS of one (q tile, key tile) pair from the saved row statistics: p[r], ds[r] for query qt*16 + 4g + r
+        auto pds = [&](int qt, u32x2& pw, u32x2& dw) __attribute__((always_inline)) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -686,13 +700,33 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
                 p[r] = key_ok ? __builtin_amdgcn_exp2f((s[r] - mm[r]) * LOG2E) * ii[r] : 0.f;
                 ds[r] = p[r] * (c[r] - dd[r]);
             }
-            const u32x2 pw = {pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
-            const u32x2 dw = {pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+            pw = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
+            dw = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+        };
+        // q tiles in pairs on the K = 32 MFMA (same slot order on both operands as in pass 1), an odd last tile on the K = 16 form
+#pragma unroll 1
+        for (int tt = 0; tt < NKT / 2; ++tt) {
+            u32x2 p0, d0, p1, d1;
+            pds(2 * tt, p0, d0);
+            pds(2 * tt + 1, p1, d1);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[0], p0[1], p1[0], p1[1]});
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const s16x8 oo = __builtin_shufflevector(tfrag(Os, 2 * tt, dt), tfrag(Os, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8 qq = __builtin_shufflevector(tfrag(Qs, 2 * tt, dt), tfrag(Qs, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+                dv[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, oo), pf, dv[dt], 0, 0, 0);
+                dk[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, qq), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (NKT & 1) {
+            u32x2 pw, dw;
+            pds(NKT - 1, pw, dw);
             const s16x4 pf = __builtin_bit_cast(s16x4, pw), dsf = __builtin_bit_cast(s16x4, dw);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                dv[dt] = PV_MFMA_16x16x16(tfrag(Os, qt, dt), pf, dv[dt], 0, 0, 0);
-                dk[dt] = PV_MFMA_16x16x16(tfrag(Qs, qt, dt), dsf, dk[dt], 0, 0, 0);
+                dv[dt] = PV_MFMA_16x16x16(tfrag(Os, NKT - 1, dt), pf, dv[dt], 0, 0, 0);
+                dk[dt] = PV_MFMA_16x16x16(tfrag(Qs, NKT - 1, dt), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (key_ok) {             // d*[dt][r] = dL/d{k,v}[k0+i16][dt*16 + 4g + r]

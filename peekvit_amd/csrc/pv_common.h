@@ -28,7 +28,6 @@ typedef __attribute__((ext_vector_type(4))) _Float16 pv_h4_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 pv_h8_t;
 #define PV_OPERAND_CODE 1
 #define PV_MFMA_16x16x32(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pv_h8_t, a), __builtin_bit_cast(pv_h8_t, b), c, 0, 0, 0)
-#define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pv_h4_t, a), __builtin_bit_cast(pv_h4_t, b), c, 0, 0, 0)
 __device__ __forceinline__ uint16_t pv_f2bf(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 __device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
     const pv_f32x2_t v = {lo, hi};
@@ -39,7 +38,6 @@ __device__ __forceinline__ float pv_unpack_hi(uint32_t w) { return (float)__buil
 #else
 #define PV_OPERAND_CODE 0
 #define PV_MFMA_16x16x32(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
-#define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0)
 // fp32 -> bf16 bits, round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN.
 __device__ __forceinline__ uint16_t pv_f2bf(float f) {
     __bf16 h = (__bf16)f;
@@ -64,6 +62,18 @@ __device__ __forceinline__ PvHiLo pv_split2(float a, float b) {
 }
 
 __device__ __forceinline__ float pv_bf2f(uint16_t b) { return pv_unpack_lo((uint32_t)b); }
+
+// K = 16 product (4 operand values per lane: lane group g supplies k = 4g .. 4g+3) on the K = 32 MFMA with the upper four slots
+// of BOTH operands zero.  The native v_mfma_f32_16x16x16_bf16 is NOT used: hipcc (ROCm 7.2) allocates its destination over its
+// A-operand registers (no early-clobber for the "4-pass" form), and on gfx950 that returned wrong values in exactly the
+// overlapping registers (first seen in the attention backward: dq[2][0..1], run-to-run varying).  The zero-padded K = 32 form
+// costs the same issue slots as the half-rate K = 16 instruction.
+typedef __attribute__((ext_vector_type(8))) short pv_s16x8_t;
+__device__ __forceinline__ bf16x8 pv_pad_k16(s16x4 v) {
+    const s16x4 z = {0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v, z, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) PV_MFMA_16x16x32(pv_pad_k16(__builtin_bit_cast(s16x4, a)), pv_pad_k16(__builtin_bit_cast(s16x4, b)), c, 0, 0, 0)
 
 __device__ __forceinline__ float pv_wave_sum(float v) {
 #pragma unroll
