@@ -179,9 +179,10 @@ int pv_scatter_tokens(const float* dy, const int32_t* keep, float* dx, int64_t B
 /* Attention backward for one block (models/blocks.py:32-37 under train/train.py:118 loss.backward()):
  * qkv bf16 [B,S,3D] as the forward in-proj wrote it (q columns pre-scaled by qscale), dout bf16 [B,S,D] = dL/d(attention
  * output); dqkv bf16 [B,S,3D] = dL/d(in-proj output before the q pre-scale).  Probabilities are recomputed.
- * dh in {32, 48, 64}; S <= 208 (S <= 416 at dh = 32): Q, K, V and dO of one head live in the LDS. */
-int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
-                          float qscale, void* stream);
+ * dbias_partial (fp32 [B, 3D], optional): per-image column sums of dqkv (of the stored 16-bit values); their sum over B is the
+ * in-proj bias gradient.  dh in {32, 48, 64}; S <= 208 (S <= 416 at dh = 32): Q, K, V and dO of one head live in the LDS. */
+int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbias_partial, int64_t B, int64_t S,
+                          int64_t H, int64_t dh, float qscale, void* stream);
 
 /* Final LayerNorm on the class-token rows only + sum over class tokens:
  *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.

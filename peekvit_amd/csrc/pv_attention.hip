@@ -529,7 +529,7 @@ static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int 
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NKT, int NW>     // NW waves per workgroup: 8, or 4 when the 2*NKT accumulator tiles need the full register file
 __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                          uint16_t* __restrict__ dqkv, int S, int H, float qscale) {
+                                                          uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H, float qscale) {
     constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;      // TB: bytes of 16 LDS rows
     constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
     constexpr float LOG2E = 1.44269504088896340736f;
@@ -587,6 +587,10 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * TB));
     };
     const int nqt = (S + 15) >> 4;
+    // column sums of the stored (operand-rounded) gradient rows of this (image, head): the in-proj bias gradient, per lane here
+    f32x4 cq[NDT], ck[NDT], cv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { cq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ck[dt] = cq[dt]; cv[dt] = cq[dt]; }
 
     // =============================== pass 1: per 16-query tile ===============================
     for (int qt = wid; qt < nqt; qt += NW) {
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             for (int dt = 0; dt < NDT; ++dt) {
                 const u32x2 ov = {pv_pack_bf16x2(dq[dt][0] * qscale, dq[dt][1] * qscale), pv_pack_bf16x2(dq[dt][2] * qscale, dq[dt][3] * qscale)};
                 *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+                cq[dt] += (f32x4){pv_unpack_lo(ov[0]), pv_unpack_hi(ov[0]), pv_unpack_lo(ov[1]), pv_unpack_hi(ov[1])};
             }
         }
     }
@@ -737,13 +742,36 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
                 const u32x2 vv = {pv_pack_bf16x2(dv[dt][0], dv[dt][1]), pv_pack_bf16x2(dv[dt][2], dv[dt][3])};
                 *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
                 *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;
+                ck[dt] += (f32x4){pv_unpack_lo(kv[0]), pv_unpack_hi(kv[0]), pv_unpack_lo(kv[1]), pv_unpack_hi(kv[1])};
+                cv[dt] += (f32x4){pv_unpack_lo(vv[0]), pv_unpack_hi(vv[0]), pv_unpack_lo(vv[1]), pv_unpack_hi(vv[1])};
             }
+        }
+    }
+    if (dbp) {        // (workgroup-uniform) sum over the 16 rows a lane group holds, then over the waves through LDS
+        __syncthreads();                                  // every wave has left pass 2: the Q image is free
+        float* red = reinterpret_cast<float*>(smem);      // [NW][3][DH]
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = pv_row16_sum(cq[dt][r]), bsum = pv_row16_sum(ck[dt][r]), c = pv_row16_sum(cv[dt][r]);
+                if (i16 == 0) {
+                    const int col = dt * 16 + 4 * g + r;
+                    red[(wid * 3 + 0) * DH + col] = a; red[(wid * 3 + 1) * DH + col] = bsum; red[(wid * 3 + 2) * DH + col] = c;
+                }
+            }
+        __syncthreads();
+        for (int e = tid; e < 3 * DH; e += NW * 64) {
+            const int part = e / DH, col = e - part * DH;
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red[(w * 3 + part) * DH + col];
+            dbp[(int64_t)b * 3 * D + part * D + h * DH + col] = t;
         }
     }
 }
 
 template <int DH, int NKT>
-static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int S, int H, float qscale, hipStream_t stream) {
+static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int lds = 4 * NKT * 16 * DHP * 2 + 3 * NKT * 16 * 4;
     constexpr int NW = NKT <= 13 ? 8 : 4;
@@ -753,14 +781,14 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd_kernel<DH, NKT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    PV_LAUNCH((pv_attn_bwd_kernel<DH, NKT, NW>), dim3((unsigned)(B * H)), dim3(NW * 64), lds, stream, qkv, dout, dqkv, S, H, qscale);
+    PV_LAUNCH((pv_attn_bwd_kernel<DH, NKT, NW>), dim3((unsigned)(B * H)), dim3(NW * 64), lds, stream, qkv, dout, dqkv, dbp, S, H, qscale);
     return pv_check_launch();
 }
 
 template <int DH>
-static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int S, int H, float qscale, hipStream_t s) {
+static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t s) {
     switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, B, S, H, qscale, s);
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, dbp, B, S, H, qscale, s);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
         PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
 #undef PV_ATTN_CASE
@@ -768,7 +796,7 @@ static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint1
     }
     if constexpr (DH == 32) {                  // 64-byte LDS rows: twice the sequence fits
         switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, B, S, H, qscale, s);
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, dbp, B, S, H, qscale, s);
             PV_ATTN_CASE(14) PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20)
             PV_ATTN_CASE(21) PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
@@ -778,16 +806,16 @@ static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint1
     return PV_ERR_UNSUPPORTED;
 }
 
-extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, int64_t B, int64_t S, int64_t H, int64_t dh,
-                                     float qscale, void* stream) {
+extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbias_partial, int64_t B, int64_t S,
+                                     int64_t H, int64_t dh, float qscale, void* stream) {
     if (!qkv || !dout || !dqkv || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return PV_ERR_INVALID_ARG;
     if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {          // S <= 208 at dh = 48 / 64, S <= 416 at dh = 32
-        case 32: return pv_dispatch_attn_bwd<32>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
-        case 48: return pv_dispatch_attn_bwd<48>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
-        case 64: return pv_dispatch_attn_bwd<64>(qkv, dout, dqkv, B, (int)S, (int)H, qscale, s);
+        case 32: return pv_dispatch_attn_bwd<32>(qkv, dout, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
+        case 48: return pv_dispatch_attn_bwd<48>(qkv, dout, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
+        case 64: return pv_dispatch_attn_bwd<64>(qkv, dout, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
         default: return PV_ERR_UNSUPPORTED;
     }
 }

@@ -288,10 +288,12 @@ def gelu_bwd(pre: torch.Tensor, dg: torch.Tensor, dpre: Optional[torch.Tensor] =
     return dpre
 
 
-def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, B: int, S: int, H: int, dh: int, qscale: float):
+def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, B: int, S: int, H: int, dh: int, qscale: float,
+                  dbias_partial: Optional[torch.Tensor] = None):
+    """dbias_partial (fp32 [B, 3*H*dh], optional) receives the per-image column sums of dqkv."""
     with _timed("pv_attention_bwd_bf16", qkv.device, 14.0 * B * H * S * S * dh, 14.0 * B * S * H * dh):
-        check(_lib.load().pv_attention_bwd_bf16(_ptr(qkv), _ptr(dout), _ptr(dqkv), B, S, H, dh, float(qscale), _stream(qkv)),
-              "pv_attention_bwd_bf16")
+        check(_lib.load().pv_attention_bwd_bf16(_ptr(qkv), _ptr(dout), _ptr(dqkv), _ptr(dbias_partial), B, S, H, dh, float(qscale),
+                                                _stream(qkv)), "pv_attention_bwd_bf16")
     _count()
     return dqkv
 

@@ -183,8 +183,10 @@ class BlockFn(torch.autograd.Function):
         datt = ws.get("bw_datt", (R, D), bf, dev)
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
-        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale)
-        dwin, dbin = _wgrad(dqkv, h1, "qkv")
+        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev)
+        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev))        # sum of the per-image column sums
+        dwin, _ = _wgrad(dqkv, h1, "qkv", bias_grad=False)
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)

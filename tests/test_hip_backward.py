@@ -86,9 +86,11 @@ def test_attention_backward(ops, B, S, H, dh):
     qkv[..., :D] = (qkv[..., :D].float() * qscale).to(torch.bfloat16)
     dout = _bf(B, S, D, seed=S + 1, scale=0.1)
     dqkv = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ops.attention_bwd(qkv, dout, dqkv, B, S, H, dh, qscale)
+    dbp = torch.full((B, 3 * D), float("nan"), device="cuda")
+    ops.attention_bwd(qkv, dout, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
     ref = _attn_ref(qkv, dout, B, S, H, dh, qscale)
     assert torch.isfinite(dqkv.float()).all()
+    assert rel_l2(dbp, dqkv.double().sum(1)) < 2e-6               # per-image column sums of exactly the stored values
     for i, name in enumerate("qkv"):
         err = rel_l2(dqkv[..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
