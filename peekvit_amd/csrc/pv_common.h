@@ -75,11 +75,6 @@ __device__ __forceinline__ bf16x8 pv_pad_k16(s16x4 v) {
 }
 #define PV_MFMA_16x16x16(a, b, c, x_, y_, z_) PV_MFMA_16x16x32(pv_pad_k16(__builtin_bit_cast(s16x4, a)), pv_pad_k16(__builtin_bit_cast(s16x4, b)), c, 0, 0, 0)
 
-__device__ __forceinline__ float pv_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 // sum over the 16 lanes of a row (lanes 16r .. 16r+15) with DPP row operations - four full-rate VALU adds, no LDS crossbar:
 // xor 1, xor 2 (quad_perm), then the two quads of each half (row_half_mirror), then the two halves (row_mirror).
 __device__ __forceinline__ float pv_row16_sum(float v) {
@@ -88,6 +83,15 @@ __device__ __forceinline__ float pv_row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
     return v;
+}
+// wave-wide sum, the same value in every lane: DPP within the four 16-lane rows, then the four row sums through v_readlane
+// (scalar registers) - no ds_bpermute round trips (the 6-step __shfl_xor butterfly costs six LDS-crossbar latencies).
+__device__ __forceinline__ float pv_wave_sum(float v) {
+    v = pv_row16_sum(v);
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll

@@ -495,10 +495,8 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
                 s2 += (d[j].x * v.x + d[j].y * v.y) + (d[j].z * v.z + d[j].w * v.w);
             }
-        // the two sums travel together through the butterfly
-        s1 *= invD; s2 *= invD;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        s1 = pv_wave_sum(s1) * invD;
+        s2 = pv_wave_sum(s2) * invD;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = lane + 64 * j;
