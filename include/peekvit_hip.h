@@ -111,7 +111,14 @@ typedef struct pv_gemm_args {
      * products over K slices of K/ksplit (K % (64*ksplit) == 0) into out[t] = out + t*M*ldo (fp32), bias added by slice 0;
      * pv_sum_slices_f32 reduces them.  dW = dY^T . X (train.py:118 loss.backward()) = this GEMM on transposed activations. */
     int32_t ksplit;
+    /* PV_EPI_GELU_GRAD_BF16 only, optional: fp32 [ceil(M/256), N] receives the column sums of the stored output values per
+     * 256-row block (summed over the blocks = the fc1 bias gradient).  Served by the 256-row tile kernel only: ask
+     * pv_gemm_tile_rows() first and pass NULL when it answers 128. */
+    float* colsum_partial;
 } pv_gemm_args;
+
+/* The M-tile height (256 or 128) pv_gemm_bf16 would choose for these arguments (no launch). */
+int pv_gemm_tile_rows(const pv_gemm_args* args);
 
 /* out = epilogue(A . W^T): bf16 MFMA operands, fp32 accumulation.  Replaces the addmm/mm behind
  *   nn.MultiheadAttention in-proj / out-proj   models/blocks.py:91,94

@@ -52,6 +52,7 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
+    float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
     int ksplit;                // split-K (wgrad): blocks [t*ntiles, (t+1)*ntiles) compute K slice t into out + t*split_stride
     int k_slice;
     int64_t split_stride;      // elements of `out` between consecutive slices
@@ -527,6 +528,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         }
     } else {
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // PV_EPI_GELU_GRAD_BF16: this lane's 4 columns summed over the rows its wave stores
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
@@ -586,11 +588,26 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 } else if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
                 else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
                 if (m0 + ps * 128 + row < p.M && col_ok) {
-                    if (EPI == PV_EPI_GELU_GRAD_BF16)
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow[j] * p.ldo + ncol) = (u32x2){pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
-                    else
+                    if (EPI == PV_EPI_GELU_GRAD_BF16) {
+                        const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow[j] * p.ldo + ncol) = pk;
+                        csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
+                    } else
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
                 }
+            }
+        }
+        if (EPI == PV_EPI_GELU_GRAD_BF16 && p.colsum_partial) {      // (workgroup-uniform) combine the 8 waves through LDS: [8][256] floats
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // the last image has been consumed by every wave
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + wid * 1024 + lane * 16) = csum;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 256 && n0 + tid < p.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) t += *reinterpret_cast<const __attribute__((address_space(3))) float*>(cimg + w * 1024 + tid * 4);
+                p.colsum_partial[(int64_t)(m0 / G2_BM) * p.N + n0 + tid] = t;
             }
         }
     }
@@ -947,7 +964,15 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
     return pv_check_launch();
 }
 
-extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
+static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only);
+extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) { return pv_gemm_dispatch(a, stream, false); }
+extern "C" int pv_gemm_tile_rows(const pv_gemm_args* a) {
+    if (!a) return PV_ERR_INVALID_ARG;
+    pv_gemm_args q = *a;
+    q.colsum_partial = nullptr;
+    return pv_gemm_dispatch(&q, nullptr, true);
+}
+static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only) {
     if (!a || !a->A || !a->W || !a->out || a->M <= 0 || a->N <= 0 || a->K <= 0) return PV_ERR_INVALID_ARG;
     if (a->K % 64 || a->N % 4) return PV_ERR_UNSUPPORTED;
     if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->K || a->ldw < a->K || a->ldo < a->N) return PV_ERR_INVALID_ARG;
@@ -962,6 +987,8 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
 #ifdef PV_STAMPS
     p.dbg = g_pv_dbg;
 #endif
+    p.colsum_partial = a->colsum_partial;
+    if (a->colsum_partial && (a->epilogue != PV_EPI_GELU_GRAD_BF16 || ((uintptr_t)a->colsum_partial & 15))) return PV_ERR_INVALID_ARG;
     p.ksplit = a->ksplit > 1 ? a->ksplit : 1; p.k_slice = (int)(a->K / p.ksplit); p.split_stride = a->M * a->ldo;
     if (p.ksplit > 1) {
         // split-K: fp32 partial slices out[t] (t < ksplit) of M*ldo floats each, summed by pv_sum_slices_f32; bias goes to slice 0
@@ -992,6 +1019,8 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) {
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
                                        (p.M >= 2048 || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+    if (a->colsum_partial && !big) return PV_ERR_UNSUPPORTED;            // only the 256-row tile kernel produces it (pv_gemm_tile_rows)
+    if (query_only) return big ? G2_BM : G1_BM;
     if ((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
     p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768

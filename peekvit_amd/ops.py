@@ -143,9 +143,11 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag=""):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
     ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
+    colsum_out (PV_EPI_GELU_GRAD_BF16): fp32 [N] tensor that receives the column sums of the output (bias gradient) - fused into the
+    epilogue when the 256-row tile kernel serves the shape, a separate pv_colsum_f32 pass otherwise.
     ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
     K = a.shape[-1]
     if M is None:
@@ -162,10 +164,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     qcols=qcols, qscale=float(qscale), epilogue=epilogue,
                     ln_gamma=ln[0].data_ptr() if ln else 0, ln_beta=ln[1].data_ptr() if ln else 0,
                     ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
-                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit))
+                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit), colsum_partial=0)
+    part = None
+    if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
+        part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)
+        args.colsum_partial = part.data_ptr()
     with _timed("pv_gemm_bf16" + tag, a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
         check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
+    if colsum_out is not None:
+        colsum(part if part is not None else out, colsum_out)
     return out
 
 

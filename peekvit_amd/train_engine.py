@@ -169,8 +169,9 @@ class BlockFn(torch.autograd.Function):
         dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
         db2 = db2c if db2 is None else db2
         dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
-        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]")
-        dw1, db1 = _wgrad(dpre, h2, "fc1")
+        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev)
+        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]", colsum_out=db1)
+        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)

@@ -206,9 +206,11 @@ def test_gemm_training_epilogues(ops, M, N, K):
     xr = x.float().requires_grad_(True)
     torch.nn.functional.gelu(xr).sum().backward()
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ops.gemm(a, w, None, out, PV_EPI_GELU_GRAD_BF16, res=x)
+    csum = torch.full((N,), float("nan"), device="cuda")
+    ops.gemm(a, w, None, out, PV_EPI_GELU_GRAD_BF16, res=x, colsum_out=csum)
     ref = (a.float() @ w.float().t()) * xr.grad
     assert rel_l2(out.float(), ref) < 3e-3
+    assert rel_l2(csum, out.double().sum(0)) < 2e-6               # column sums of exactly the stored values (bias gradient)
 
 
 @pytest.mark.parametrize("K,M,N,ks,lda_pad", [(256, 128, 128, 1, 0), (1024, 256, 256, 4, 0), (4096, 768, 768, 8, 0), (2048, 384, 1536, 2, 0),
