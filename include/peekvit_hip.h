@@ -152,7 +152,7 @@ int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S
 /* Weight-gradient GEMM without transposed copies ("TN"): out[t][m][n] = sum over K slice t of A[k][m] * W[k][n], with
  * A = dY bf16 [K, M] (row stride lda), W = X bf16 [K, N] (row stride ldw), out fp32 [ksplit][M][ldo] partial slices for
  * pv_sum_slices_f32.  Same struct as pv_gemm_bf16 (epilogue must be PV_EPI_BIAS_F32, bias NULL).  M, N multiples of 128;
- * K a multiple of 128 * max(ksplit, 1).  dW = dY^T . X of train/train.py:118 loss.backward(). */
+ * K a multiple of 128 (>= 128 * ksplit; slice t covers rows [t*ks, ...) with ks = floor(K/128/ksplit)*128, the last slice the rest).  dW = dY^T . X of train/train.py:118 loss.backward(). */
 int pv_gemm_tn_bf16(const pv_gemm_args* args, void* stream);
 
 /* ---- backward building blocks (SURVEY.md section 2b "B*": what train/train.py:118 `loss.backward()` needs) ---- */

@@ -52,6 +52,7 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
+    int k_last;                // TN kernel: K extent of the last split-K slice (the slices need not be equal)
     float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
     int ksplit;                // split-K (wgrad): blocks [t*ntiles, (t+1)*ntiles) compute K slice t into out + t*split_stride
     int k_slice;
@@ -662,7 +663,8 @@ __global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) 
     GemmDev p = p_in;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int slice = blockIdx.x / ntiles;
-    p.A += (int64_t)slice * p.k_slice * p.lda; p.W += (int64_t)slice * p.k_slice * p.ldw; p.K = p.k_slice;
+    p.A += (int64_t)slice * p.k_slice * p.lda; p.W += (int64_t)slice * p.k_slice * p.ldw;
+    p.K = slice == p.ksplit - 1 ? p.k_last : p.k_slice;          // the last slice takes the remainder
     p.out = reinterpret_cast<float*>(p.out) + slice * p.split_stride;
     const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
@@ -840,11 +842,11 @@ __global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) 
 }
 
 // out fp32 [ksplit][M][ldo] partial products of A^T . B over K slices; A bf16 [K, M] (row stride lda), B = args->W bf16 [K, N]
-// (row stride ldw).  M, N multiples of 128, K a multiple of 128 * ksplit.
+// (row stride ldw).  M, N multiples of 128, K a multiple of 128 with at least ksplit blocks of 128 rows.
 extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->out || a->M < 8 || a->N < 8 || a->K <= 0) return PV_ERR_INVALID_ARG;
     const int ks = a->ksplit > 1 ? a->ksplit : 1;
-    if (a->M % 128 || a->N % 128 || a->K % (ks * 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
+    if (a->M % 128 || a->N % 128 || a->K % (2 * G2_BK) || a->K / (2 * G2_BK) < ks) return PV_ERR_UNSUPPORTED;
     if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->M || a->ldw < a->N || a->ldo < a->N) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) || ((uintptr_t)a->out & 15)) return PV_ERR_INVALID_ARG;
     if (a->epilogue != PV_EPI_BIAS_F32 || a->bias || a->qcols) return PV_ERR_INVALID_ARG;
@@ -853,7 +855,9 @@ extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
     p.A = a->A; p.W = a->W; p.out = a->out;
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
-    p.ksplit = ks; p.k_slice = (int)(a->K / ks); p.split_stride = a->M * a->ldo;
+    // K / 128 blocks of rows are dealt to the slices as evenly as whole blocks allow; the last slice takes the remainder
+    p.ksplit = ks; p.k_slice = (int)(a->K / (2 * G2_BK) / ks) * (2 * G2_BK); p.k_last = (int)a->K - p.k_slice * (ks - 1);
+    p.split_stride = a->M * a->ldo;
     p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = 1;
     if ((int64_t)p.tiles_m * p.tiles_n * ks > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     static bool attr_set = false;

@@ -91,8 +91,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
         s_ = 1
         while s_ < 32 and tiles * s_ < 512 and R // (s_ * 2) >= 256:
             s_ *= 2
-        k_slice = R // (128 * s_) * 128
-        r_main = k_slice * s_
+        r_main = R // 128 * 128                      # the TN kernel deals whole 128-row blocks to the slices (last slice: the rest)
         part = workspace.get("wg_part", (s_, No, Ni), torch.float32, dev)
         ops.gemm_tn(dy[:r_main], x[:r_main], part, s_)
         ops.sum_slices(part, out)

@@ -214,7 +214,8 @@ def test_gemm_training_epilogues(ops, M, N, K):
 
 
 @pytest.mark.parametrize("K,M,N,ks,lda_pad", [(256, 128, 128, 1, 0), (1024, 256, 256, 4, 0), (4096, 768, 768, 8, 0), (2048, 384, 1536, 2, 0),
-                                              (3072, 2304, 768, 4, 0), (1024, 3072, 768, 2, 3072), (512, 128, 640, 2, 0)])
+                                              (3072, 2304, 768, 4, 0), (1024, 3072, 768, 2, 3072), (512, 128, 640, 2, 0),
+                                              (1152, 256, 128, 4, 0), (896, 128, 128, 3, 0)])
 def test_gemm_tn_weight_gradient(ops, K, M, N, ks, lda_pad):
     """pv_gemm_tn_bf16: dW slices straight from row-major dY [K,M], X [K,N] (no transposed copies) vs fp32 matmul."""
     dy_full = _bf(K, M + lda_pad, seed=K + M, scale=0.1)
@@ -226,8 +227,10 @@ def test_gemm_tn_weight_gradient(ops, K, M, N, ks, lda_pad):
     ops.sum_slices(part, out)
     ref = dy.float().t() @ x.float()
     assert rel_l2(out, ref) < 2e-6
-    kslice = K // ks
-    assert rel_l2(part[ks - 1], dy[-kslice:].float().t() @ x[-kslice:].float()) < 2e-6
+    kslice = K // 128 // ks * 128                                # slices of whole 128-row blocks, the last one takes the remainder
+    klast = K - kslice * (ks - 1)
+    assert rel_l2(part[ks - 1], dy[-klast:].float().t() @ x[-klast:].float()) < 2e-6
+    assert rel_l2(part[0], dy[:kslice].float().t() @ x[:kslice].float()) < 2e-6
 
 
 def test_harness_training_loop_on_hip(monkeypatch, tmp_path):
