@@ -132,8 +132,8 @@ int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
  *   torch F.multi_head_attention_forward as called by models/blocks.py:94 (the head-averaged weights it
  *   also returns are discarded there and are not computed here).
  * qkv: bf16 [B,S,3*H*dh] packed q|k|v (nn.MultiheadAttention in_proj layout), out: bf16 [B,S,H*dh].
- * dh in {32,48,64}.  S <= 416: K and V of a head stay in the LDS (single-pass softmax); longer sequences stream 64-key blocks
- * with an online softmax. */
+ * dh in {32,48,64}: S <= 416 keeps K and V of a head in the LDS (single-pass softmax), longer sequences stream 64-key blocks
+ * with an online softmax; dh in {80,96,128}: the streaming kernel for every S. */
 int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
 
 /* ---- precision mode "bf16x3" (opt-in): split operands v = hi + lo, concatenated along K so that the

@@ -842,6 +842,10 @@ extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, 
         case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, s);
         case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, s);
         case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, s);
+        // wider heads (ViT-H: 80, 96, 128): the streaming kernel for every sequence length
+        case 80: return pv_launch_attn_stream<80>(qkv, out, B, (int)S, (int)H, s);
+        case 96: return pv_launch_attn_stream<96>(qkv, out, B, (int)S, (int)H, s);
+        case 128: return pv_launch_attn_stream<128>(qkv, out, B, (int)S, (int)H, s);
         default: return PV_ERR_UNSUPPORTED;
     }
 }

@@ -195,7 +195,8 @@ def test_attention(ops, B, S, H, dh):
     assert rel_l2(out.float().cpu(), exact.transpose(1, 2).reshape(B, S, D)) < 6e-3
 
 
-@pytest.mark.parametrize("B,S,H,dh", [(1, 417, 2, 64), (2, 577, 12, 64), (1, 785, 3, 32), (1, 1025, 2, 48), (1, 2000, 1, 64)])
+@pytest.mark.parametrize("B,S,H,dh", [(1, 417, 2, 64), (2, 577, 12, 64), (1, 785, 3, 32), (1, 1025, 2, 48), (1, 2000, 1, 64),
+                                      (2, 257, 4, 80), (1, 197, 2, 128), (1, 50, 3, 96)])
 def test_attention_long_sequences(ops, B, S, H, dh):
     """S > 416 (e.g. 384x384 images at patch 16: S = 577): the streaming kernel with the online softmax."""
     D = H * dh
