@@ -29,6 +29,9 @@ import torch
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0               # HBM3E spec, same guide
+# measured on this box (scripts/mfma_peak.hip, profiles/r01_mfma_peak.txt): register-only MFMA loop with data-like operand toggling;
+# reported next to the nominal peak, never used for `frac`
+MFMA_BF16_SUSTAINED_MEASURED_TFLOPS = 2003.0
 
 
 def parse():
@@ -193,7 +196,8 @@ def main():
         d = ks[dom]
         if d["flops"] > 0:
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                    "peak_sustained_mfma_only_measured": MFMA_BF16_SUSTAINED_MEASURED_TFLOPS}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
