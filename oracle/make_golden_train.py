@@ -1,0 +1,66 @@
+"""Generate tests/golden/train_step.npz: ONE training step of the REAL reference model.
+
+    python oracle/make_golden_train.py        (build container only; same import recipe as make_golden.py)
+
+The reference's step (train/train.py:112-121) is `out = model(batch); loss = CrossEntropyLoss()(out, labels); loss.backward();
+clip_grad_norm_(model.parameters(), 1.0); optimizer.step()` with Adam(lr 1e-3) (configs/optimizer/adam.yaml).  train.py itself needs
+hydra / torchmetrics (absent), so the step is driven here around the reference's own module class, in train mode.  Stored per
+model: logits, loss, per-parameter gradient L2 norms, the total norm, a few complete gradients, and per-parameter checksums of
+the weights after the clipped Adam step.  Inputs / weights / labels are pure functions (peekvit_amd.synth, labels = i mod C).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+import numpy as np
+import torch
+
+from make_golden import GOLD, import_reference
+from peekvit_amd import synth
+
+FULL_GRADS = ("head.weight", "head.bias", "class_tokens", "conv_proj.bias", "encoder.layers.0.ln_1.weight", "encoder.layers.0.ln_1.bias",
+              "encoder.layers.0.self_attention.self_attention.in_proj_bias", "encoder.layers.1.mlp.fc2.bias", "encoder.ln.weight")
+
+
+def main():
+    VT, _, _ = import_reference()
+    out = {}
+    for name, batch in (("vit_micro", 6), ("vit_tiny", 3)):
+        cfg = synth.MODEL_CONFIGS[name]
+        torch.manual_seed(0)
+        m = VT(**cfg)
+        synth.load_synth_weights(m, cfg, "vit", seed=0)
+        m.train()
+        x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
+        y = torch.arange(batch) % cfg["num_classes"]
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        opt.zero_grad()
+        logits = m(x)
+        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        names = [n for n, _ in m.named_parameters()]
+        gn = np.array([float(p.grad.norm()) for _, p in m.named_parameters()])
+        total = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0))
+        for n, p in m.named_parameters():
+            if n in FULL_GRADS:
+                out[f"{name}/grad/{n}"] = p.grad.detach().numpy().copy()      # AFTER the clip (scaled by 1/total when total > 1)
+        opt.step()
+        out[f"{name}/logits"] = logits.detach().numpy()
+        out[f"{name}/loss"] = np.array(float(loss))
+        out[f"{name}/grad_norms"] = gn                                        # before the clip, named_parameters() order
+        out[f"{name}/total_norm"] = np.array(total)
+        out[f"{name}/post_step_sum"] = np.array([float(p.detach().double().sum()) for _, p in m.named_parameters()])
+        out[f"{name}/post_step_abs"] = np.array([float(p.detach().double().abs().sum()) for _, p in m.named_parameters()])
+        out[f"{name}/names"] = np.array(names)
+        print(f"{name}: loss {float(loss):.6f} total grad norm {total:.5f} params {len(names)}")
+    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

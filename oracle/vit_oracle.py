@@ -40,6 +40,8 @@ def _t(sd: Dict[str, object], key: str) -> Tensor:
     v = sd[key]
     if not isinstance(v, torch.Tensor):
         v = torch.from_numpy(v)
+    if v.requires_grad:                 # training-step checks (tests): leaf parameters stay attached to autograd
+        return v
     return v.detach().to(torch.float32).cpu()
 
 

@@ -253,7 +253,9 @@ def run_layers(layers: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
         if nxt is not None and getattr(nxt, "_pv_plain_ln1", None) is not None and nxt._pv_plain_ln1():
             hint = nxt.ln_1
         if hasattr(layer, "_pv_next_ln"):
-            layer._pv_next_ln = hint
+            # a PLAIN attribute (nn.Module.__setattr__ would register the neighbour's LayerNorm as a submodule of this block and
+            # leak `layers.{i}._pv_next_ln.*` into named_parameters() / state_dict())
+            object.__setattr__(layer, "_pv_next_ln", hint)
         x = layer(x)
     return x
 

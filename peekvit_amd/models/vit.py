@@ -33,7 +33,9 @@ class ViTBlock(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.ln_2 = nn.LayerNorm(hidden_dim, eps=self.LN_EPS)
         self.mlp = MLP(hidden_dim=hidden_dim, mlp_dim=mlp_dim)
-        self._pv_next_ln = None     # engine hint: the LayerNorm the next block applies first (fused into fc2's epilogue)
+        # engine hint: the LayerNorm the next block applies first (fused into fc2's epilogue); always a plain attribute, never a
+        # registered submodule (engine.run_layers)
+        object.__setattr__(self, "_pv_next_ln", None)
 
     def _pv_plain_ln1(self) -> bool:
         """True when this block applies ln_1 directly to its input (so a producer may pre-compute it)."""

@@ -1,5 +1,6 @@
 """GPU parity of the backward building blocks (SURVEY.md section 2b "B*": train/train.py:118 loss.backward()) against
 torch autograd / plain torch fp32 on the same inputs.  Everything goes through the C ABI (peekvit_amd.ops)."""
+import numpy as np
 import pytest
 import torch
 
@@ -288,3 +289,33 @@ def test_rankvit_training_step(monkeypatch):
     for (n, ph), (_, pr) in zip(models[0].named_parameters(), models[1].named_parameters()):
         assert ph.grad is not None and torch.isfinite(ph.grad).all(), n
         assert rel_l2(ph.grad, pr.grad) < 6e-2, (n, rel_l2(ph.grad, pr.grad))
+
+
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3)])
+def test_training_step_vs_reference_golden(golden, name, batch):
+    """The HIP training path against ONE step of the REAL reference model (tests/golden/train_step.npz, made by
+    oracle/make_golden_train.py from /root/reference): loss, every parameter's gradient norm, complete gradients of nine parameters."""
+    from peekvit_amd import ops, synth
+    from peekvit_amd.models.vit import VisionTransformer
+    g = golden("train_step")
+    cfg = synth.MODEL_CONFIGS[name]
+    m = VisionTransformer(**cfg)
+    synth.load_synth_weights(m, cfg)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0)).cuda()
+    y = (torch.arange(batch) % cfg["num_classes"]).cuda()
+    n0 = ops.launch_count
+    loss = torch.nn.functional.cross_entropy(m(x), y)
+    loss.backward()
+    assert ops.launch_count - n0 > 20 * cfg["num_layers"], "the HIP training path did not run"
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 2e-3
+    named = dict(m.named_parameters())
+    names = [str(n) for n in g[f"{name}/names"]]
+    total_ref = float(g[f"{name}/total_norm"])
+    gn = np.array([float(named[n].grad.norm()) for n in names])
+    assert np.all(np.abs(gn - g[f"{name}/grad_norms"]) < 3e-2 * g[f"{name}/grad_norms"] + 1e-4 * total_ref), np.abs(gn / g[f"{name}/grad_norms"] - 1).max()
+    total = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0))
+    assert abs(total - total_ref) < 1e-2 * total_ref
+    for key in g.files:
+        if key.startswith(f"{name}/grad/"):
+            assert rel_l2(named[key.split("/grad/")[1]].grad, g[key]) < 3e-2, key

@@ -233,3 +233,19 @@ def test_vit_384_long_sequence_forward():
         got = m(x)
         ref = m._composite_head(m.encoder(m._composite_tokens(x)))
     assert rel_l2(got.cpu(), ref.cpu()) < 1.2e-2
+
+
+def test_forward_leaves_the_module_tree_untouched():
+    """The engine's per-block hints must never register modules: state_dict keys / named_parameters are the reference's before and
+    after a forward on the HIP path (checkpoints written after evaluation must load in a peekvit checkout)."""
+    from peekvit_amd import synth
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    m = VisionTransformer(**cfg)
+    synth.load_synth_weights(m, cfg)
+    m = m.eval().to("cuda:0")
+    keys, names = list(m.state_dict().keys()), [n for n, _ in m.named_parameters()]
+    with torch.no_grad():
+        m(torch.randn(2, 3, cfg["image_size"], cfg["image_size"], device="cuda:0"))
+    assert list(m.state_dict().keys()) == keys and [n for n, _ in m.named_parameters()] == names
+    assert not any("_pv" in k for k in keys)

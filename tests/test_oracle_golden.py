@@ -111,3 +111,32 @@ def test_meta_has_reference_error_contract():
     meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
     assert meta["errors"]["wrong_height"]["message"].startswith("Wrong image height!")
     assert "class_tokens" in meta["state_dict"]["vit_micro"]
+
+
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3)])
+def test_training_step_matches_the_reference(golden, name, batch):
+    """One step of the reference's loop (train/train.py:112-121: CE loss, backward, clip_grad_norm_ 1.0, Adam 1e-3) on the REAL
+    reference model (tests/golden/train_step.npz, oracle/make_golden_train.py) vs the oracle restatement under autograd."""
+    g = golden("train_step")
+    cfg = synth.MODEL_CONFIGS[name]
+    names = [str(n) for n in g[f"{name}/names"]]
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.synth_state_dict(cfg).items()}
+    x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
+    y = torch.arange(batch) % cfg["num_classes"]
+    params = [sd[n] for n in names]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    logits = O.vit_forward(x, sd, cfg, "fp32")
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    assert rel_l2(logits.detach().numpy(), g[f"{name}/logits"]) < 2e-6
+    assert abs(float(loss) - float(g[f"{name}/loss"])) < 1e-6
+    gn = np.array([float(p.grad.norm()) for p in params])
+    assert np.allclose(gn, g[f"{name}/grad_norms"], rtol=2e-4, atol=1e-7)
+    total = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+    assert abs(total - float(g[f"{name}/total_norm"])) < 2e-5 * total
+    for key in g.files:
+        if key.startswith(f"{name}/grad/"):
+            assert rel_l2(sd[key.split("/grad/")[1]].grad.numpy(), g[key]) < 2e-4, key
+    opt.step()
+    assert np.allclose([float(p.detach().double().abs().sum()) for p in params], g[f"{name}/post_step_abs"], rtol=1e-4)     # Adam's first step is -lr*g/(|g|+eps): elements with |g| ~ eps differ
+    assert np.allclose([float(p.detach().double().sum()) for p in params], g[f"{name}/post_step_sum"], rtol=1e-4, atol=2e-3)
