@@ -29,13 +29,17 @@ FULL_GRADS = ("head.weight", "head.bias", "class_tokens", "conv_proj.bias", "enc
 
 
 def main():
-    VT, _, _ = import_reference()
+    VT, RVT, _ = import_reference()
     out = {}
-    for name, batch in (("vit_micro", 6), ("vit_tiny", 3)):
-        cfg = synth.MODEL_CONFIGS[name]
+    # (tag, config, batch, class, extra kwargs, budget): the last row is RankViT (rankvit.py:55-101) pruning to half the tokens in layer 1
+    for name, cname, batch, cls, extra, budget in (("vit_micro", "vit_micro", 6, VT, {}, None), ("vit_tiny", "vit_tiny", 3, VT, {}, None),
+                                                   ("rankvit_micro", "vit_micro", 6, RVT, {"rankvit_layers": [1]}, 0.5)):
+        cfg = synth.MODEL_CONFIGS[cname]
         torch.manual_seed(0)
-        m = VT(**cfg)
+        m = cls(**cfg, **extra)
         synth.load_synth_weights(m, cfg, "vit", seed=0)
+        if budget is not None:
+            m.set_budget(budget)
         m.train()
         x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
         y = torch.arange(batch) % cfg["num_classes"]

@@ -291,15 +291,21 @@ def test_rankvit_training_step(monkeypatch):
         assert rel_l2(ph.grad, pr.grad) < 6e-2, (n, rel_l2(ph.grad, pr.grad))
 
 
-@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3)])
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6)])
 def test_training_step_vs_reference_golden(golden, name, batch):
     """The HIP training path against ONE step of the REAL reference model (tests/golden/train_step.npz, made by
     oracle/make_golden_train.py from /root/reference): loss, every parameter's gradient norm, complete gradients of nine parameters."""
     from peekvit_amd import ops, synth
     from peekvit_amd.models.vit import VisionTransformer
     g = golden("train_step")
-    cfg = synth.MODEL_CONFIGS[name]
-    m = VisionTransformer(**cfg)
+    if name.startswith("rankvit"):                       # the reference's RankViT (rankvit_layers=[1]) at budget 0.5
+        from peekvit_amd.models.rankvit import RankVisionTransformer
+        cfg = synth.MODEL_CONFIGS["vit_micro"]
+        m = RankVisionTransformer(**cfg, rankvit_layers=[1])
+        m.set_budget(0.5)
+    else:
+        cfg = synth.MODEL_CONFIGS[name]
+        m = VisionTransformer(**cfg)
     synth.load_synth_weights(m, cfg)
     m = m.cuda().train()
     x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0)).cuda()

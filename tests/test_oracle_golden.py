@@ -113,19 +113,20 @@ def test_meta_has_reference_error_contract():
     assert "class_tokens" in meta["state_dict"]["vit_micro"]
 
 
-@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3)])
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6)])
 def test_training_step_matches_the_reference(golden, name, batch):
     """One step of the reference's loop (train/train.py:112-121: CE loss, backward, clip_grad_norm_ 1.0, Adam 1e-3) on the REAL
     reference model (tests/golden/train_step.npz, oracle/make_golden_train.py) vs the oracle restatement under autograd."""
     g = golden("train_step")
-    cfg = synth.MODEL_CONFIGS[name]
+    rank = name.startswith("rankvit")
+    cfg = synth.MODEL_CONFIGS["vit_micro" if rank else name]
     names = [str(n) for n in g[f"{name}/names"]]
     sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.synth_state_dict(cfg).items()}
     x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
     y = torch.arange(batch) % cfg["num_classes"]
     params = [sd[n] for n in names]
     opt = torch.optim.Adam(params, lr=1e-3)
-    logits = O.vit_forward(x, sd, cfg, "fp32")
+    logits = O.vit_forward(x, sd, cfg, "fp32", rankvit_layers=[1] if rank else None, budget=0.5 if rank else 1.0)
     loss = torch.nn.functional.cross_entropy(logits, y)
     loss.backward()
     assert rel_l2(logits.detach().numpy(), g[f"{name}/logits"]) < 2e-6
