@@ -29,18 +29,22 @@ FULL_GRADS = ("head.weight", "head.bias", "class_tokens", "conv_proj.bias", "enc
 
 
 def main():
-    VT, RVT, _ = import_reference()
+    VT, RVT, ResVT = import_reference()
+    res_extra = dict(residual_layers=["attention+mlp"] * 2, gate_temp=1, add_input=False, gate_type="sigmoid", gate_threshold=0.5,
+                     gate_bias=10, add_budget_token="learnable")
     out = {}
     # (tag, config, batch, class, extra kwargs, budget): the last row is RankViT (rankvit.py:55-101) pruning to half the tokens in layer 1
     for name, cname, batch, cls, extra, budget in (("vit_micro", "vit_micro", 6, VT, {}, None), ("vit_tiny", "vit_tiny", 3, VT, {}, None),
-                                                   ("rankvit_micro", "vit_micro", 6, RVT, {"rankvit_layers": [1]}, 0.5)):
+                                                   ("rankvit_micro", "vit_micro", 6, RVT, {"rankvit_layers": [1]}, 0.5),
+                                                   ("residualvit_micro", "vit_micro", 6, ResVT, res_extra, 0.5)):
         cfg = synth.MODEL_CONFIGS[cname]
         torch.manual_seed(0)
         m = cls(**cfg, **extra)
-        synth.load_synth_weights(m, cfg, "vit", seed=0)
-        if budget is not None:
+        synth.load_synth_weights(m, dict(cfg, **extra) if cls is ResVT else cfg, "residualvit" if cls is ResVT else "vit", seed=0)
+        if budget is not None and cls is not ResVT:
             m.set_budget(budget)
         m.train()
+        torch.manual_seed(7)        # ResidualViT draws one budget per sample with torch.rand(n) in training (residualvit.py:541-549,565-567)
         x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
         y = torch.arange(batch) % cfg["num_classes"]
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)

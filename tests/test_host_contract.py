@@ -193,3 +193,31 @@ def test_flop_accounting_conventions():
     rs.set_budget(0.2)
     fl2, sp2 = flops.measured_flops(rs, x)
     assert sp2 < sp and fl2 > fl                       # golden: 81 % zeros at 0.2 vs 92 % at 0.5
+
+
+def test_residualvit_training_step_matches_the_reference():
+    """ResidualViT in TRAINING mode (sigmoid gates, learnable budget token, one budget per sample drawn with torch.rand(n):
+    reference models/residualvit.py:541-567) - this package's module vs one step of the REAL reference model
+    (tests/golden/train_step.npz): same RNG consumption, loss, every gradient norm, nine complete gradients."""
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    g = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    extra = dict(residual_layers=["attention+mlp"] * 2, gate_temp=1, add_input=False, gate_type="sigmoid", gate_threshold=0.5,
+                 gate_bias=10, add_budget_token="learnable")
+    m = ResidualVisionTransformer(**cfg, **extra)
+    synth.load_synth_weights(m, dict(cfg, **extra), "residualvit", seed=0)
+    m.train()
+    x = torch.from_numpy(synth.synth_images(6, cfg["image_size"], seed=0))
+    y = torch.arange(6) % cfg["num_classes"]
+    torch.manual_seed(7)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    name = "residualvit_micro"
+    assert rel_l2(logits.detach().numpy(), g[f"{name}/logits"]) < 2e-6
+    assert abs(float(loss) - float(g[f"{name}/loss"])) < 1e-6
+    named = dict(m.named_parameters())
+    names = [str(n) for n in g[f"{name}/names"]]
+    assert names == [n for n, _ in m.named_parameters()]
+    gn = np.array([float(named[n].grad.norm()) if named[n].grad is not None else 0.0 for n in names])
+    assert np.allclose(gn, g[f"{name}/grad_norms"], rtol=2e-4, atol=1e-7)
