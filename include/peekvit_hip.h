@@ -172,6 +172,16 @@ int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R
  * ws: fp32 scratch of >= min(ceil(rows/4),1024)*3*D floats.  D % 4 == 0, D <= 1024. */
 int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, uint16_t* dx_bf16,
                      float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
+/* Masked form for ResidualViT training (models/residualvit.py:249-260): the forward was y = row_scale[row] * LayerNorm(x).
+ * dmask fp32 [rows] (+)= sum_d dy * LayerNorm(x) (+ sum_d dx_out * u when u, the bf16 branch output of x1 = x + m*u, is given);
+ * dy is then scaled by row_scale and the plain backward follows.  scale_copy != 0 writes dx_bf16 = row_scale * dx_out (the gradient
+ * of u) - dgb[2] holds the column sums of that copy. */
+int pv_layernorm_bwd_masked(const float* x, const uint16_t* dy, const float* gamma, const float* beta, const float* row_scale,
+                            const float* dres_in, const uint16_t* u, float* dx_out, uint16_t* dx_bf16, int scale_copy, float* dgb,
+                            float* dmask, int dmask_accumulate, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps,
+                            void* stream);
+/* out = x + row_scale[row] * u: the masked residual add (residualvit.py:254) of the training forward, u = bf16 branch output. */
+int pv_masked_residual(const float* x, const uint16_t* u, const float* row_scale, float* out, int64_t rows, int64_t D, void* stream);
 /* Training-path GELU (models/blocks.py:82) on bf16 streams: out = gelu(pre);  dpre = dg * gelu'(pre) (may alias dg). n % 8 == 0. */
 int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream);
 int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream);

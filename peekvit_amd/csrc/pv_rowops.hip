@@ -445,11 +445,17 @@ extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma
 //   dgamma = sum_rows dy * xhat, dbeta = sum_rows dy:  per-lane column accumulators over the rows a wave walks, combined per
 //   block through LDS into ws[block][2][D]; pv_sum_slices_f32 finishes the reduction.  Statistics are recomputed from x.
 // ------------------------------------------------------------------------------------------------
-template <int NCH>
+// MASKED (ResidualViT, models/residualvit.py:249-260 under loss.backward()): the forward was y = m[row] * (xhat * gamma + beta).
+//   dmask[row] (+)= sum_d dy * (xhat * gamma + beta)  [+ sum_d dx_out * u  when the branch output u is given: x1 = x + m * u]
+//   then dy <- m * dy and everything proceeds as in the plain case; the 16-bit copy of dx_out can be written scaled by m (the
+//   gradient of the branch output u), and the third column-sum plane is taken of exactly that copy.
+template <int NCH, bool MASKED>
 __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres_in,
                                                                float* __restrict__ dx_out, uint16_t* __restrict__ dx_bf16, float* __restrict__ ws,
-                                                               int64_t rows, int D, float eps) {
+                                                               int64_t rows, int D, float eps, const float* __restrict__ beta,
+                                                               const float* __restrict__ row_scale, float* __restrict__ dmask,
+                                                               const uint16_t* __restrict__ u, int scale_copy, int dmask_accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
     float4 ag[NCH], ab[NCH], ac[NCH], gm[NCH];
 #pragma unroll
@@ -483,12 +489,19 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 q += (a * a + b * b) + (c * c + e * e);
             }
         const float rstd = 1.0f / sqrtf(pv_wave_sum(q) * invD + eps);
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, mdot = 0.f;
+        const float msk = MASKED ? row_scale[row] : 1.0f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
             if (lane + 64 * j < nvec) {
                 float4& v = r.v[j];                                          // v <- xhat
                 v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+                if (MASKED) {
+                    const float4 bt = reinterpret_cast<const float4*>(beta)[lane + 64 * j];
+                    mdot += (d[j].x * fmaf(v.x, gm[j].x, bt.x) + d[j].y * fmaf(v.y, gm[j].y, bt.y)) +
+                            (d[j].z * fmaf(v.z, gm[j].z, bt.z) + d[j].w * fmaf(v.w, gm[j].w, bt.w));
+                    d[j].x *= msk; d[j].y *= msk; d[j].z *= msk; d[j].w *= msk;
+                }
                 ag[j].x += d[j].x * v.x; ag[j].y += d[j].y * v.y; ag[j].z += d[j].z * v.z; ag[j].w += d[j].w * v.w;
                 ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
                 d[j].x *= gm[j].x; d[j].y *= gm[j].y; d[j].z *= gm[j].z; d[j].w *= gm[j].w;     // d <- g
@@ -507,8 +520,13 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                 o.z += rstd * (d[j].z - s1 - r.v[j].z * s2);
                 o.w += rstd * (d[j].w - s1 - r.v[j].w * s2);
                 reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
+                if (MASKED && u) {
+                    const u32x2 uw = reinterpret_cast<const u32x2*>(u + row * D)[idx];
+                    mdot += (o.x * pv_unpack_lo(uw[0]) + o.y * pv_unpack_hi(uw[0])) + (o.z * pv_unpack_lo(uw[1]) + o.w * pv_unpack_hi(uw[1]));
+                }
                 if (dx_bf16) {
-                    const u32x2 pk = {pv_pack_bf16x2(o.x, o.y), pv_pack_bf16x2(o.z, o.w)};
+                    const float cs_ = (MASKED && scale_copy) ? msk : 1.0f;
+                    const u32x2 pk = {pv_pack_bf16x2(o.x * cs_, o.y * cs_), pv_pack_bf16x2(o.z * cs_, o.w * cs_)};
                     reinterpret_cast<u32x2*>(dx_bf16 + row * D)[idx] = pk;
                     // column sums of the bf16 values the downstream GEMMs consume (their bias gradient)
                     ac[j].x += pv_unpack_lo(pk[0]); ac[j].y += pv_unpack_hi(pk[0]);
@@ -517,6 +535,10 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                     ac[j].x += o.x; ac[j].y += o.y; ac[j].z += o.z; ac[j].w += o.w;
                 }
             }
+        }
+        if (MASKED) {
+            mdot = pv_wave_sum(mdot);
+            if (lane == 0) dmask[row] = dmask_accumulate ? dmask[row] + mdot : mdot;
         }
     }
     // per-block partial sums through LDS: ws[block][3][D] (dgamma, dbeta, colsum dx); pv_colsum stage 2 adds the blocks up
@@ -546,11 +568,55 @@ extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float*
     if (blocks > 1024) blocks = 1024;
     if (ws_floats < blocks * 3 * D) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)blocks);
-#define LNB_LAUNCH(N) PV_LAUNCH(pv_layernorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps)
+#define LNB_LAUNCH(N) PV_LAUNCH((pv_layernorm_bwd_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps, \
+                                (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const uint16_t*)nullptr, 0, 0)
     { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
 #undef LNB_LAUNCH
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
     PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgb, blocks, (int)(3 * D), accumulate);
+    return pv_check_launch();
+}
+
+extern "C" int pv_layernorm_bwd_masked(const float* x, const uint16_t* dy, const float* gamma, const float* beta, const float* row_scale,
+                                       const float* dres_in, const uint16_t* u, float* dx_out, uint16_t* dx_bf16, int scale_copy, float* dgb,
+                                       float* dmask, int dmask_accumulate, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps,
+                                       void* stream) {
+    if (!x || !dy || !gamma || !beta || !row_scale || !dx_out || !dgb || !dmask || !ws || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 1024) return PV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)dx_out & 15) ||
+        ((uintptr_t)dgb & 15) || ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15)) || (dx_bf16 && ((uintptr_t)dx_bf16 & 7)) ||
+        (u && ((uintptr_t)u & 7))) return PV_ERR_INVALID_ARG;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (ws_floats < blocks * 3 * D) return PV_ERR_INVALID_ARG;
+    dim3 grid((unsigned)blocks);
+#define LNM_LAUNCH(N) PV_LAUNCH((pv_layernorm_bwd_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps, \
+                                beta, row_scale, dmask, u, scale_copy, dmask_accumulate)
+    { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNM_LAUNCH(1); } else if (nch_ == 2) { LNM_LAUNCH(2); } else if (nch_ == 3) { LNM_LAUNCH(3); } else { LNM_LAUNCH(4); } }
+#undef LNM_LAUNCH
+    if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
+    PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgb, blocks, (int)(3 * D), 0);
+    return pv_check_launch();
+}
+
+// x1 = x + m[row] * u  (fp32 residual stream, 16-bit branch output): the masked residual add of the ResidualViT training forward
+__global__ __launch_bounds__(256) void pv_masked_residual_kernel(const float* __restrict__ x, const uint16_t* __restrict__ u, const float* __restrict__ m,
+                                                                 float* __restrict__ out, int64_t rows, int D) {
+    const int nvec = D >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rows * nvec; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / nvec;
+        const float s = m[row];
+        const float4 xv = reinterpret_cast<const float4*>(x)[e];
+        const u32x2 uw = reinterpret_cast<const u32x2*>(u)[e];
+        reinterpret_cast<float4*>(out)[e] = make_float4(fmaf(s, pv_unpack_lo(uw[0]), xv.x), fmaf(s, pv_unpack_hi(uw[0]), xv.y),
+                                                        fmaf(s, pv_unpack_lo(uw[1]), xv.z), fmaf(s, pv_unpack_hi(uw[1]), xv.w));
+    }
+}
+
+extern "C" int pv_masked_residual(const float* x, const uint16_t* u, const float* row_scale, float* out, int64_t rows, int64_t D, void* stream) {
+    if (!x || !u || !row_scale || !out || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || ((uintptr_t)x & 15) || ((uintptr_t)u & 7) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_masked_residual_kernel, dim3(pv_stream_grid(rows * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, u, row_scale, out, rows, (int)D);
     return pv_check_launch();
 }
 

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from .. import engine, ops
+from .. import engine, ops, train_engine
 from .blocks import MLP, GumbelSigmoid, SelfAttention, SigmoidWithTemp
 from .vit import _ViTBase, _make_layers
 
@@ -151,9 +151,15 @@ class ResidualViTBlock(ResidualModule):
         """Masked pre-LN block: the mask multiplies LN1's output, the attention branch and LN2's output
         (reference models/residualvit.py:249-260)."""
         if mask is None:
+            if train_engine.train_eligible(input, self, self._p_drop) and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]):
+                return train_engine.block_forward_train(self, input)
             if engine.backend_for(input, self, self._p_drop) == "hip":
                 return engine.block_forward(self, input, self.ln_1.eps)
             mask = torch.tensor(1.0, device=input.device)
+        elif (mask.dim() == 3 and mask.shape[:2] == input.shape[:2] and train_engine.train_eligible(input, self, self._p_drop)
+              and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1])):
+            # training on the MI355X kernels: masked block forward + backward incl. the gradient of the mask (train_engine.MaskedBlockFn)
+            return train_engine.masked_block_forward_train(self, input, mask.to(input.device))
         mask = mask.to(input.device)
         mid = self.dropout(mask * self.self_attention(mask * self.ln_1(input))) + input
         return mid + self.mlp(mask * self.ln_2(mid))

@@ -276,6 +276,34 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_i
     return dx_out
 
 
+def layernorm_bwd_masked(x, dy, gamma, beta, row_scale, dres_in, u, dx_out, dx_bf16, scale_copy: bool, dgb, dmask, dmask_accumulate: bool,
+                         eps: float):
+    """Backward of y = row_scale * LayerNorm(x) (ResidualViT): as layernorm_bwd, plus dmask [rows] (+)= rowdot(dy, LN(x))
+    (+ rowdot(dx_out, u) when u is given); dx_bf16 = row_scale * dx_out when scale_copy."""
+    _chk(x, torch.float32, "x"); _chk(dy, _lib.operand_dtype(), "dy"); _chk(dx_out, torch.float32, "dx_out")
+    _chk(dgb, torch.float32, "dgb"); _chk(dmask, torch.float32, "dmask"); _chk(row_scale, torch.float32, "row_scale")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    blocks = min((rows + 3) // 4, 1024)
+    ws = torch.empty((blocks, 3 * D), dtype=torch.float32, device=x.device)
+    with _timed("pv_layernorm_bwd", x.device, 0.0, 16.0 * x.numel()):
+        check(_lib.load().pv_layernorm_bwd_masked(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(dres_in), _ptr(u),
+                                                  _ptr(dx_out), _ptr(dx_bf16), int(scale_copy), _ptr(dgb), _ptr(dmask), int(dmask_accumulate),
+                                                  _ptr(ws), ws.numel(), rows, D, float(eps), _stream(x)), "pv_layernorm_bwd_masked")
+    _count()
+    return dx_out
+
+
+def masked_residual(x: torch.Tensor, u: torch.Tensor, row_scale: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out = x + row_scale[row] * u  (x, out fp32 [rows, D]; u 16-bit [rows, D])."""
+    _chk(x, torch.float32, "x"); _chk(u, _lib.operand_dtype(), "u"); _chk(out, torch.float32, "out")
+    D = x.shape[-1]
+    with _timed("pv_masked_residual", x.device, 0.0, 10.0 * x.numel()):
+        check(_lib.load().pv_masked_residual(_ptr(x), _ptr(u), _ptr(row_scale), _ptr(out), x.numel() // D, D, _stream(x)), "pv_masked_residual")
+    _count()
+    return out
+
+
 def gelu(pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(pre, _lib.operand_dtype(), "pre")
     if out is None:

@@ -196,6 +196,100 @@ class BlockFn(torch.autograd.Function):
         return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
 
+class MaskedBlockFn(torch.autograd.Function):
+    """ResidualViT's masked pre-LN block (reference models/residualvit.py:249-260): with a per-token mask m [B,S] (1 on the class /
+    budget rows)  x1 = x + m * MHA(m * LN1(x)),  out = x1 + MLP(m * LN2(x1)).  Forward: the kernels of BlockFn with the row scale
+    in the LayerNorm kernels and a masked residual add (the bf16 branch output u is kept for the mask gradient); backward:
+    pv_layernorm_bwd_masked adds  dm = rowdot(dh1, LN1(x)) + rowdot(dh2, LN2(x1)) + rowdot(dx1, u)."""
+
+    @staticmethod
+    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+        x = x.float() if x.dtype != torch.float32 else x
+        x = x if x.is_contiguous() else x.contiguous()
+        m = m.float().contiguous()
+        B, S, D = x.shape
+        mha = blk.self_attention.self_attention
+        H = mha.num_heads
+        dh = D // H
+        Mh = blk.mlp.fc1.out_features
+        R, dev, bf = B * S, x.device, torch.bfloat16
+        h1 = torch.empty((R, D), dtype=bf, device=dev)
+        qkv = torch.empty((R, 3 * D), dtype=bf, device=dev)
+        att = torch.empty((R, D), dtype=bf, device=dev)
+        u = torch.empty((R, D), dtype=bf, device=dev)
+        x1 = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        h2 = torch.empty((R, D), dtype=bf, device=dev)
+        pair = torch.empty((R, 2 * Mh), dtype=bf, device=dev)
+        out = torch.empty_like(x)
+        qscale = float(dh) ** -0.5
+        mrow = m.view(R)
+        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), blk.ln_1.eps, h1, mrow)
+        ops.gemm(h1, bf16_weight(mha.in_proj_weight), _f32(inb), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=qscale)
+        ops.attention(qkv, att, B, S, H, dh)
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), u, PV_EPI_BIAS_BF16, M=R)
+        ops.masked_residual(x.view(R, D), u, mrow, x1.view(R, D))
+        ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2, mrow)
+        ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=R)
+        ops.gemm(pair[:, :Mh], bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
+        ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.save_for_backward(x, mrow, h1, qkv, att, u, x1, h2, pair)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        x, mrow, h1, qkv, att, u, x1, h2, pair = ctx.saved_tensors
+        B, S, D, H, dh, Mh, qscale = ctx.dims
+        gl, pre = pair[:, :Mh], pair[:, Mh:]
+        mha = blk.self_attention.self_attention
+        R, dev, bf = B * S, x.device, torch.bfloat16
+        dout = dout.float() if dout.dtype != torch.float32 else dout
+        ws = workspace
+        dout3 = dout
+        dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
+        d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
+        dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
+        db2 = db2c if db2 is None else db2
+        dpre = ws.get("bw_dgl", (R, Mh), bf, dev)
+        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev)
+        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]", colsum_out=db1)
+        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
+        dhid = ws.get("bw_dh", (R, D), bf, dev)
+        ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
+        dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
+        du = ws.get("bw_d1", (R, D), bf, dev)
+        dgb2 = torch.empty((3, D), dtype=torch.float32, device=dev)
+        dm = torch.empty((R,), dtype=torch.float32, device=dev)
+        ops.layernorm_bwd_masked(x1.view(R, D), dhid, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), mrow, dout, u, dx1, du, True, dgb2, dm, False,
+                                 blk.ln_2.eps)
+        dwo, _ = _wgrad(du, att, "proj", bias_grad=False)
+        dbo = dgb2[2]
+        datt = ws.get("bw_datt", (R, D), bf, dev)
+        ops.gemm(du, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
+        dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
+        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev)
+        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev))
+        dwin, _ = _wgrad(dqkv, h1, "qkv", bias_grad=False)
+        ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
+        dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        dxb = torch.empty((B, S, D), dtype=bf, device=dev)
+        dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
+        ops.layernorm_bwd_masked(x.view(R, D), dhid, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), mrow, dx1, None, dx.view(R, D), dxb, False, dgb1,
+                                 dm, True, blk.ln_1.eps)
+        dx._pv_bf16 = (dxb, dx._version, dgb1[2])
+        return (None, dx, dm.view(B, S), dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+
+
+def masked_block_forward_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """mask: [B,S,1] or [B,S] (carries the gate's autograd graph)."""
+    mha = blk.self_attention.self_attention
+    m = mask.squeeze(-1) if mask.dim() == 3 else mask
+    return MaskedBlockFn.apply(blk, x, m, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                               mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                               blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+
+
 def block_forward_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
     mha = blk.self_attention.self_attention
     return BlockFn.apply(blk, x, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,

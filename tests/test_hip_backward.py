@@ -325,3 +325,65 @@ def test_training_step_vs_reference_golden(golden, name, batch):
     for key in g.files:
         if key.startswith(f"{name}/grad/"):
             assert rel_l2(named[key.split("/grad/")[1]].grad, g[key]) < 3e-2, key
+
+
+@pytest.mark.parametrize("rows,D", [(50, 128), (3940, 768)])
+def test_layernorm_backward_masked(ops, rows, D):
+    """y = m * LayerNorm(x) (+ x1 = x + m * u elsewhere): dx, dgamma/dbeta, the mask gradient incl. the rowdot(dx_out, u) term,
+    and the m-scaled 16-bit copy, vs torch autograd."""
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, D, generator=g, device="cuda") * 2 + 0.5
+    gamma = torch.randn(D, generator=g, device="cuda") * 0.3 + 1
+    beta = torch.randn(D, generator=g, device="cuda") * 0.1
+    m = torch.rand(rows, generator=g, device="cuda")
+    m[::7] = 0.0                                               # relu-clipped gates are exactly zero
+    dy = _bf(rows, D, seed=rows + 1, scale=0.05)
+    dres = torch.randn(rows, D, generator=g, device="cuda") * 0.05
+    u = _bf(rows, D, seed=rows + 2, scale=0.5)
+    xr, gr, br, mr = (t.clone().requires_grad_(True) for t in (x, gamma, beta, m))
+    y = mr[:, None] * torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    y.backward(dy.float())
+    dx = torch.empty_like(x); dxb = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    dgb = torch.empty(3, D, device="cuda"); dm = torch.full((rows,), float("nan"), device="cuda")
+    ops.layernorm_bwd_masked(x, dy, gamma, beta, m, dres, u, dx, dxb, True, dgb, dm, False, 1e-6)
+    dx_ref = dres + xr.grad
+    assert rel_l2(dx, dx_ref) < 5e-6
+    assert rel_l2(dgb[0], gr.grad) < 5e-6 and rel_l2(dgb[1], br.grad) < 5e-6
+    assert rel_l2(dm, mr.grad + (dx_ref * u.float()).sum(1)) < 5e-6
+    assert torch.equal(dxb, (m[:, None] * dx).to(torch.bfloat16)) and rel_l2(dgb[2], dxb.double().sum(0)) < 5e-6
+    ops.layernorm_bwd_masked(x, dy, gamma, beta, m, None, None, dx, dxb, False, dgb, dm, True, 1e-6)      # accumulate, no u, unscaled copy
+    assert rel_l2(dm, 2 * mr.grad + (dx_ref * u.float()).sum(1)) < 5e-6
+    assert torch.equal(dxb, dx.to(torch.bfloat16)) and rel_l2(dx, xr.grad) < 5e-6
+
+
+def test_residualvit_training_step_vs_reference_golden(golden):
+    """ResidualViT (sigmoid gates, learnable budget token) in training: the masked blocks run forward + backward on the HIP kernels
+    (gate / stem / head on stock ops); loss and every gradient norm against ONE step of the REAL reference model."""
+    from peekvit_amd import ops, synth
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    g = golden("train_step")
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    extra = dict(residual_layers=["attention+mlp"] * 2, gate_temp=1, add_input=False, gate_type="sigmoid", gate_threshold=0.5,
+                 gate_bias=10, add_budget_token="learnable")
+    m = ResidualVisionTransformer(**cfg, **extra)
+    synth.load_synth_weights(m, dict(cfg, **extra), "residualvit", seed=0)
+    m = m.cuda().train()
+    x = torch.from_numpy(synth.synth_images(6, cfg["image_size"], seed=0)).cuda()
+    y = (torch.arange(6) % cfg["num_classes"]).cuda()
+    torch.manual_seed(7)                     # the per-sample budgets are drawn on the CPU generator (torch.rand(n)), as in the reference
+    n0 = ops.launch_count
+    loss = torch.nn.functional.cross_entropy(m(x), y)
+    loss.backward()
+    assert ops.launch_count - n0 > 50, "the HIP masked-block training path did not run"
+    name = "residualvit_micro"
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 2e-3
+    named = dict(m.named_parameters())
+    names = [str(n) for n in g[f"{name}/names"]]
+    total_ref = float(g[f"{name}/total_norm"])
+    gn = np.array([float(named[n].grad.norm()) for n in names])
+    ref = g[f"{name}/grad_norms"]
+    assert np.all(np.abs(gn - ref) < 3e-2 * ref + 1e-4 * total_ref), [(n, a, b) for n, a, b in zip(names, gn, ref) if abs(a - b) > 3e-2 * b + 1e-4 * total_ref]
+    for key in g.files:
+        if key.startswith(f"{name}/grad/"):
+            clip = min(1.0, 1.0 / (total_ref + 1e-6))          # the stored gradients are post-clip (max_norm 1.0)
+            assert rel_l2(named[key.split("/grad/")[1]].grad * clip, g[key]) < 3e-2, key
