@@ -47,7 +47,7 @@ def parse():
                          "ranks the parameter gradients are all-reduced over RCCL (data-parallel training path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"],
                     help="operand precision of the MFMA products: bf16 (headline), f16 (IEEE fp16 operands, same speed, meets the 1e-3 "
                          "logits tolerance) or split bf16x3 (1e-5)")
