@@ -150,6 +150,7 @@ def main():
         from peekvit_amd import dist as pvdist
         y = torch.randint(0, cfg["num_classes"], (args.batch,), generator=gen, device=dev)
         infer = model
+        reducer = pvdist.OverlappedGradReducer(infer.parameters()) if dist else None      # ~25 MB buckets leave during backward
 
         def train_step(inp):
             for p in infer.parameters():
@@ -157,7 +158,7 @@ def main():
             logits = infer(inp)
             torch.nn.functional.cross_entropy(logits, y).backward()
             if dist:
-                pvdist.allreduce_gradients(infer.parameters())
+                reducer.finish()
             return logits.detach()
 
         model = train_step

@@ -78,3 +78,60 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     return len(work)
+
+
+class OverlappedGradReducer:
+    """Gradient all-reduce OVERLAPPED with backward: a post-accumulate hook on every parameter files its
+    gradient into the current ~25 MB bucket; a full bucket is flattened and all-reduced asynchronously while backward keeps
+    producing the earlier layers' gradients (the HIP training path hands over one encoder block's 12 gradients at a time, last
+    block first).  `finish()` - called where the reference's loop has `clip_grad_norm_` (train/train.py:120) - flushes the last
+    bucket, waits for every collective, averages and writes the reduced values back into `p.grad`.
+
+        reducer = OverlappedGradReducer(model.parameters())
+        loss.backward(); reducer.finish(); clip_grad_norm_(...); optimizer.step()
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket_bytes, self.average = bucket_bytes, average
+        self._bucket: List[torch.nn.Parameter] = []
+        self._size = 0
+        self._work = []
+        self.buckets_launched = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _on_grad(self, p: torch.nn.Parameter):
+        nbytes = p.grad.numel() * p.grad.element_size()
+        if self._bucket and self._size + nbytes > self.bucket_bytes:
+            self._launch()
+        self._bucket.append(p)
+        self._size += nbytes
+
+    def _launch(self):
+        if not self._bucket:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in self._bucket])
+        self._work.append((td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True), flat, self._bucket))
+        self._bucket, self._size = [], 0
+        self.buckets_launched += 1
+
+    def finish(self) -> int:
+        """Flush, wait, average, write back.  Returns the number of buckets of this step."""
+        self._launch()
+        world = td.get_world_size()
+        for handle, flat, ps in self._work:
+            handle.wait()
+            if self.average:
+                flat.div_(world)
+            off = 0
+            for p in ps:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        n_buckets, self._work, self.buckets_launched = len(self._work), [], 0
+        return n_buckets
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

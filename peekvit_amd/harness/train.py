@@ -27,6 +27,7 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
     model.train()
     loss_fn = torch.nn.CrossEntropyLoss()
     last = float("nan")
+    reducer = pdist.OverlappedGradReducer(model.parameters()) if distributed else None   # buckets leave while backward still runs
     for batch, labels in loader:
         batch, labels = batch.to(device), labels.to(device)
         if distributed:                                   # rank r trains on samples r::world of the global batch
@@ -35,11 +36,13 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
         loss = loss_fn(model(batch), labels)
         loss.backward()
         if distributed:
-            pdist.allreduce_gradients(model.parameters())  # before the global-norm clip (train.py:120-121)
+            reducer.finish()                               # every bucket reduced before the global-norm clip (train.py:120-121)
         if clip:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         optimizer.step()
         last = float(loss.item())
+    if reducer is not None:
+        reducer.remove()
     return last
 
 

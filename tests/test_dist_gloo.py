@@ -38,9 +38,20 @@ def _worker(rank, world, port, out_dir):
     loss = torch.nn.functional.cross_entropy(out, dist.shard_batch(y), reduction="sum") / x.shape[0]
     loss.backward()
     nb = dist.allreduce_gradients(model.parameters(), bucket_bytes=64 << 10, average=False)
+    reduced = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # the same step again with the reduction OVERLAPPED with backward (hooks launch buckets while gradients still arrive)
+    for p in model.parameters():
+        p.grad = None
+    reducer = dist.OverlappedGradReducer(model.parameters(), bucket_bytes=64 << 10, average=False)
+    out = model(dist.shard_batch(x))
+    (torch.nn.functional.cross_entropy(out, dist.shard_batch(y), reduction="sum") / x.shape[0]).backward()
+    launched_during_backward = reducer.buckets_launched
+    nb2 = reducer.finish()
+    reducer.remove()
+    same = all(torch.equal(reduced[n], p.grad) for n, p in model.named_parameters() if p.grad is not None)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb,
-                 **{"g_" + n: p.grad.numpy() for n, p in model.named_parameters() if p.grad is not None})
+        np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same,
+                 **{"g_" + n: g.numpy() for n, g in reduced.items()})
     td.barrier()
     td.destroy_process_group()
 
@@ -62,5 +73,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     y = torch.arange(5) % cfg["num_classes"]
     torch.nn.functional.cross_entropy(model(x), y).backward()
     assert int(got["nb"]) > 1                                             # really bucketed
+    assert int(got["nb2"]) > 1 and int(got["early"]) >= 1                 # overlapped reducer: buckets left before backward ended
+    assert bool(got["same"])                                              # ... and produced bit-identical reduced gradients
     for n, p in model.named_parameters():
         assert np.allclose(got["g_" + n], p.grad.numpy(), rtol=1e-4, atol=1e-6), n
