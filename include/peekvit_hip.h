@@ -115,7 +115,20 @@ typedef struct pv_gemm_args {
      * 256-row block (summed over the blocks = the fc1 bias gradient).  Served by the 256-row tile kernel only: ask
      * pv_gemm_tile_rows() first and pass NULL when it answers 128. */
     float* colsum_partial;
+    /* LayerNorm folding (opt-in; 256-row tile kernel only).  Producer, PV_EPI_BIAS_RES_F32: x16_out bf16 [M, N] (row stride N)
+     * receives the 16-bit copy of the output rows, rowstat_out fp32 [ceil(N/256), M, 2] the (sum, sum of squares) of each row's
+     * segment per column tile.  Consumer, PV_EPI_BIAS_BF16 / PV_EPI_BIAS_GELU_BF16 with bias == NULL: A is that copy, W is
+     * gamma (.) W, and  acc <- fold_stat[m].rstd * (acc - fold_stat[m].mean * fold_c1[n]) + fold_c2[n]  precedes the epilogue
+     * (fold_stat fp32 [M, 2] from pv_rowstat_finalize; fold_c1[n] = sum_k W'[n,k]; fold_c2[n] = sum_k beta[k] W[n,k] + bias[n]). */
+    uint16_t* x16_out;
+    float* rowstat_out;
+    const float* fold_stat;
+    const float* fold_c1;
+    const float* fold_c2;
 } pv_gemm_args;
+
+/* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length. */
+int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, void* stream);
 
 /* The M-tile height (256 or 128) pv_gemm_bf16 would choose for these arguments (no launch). */
 int pv_gemm_tile_rows(const pv_gemm_args* args);

@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ("rows_per_img_in", _i64), ("rows_per_img_out", _i64), ("row_off", _i64), ("qcols", _i64),
                 ("qscale", _f32), ("epilogue", _i32),
                 ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32),
-                ("ksplit", _i32), ("colsum_partial", _p)]
+                ("ksplit", _i32), ("colsum_partial", _p),
+                ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p)]
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
@@ -62,6 +63,7 @@ SIGNATURES = {
     "pv_operand_type": (C.c_int, []),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "pv_gemm_tile_rows": (C.c_int, [C.POINTER(GemmArgs)]),
+    "pv_rowstat_finalize": (C.c_int, [_p, _p, _i64, _i64, _i64, _f32, _p]),
     "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_cls_pool": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_head_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),

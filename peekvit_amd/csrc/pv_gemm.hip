@@ -54,6 +54,14 @@ struct GemmDev {
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
     int k_last;                // TN kernel: K extent of the last split-K slice (the slices need not be equal)
     float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
+    // LayerNorm folding (opt-in): the PRODUCER (PV_EPI_BIAS_RES_F32) also emits the 16-bit copy of its
+    // output rows and per-(column tile, row) partial (sum, sum of squares); the CONSUMER (PV_EPI_BIAS_BF16 / _GELU_BF16) runs on that
+    // copy with W' = gamma (.) W and finishes  out = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]  before its usual epilogue.
+    uint16_t* x16_out;
+    float* rowstat_out;        // [tiles_n][M][2]
+    const float* fold_stat;    // [M][2] (mean, rstd)
+    const float* fold_c1;      // [N] = sum_k W'[n][k]
+    const float* fold_c2;      // [N] = sum_k beta[k] W[n][k] + bias[n]
     int ksplit;                // split-K (wgrad): blocks [t*ntiles, (t+1)*ntiles) compute K slice t into out + t*split_stride
     int k_slice;
     int64_t split_stride;      // elements of `out` between consecutive slices
@@ -471,9 +479,26 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 const int row = wr * 128 + mt * 16 + i16;
+                float f_mean = 0.f, f_rstd = 1.f;
+                if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
+                    const int mrow = m0 + row < p.M ? m0 + row : p.M - 1;
+                    const float2 st = *reinterpret_cast<const float2*>(p.fold_stat + 2 * (int64_t)mrow);
+                    f_mean = st.x; f_rstd = st.y;
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
+                    if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
+                        // folded LayerNorm: the accumulators hold x16 . (gamma (.) W)^T; columns en0 + 32u + 0..7 (clamped reads)
+                        int cb = en0 + u * 32; cb = cb + 8 <= p.N ? cb : p.N - 8;
+                        const f32x4 c1a = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb), c1b = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb + 4);
+                        const f32x4 c2a = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb), c2b = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            lo[e] = fmaf(f_rstd, fmaf(-f_mean, c1a[e], lo[e]), c2a[e]);
+                            hi[e] = fmaf(f_rstd, fmaf(-f_mean, c1b[e], hi[e]), c2b[e]);
+                        }
+                    }
                     // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
                     const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
                     u32x4 pk;
@@ -595,6 +620,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
                     } else
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
+                }
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
+                    const bool ok = m0 + ps * 128 + row < p.M && col_ok;
+                    if (ok)
+                        *reinterpret_cast<u32x2*>(p.x16_out + orow[j] * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
+                    float s_ = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+                    float q_ = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
+                    s_ = pv_wave_sum(s_); q_ = pv_wave_sum(q_);
+                    if (lane == 0 && m0 + ps * 128 + row < p.M)
+                        *reinterpret_cast<float2*>(p.rowstat_out + ((int64_t)(n0 / G2_BN) * p.M + orow[j]) * 2) = make_float2(s_, q_);
                 }
             }
         }
@@ -973,7 +1008,7 @@ extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) { return pv_gem
 extern "C" int pv_gemm_tile_rows(const pv_gemm_args* a) {
     if (!a) return PV_ERR_INVALID_ARG;
     pv_gemm_args q = *a;
-    q.colsum_partial = nullptr;
+    q.colsum_partial = nullptr; q.x16_out = nullptr; q.rowstat_out = nullptr; q.fold_stat = nullptr;
     return pv_gemm_dispatch(&q, nullptr, true);
 }
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only) {
@@ -992,6 +1027,11 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     p.dbg = g_pv_dbg;
 #endif
     p.colsum_partial = a->colsum_partial;
+    p.x16_out = a->x16_out; p.rowstat_out = a->rowstat_out; p.fold_stat = a->fold_stat; p.fold_c1 = a->fold_c1; p.fold_c2 = a->fold_c2;
+    if ((a->x16_out != nullptr) != (a->rowstat_out != nullptr)) return PV_ERR_INVALID_ARG;
+    if (a->x16_out && (a->epilogue != PV_EPI_BIAS_RES_F32 || ((uintptr_t)a->x16_out & 7) || ((uintptr_t)a->rowstat_out & 7))) return PV_ERR_INVALID_ARG;
+    if (a->fold_stat && ((a->epilogue != PV_EPI_BIAS_BF16 && a->epilogue != PV_EPI_BIAS_GELU_BF16) || a->bias || !a->fold_c1 || !a->fold_c2 || a->N < 8 ||
+                         ((uintptr_t)a->fold_stat & 7) || ((uintptr_t)a->fold_c1 & 15) || ((uintptr_t)a->fold_c2 & 15))) return PV_ERR_INVALID_ARG;
     if (a->colsum_partial && (a->epilogue != PV_EPI_GELU_GRAD_BF16 || ((uintptr_t)a->colsum_partial & 15))) return PV_ERR_INVALID_ARG;
     p.ksplit = a->ksplit > 1 ? a->ksplit : 1; p.k_slice = (int)(a->K / p.ksplit); p.split_stride = a->M * a->ldo;
     if (p.ksplit > 1) {
@@ -1023,7 +1063,7 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
                                        (p.M >= 2048 || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
-    if (a->colsum_partial && !big) return PV_ERR_UNSUPPORTED;            // only the 256-row tile kernel produces it (pv_gemm_tile_rows)
+    if ((a->colsum_partial || a->x16_out || a->fold_stat) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
     if (query_only) return big ? G2_BM : G1_BM;
     if ((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();

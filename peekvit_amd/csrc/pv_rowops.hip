@@ -620,6 +620,29 @@ extern "C" int pv_masked_residual(const float* x, const uint16_t* u, const float
     return pv_check_launch();
 }
 
+// LayerNorm folding: per-row (mean, rstd) from the (sum, sum of squares) partials the producer GEMM wrote per column tile
+__global__ __launch_bounds__(256) void pv_rowstat_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int tiles, int64_t rows,
+                                                                  float invD, float eps) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        float s = 0.f, q = 0.f;
+        for (int t = 0; t < tiles; ++t) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)t * rows + r) * 2);
+            s += v.x; q += v.y;
+        }
+        const float mean = s * invD;
+        const float var = fmaxf(q * invD - mean * mean, 0.f);
+        *reinterpret_cast<float2*>(stat + 2 * r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
+extern "C" int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, void* stream) {
+    if (!partials || !stat || tiles <= 0 || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)partials & 7) || ((uintptr_t)stat & 7)) return PV_ERR_INVALID_ARG;
+    PV_LAUNCH(pv_rowstat_finalize_kernel, dim3(pv_stream_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, partials, stat, (int)tiles, rows,
+              1.0f / (float)D, eps);
+    return pv_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------
 // GELU forward / backward on bf16 streams for the training path (models/blocks.py:82): g = gelu(pre);
 // dpre = dg * (Phi(pre) + pre * phi(pre)), exact erf form.

@@ -143,9 +143,11 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None, x16_out=None, rowstat_out=None, fold=None):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
     ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
+    x16_out / rowstat_out (PV_EPI_BIAS_RES_F32) and fold = (stat [M,2], c1 [N], c2 [N]) (PV_EPI_BIAS_BF16 / _GELU_BF16, bias None): the
+    producer / consumer halves of the folded LayerNorm (include/peekvit_hip.h).
     colsum_out (PV_EPI_GELU_GRAD_BF16): fp32 [N] tensor that receives the column sums of the output (bias gradient) - fused into the
     epilogue when the 256-row tile kernel serves the shape, a separate pv_colsum_f32 pass otherwise.
     ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
@@ -164,7 +166,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     qcols=qcols, qscale=float(qscale), epilogue=epilogue,
                     ln_gamma=ln[0].data_ptr() if ln else 0, ln_beta=ln[1].data_ptr() if ln else 0,
                     ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
-                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit), colsum_partial=0)
+                    ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit), colsum_partial=0,
+                    x16_out=x16_out.data_ptr() if x16_out is not None else 0, rowstat_out=rowstat_out.data_ptr() if rowstat_out is not None else 0,
+                    fold_stat=fold[0].data_ptr() if fold else 0, fold_c1=fold[1].data_ptr() if fold else 0, fold_c2=fold[2].data_ptr() if fold else 0)
     part = None
     if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
         part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)
@@ -174,6 +178,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
     _count()
     if colsum_out is not None:
         colsum(part if part is not None else out, colsum_out)
+    return out
+
+
+def rowstat_finalize(partials: torch.Tensor, D: int, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """partials fp32 [tiles, rows, 2] (sum, sum of squares per column tile) -> fp32 [rows, 2] (mean, rstd) of rows of length D."""
+    _chk(partials, torch.float32, "partials")
+    T, rows, _ = partials.shape
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
+    with _timed("pv_rowstat_finalize", partials.device, 0.0, 8.0 * (T + 1) * rows):
+        check(_lib.load().pv_rowstat_finalize(_ptr(partials), _ptr(out), T, rows, D, float(eps), _stream(partials)), "pv_rowstat_finalize")
+    _count()
     return out
 
 

@@ -287,3 +287,37 @@ def test_residual_gate(ops):
         exp = torch.cat([x[:, :1], m * x[:, 1:-1], x[:, -1:]], dim=1)
         assert torch.equal(xo.cpu(), exp)
         assert torch.equal(rs.cpu(), torch.cat([torch.ones(B, 1), m[..., 0], torch.ones(B, 1)], dim=1))
+
+
+@pytest.mark.parametrize("M,D,N,epi", [(2304, 768, 2304, 0), (4096, 768, 3072, 1), (2050, 384, 1152, 0)])
+def test_layernorm_folded_into_gemms(ops, M, D, N, epi):
+    """LayerNorm folding: the producer GEMM (residual epilogue) also writes the 16-bit copy of its rows + per-tile (sum, sumsq);
+    pv_rowstat_finalize turns them into (mean, rstd); the consumer GEMM on that copy with gamma (.) W finishes
+    rstd * (acc - mean * c1) + c2.  Checked against the same formula in fp64 and against LayerNorm -> Linear."""
+    from peekvit_amd._lib import PV_EPI_BIAS_RES_F32
+    K0 = 256
+    a, w0 = T(f"fa{M}", (M, K0)).to(torch.bfloat16), T(f"fw{D}", (D, K0), "uniform", K0 ** -0.5).to(torch.bfloat16)
+    b0, res = T(f"fb{D}", (D,), "uniform", 0.1), T(f"fr{M}{D}", (M, D), scale=2.0, shift=0.3, bf16=False)
+    x = torch.empty((M, D), dtype=torch.float32, device=DEV)
+    x16 = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    part = torch.full(((D + 255) // 256, M, 2), float("nan"), device=DEV)
+    ops.gemm(a.to(DEV), w0.to(DEV), b0.to(DEV), x, PV_EPI_BIAS_RES_F32, res=res.to(DEV), x16_out=x16, rowstat_out=part)
+    xr = (a.double() @ w0.double().t() + b0.double() + res.double())
+    assert rel_l2(x.cpu(), xr) < 2e-6 and torch.equal(x16.cpu(), x.cpu().to(torch.bfloat16))
+    stat = ops.rowstat_finalize(part, D, 1e-5).cpu().double()
+    assert rel_l2(stat[:, 0], xr.mean(1)) < 1e-5 and rel_l2(stat[:, 1], (xr.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    # consumer
+    gamma, beta = T(f"fg{D}", (D,), "uniform", 0.3, 1.0, bf16=False), T(f"fbeta{D}", (D,), "uniform", 0.1, bf16=False)
+    w, b = T(f"fw2{N}{D}", (N, D), "uniform", D ** -0.5, bf16=False), T(f"fb2{N}", (N,), "uniform", 0.1, bf16=False)
+    wg = (w * gamma).to(torch.bfloat16)
+    c1, c2 = wg.float().sum(1), (w @ beta + b)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    st_dev = ops.rowstat_finalize(part, D, 1e-5)
+    ops.gemm(x16, wg.to(DEV), None, out, epi, fold=(st_dev, c1.to(DEV).contiguous(), c2.to(DEV).contiguous()))
+    x16d = x16.cpu().double()
+    exact = stat[:, 1:2] * (x16d @ wg.double().t() - stat[:, 0:1] * c1.double()) + c2.double()
+    ln_lin = torch.nn.functional.layer_norm(xr, (D,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    if epi == 1:
+        exact, ln_lin = torch.nn.functional.gelu(exact), torch.nn.functional.gelu(ln_lin)
+    assert rel_l2(out.float().cpu(), exact) < 3e-3            # 16-bit output rounding
+    assert rel_l2(out.float().cpu(), ln_lin) < 8e-3           # + operand rounding of the raw (un-normalised) row copy

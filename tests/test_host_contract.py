@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_gemm_args_struct_matches_header_layout():
     import ctypes as C
     from peekvit_amd._lib import GemmArgs
-    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8      # ABI v2+: fused-LN fields, ln_eps + ksplit (v4) share 8 bytes, colsum_partial
+    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers
     assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
     assert GemmArgs.ln_gamma.offset == 19 * 8 and GemmArgs.ln_eps.offset == 23 * 8
 
