@@ -470,6 +470,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // PAIR (training forward): pass 0 stores bf16 of the raw pre-activation to plane 1 of the [M, 2N] output, pass 1 its GELU to plane 0.
         constexpr bool SPLIT = EPI == PV_EPI_BIAS_GELU_SPLIT_BF16;
         constexpr bool PAIR = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+        // folded LayerNorm (consumer): the lane's 2 x 8 column constants, fetched ONCE (columns en0 + 32u + 0..7, clamped reads)
+        f32x4 fc1[2][2], fc2[2][2];
+        if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int cb = en0 + u * 32; cb = cb + 8 <= p.N ? cb : p.N - 8;
+                fc1[u][0] = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb); fc1[u][1] = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb + 4);
+                fc2[u][0] = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb); fc2[u][1] = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb + 4);
+            }
+        }
 #pragma unroll
         for (int pass = 0; pass < (SPLIT || PAIR ? 2 : 1); ++pass) {
             if (pass == 1) {
@@ -489,14 +499,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 for (int u = 0; u < 2; ++u) {
                     f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
                     if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
-                        // folded LayerNorm: the accumulators hold x16 . (gamma (.) W)^T; columns en0 + 32u + 0..7 (clamped reads)
-                        int cb = en0 + u * 32; cb = cb + 8 <= p.N ? cb : p.N - 8;
-                        const f32x4 c1a = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb), c1b = *reinterpret_cast<const f32x4*>(p.fold_c1 + cb + 4);
-                        const f32x4 c2a = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb), c2b = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb + 4);
+                        // folded LayerNorm: the accumulators hold x16 . (gamma (.) W)^T
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            lo[e] = fmaf(f_rstd, fmaf(-f_mean, c1a[e], lo[e]), c2a[e]);
-                            hi[e] = fmaf(f_rstd, fmaf(-f_mean, c1b[e], hi[e]), c2b[e]);
+                            lo[e] = fmaf(f_rstd, fmaf(-f_mean, fc1[u][0][e], lo[e]), fc2[u][0][e]);
+                            hi[e] = fmaf(f_rstd, fmaf(-f_mean, fc1[u][1][e], hi[e]), fc2[u][1][e]);
                         }
                     }
                     // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)

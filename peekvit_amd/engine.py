@@ -155,6 +155,35 @@ def _ln_key(ln: nn.LayerNorm):
     return (id(ln.weight), ln.weight._version, ln.bias._version, float(ln.eps))
 
 
+# LayerNorm FOLDING (opt-in, PEEKVIT_AMD_FOLD_LN=1): no LayerNorm pass at all - the residual GEMMs also emit the
+# 16-bit copy of their rows + per-tile row statistics, and the in-proj / fc1 GEMMs run on that raw copy with gamma (.) W and correct
+# in their epilogue: rstd * (acc - mean * c1) + c2.  Same math as LayerNorm -> Linear, but the operand that is rounded to 16 bits is
+# the raw row instead of the normalised one: +20 % logits error (5.6e-3 bf16, 6.8e-4 f16), hence opt-in.
+_FOLD_LN = os.environ.get("PEEKVIT_AMD_FOLD_LN", "0") == "1"
+_foldcache: Dict[Tuple[int, int, str], tuple] = {}
+
+
+def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
+    """(W' = operand(gamma (.) W) [N,D], c1 = sum_k W'[n,k], c2 = W beta + b) cached per (weight, LayerNorm, operand type) version."""
+    key = (id(w), id(ln.weight), _lib.OPERAND)
+    ver = (w._version, b._version if b is not None else -1, ln.weight._version, ln.bias._version, w.data_ptr())
+    ent = _foldcache.get(key)
+    if ent is not None and ent[0] == ver:
+        return ent[1]
+    with torch.no_grad():
+        wf = w.detach().float()
+        wg = ops.cast_bf16((wf * ln.weight.detach().float()).contiguous())
+        c1 = wg.float().sum(1).contiguous()
+        c2 = (wf @ ln.bias.detach().float() + (b.detach().float() if b is not None else 0.0)).contiguous()
+    _foldcache[key] = (ver, (wg, c1, c2))
+    return wg, c1, c2
+
+
+def _fold_ok(R: int, D: int, M: int) -> bool:
+    """Folding needs the 256-row tile kernel for all four token GEMMs (include/peekvit_hip.h): enough rows, 128-multiples."""
+    return _FOLD_LN and _PRECISION in ("bf16", "f16") and R >= 2048 and D % 128 == 0 and M % 128 == 0
+
+
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
                   next_ln: Optional[nn.LayerNorm] = None) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
@@ -187,6 +216,35 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     g = workspace.get("g", (R, M), _lib.operand_dtype(), dev)
     x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
     out = torch.empty_like(x)
+
+    if row_scale is None and _fold_ok(R, D, M):
+        # ---- LayerNorm folded into the GEMMs: no LayerNorm launch except for a block whose input has no producer hand-off ----
+        nt = (D + 255) // 256
+        fold_in = getattr(x, "_pv_fold", None)
+        if fold_in is not None and fold_in[2] == _ln_key(blk.ln_1) and fold_in[0].shape == (R, D):
+            wg, c1, c2 = _fold_weights(mha.in_proj_weight, mha.in_proj_bias, blk.ln_1)
+            stat = ops.rowstat_finalize(fold_in[1], D, blk.ln_1.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
+            ops.gemm(fold_in[0], wg, None, qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=float(dh) ** -0.5, fold=(stat, c1, c2))
+        else:
+            h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
+            ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, None)
+            ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=float(dh) ** -0.5)
+        ops.attention(qkv, att, B, S, H, dh)
+        x16 = workspace.get("fold_x16", (R, D), _lib.operand_dtype(), dev)
+        part = workspace.get("fold_part", (nt, R, 2), torch.float32, dev)
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D),
+                 x16_out=x16, rowstat_out=part)
+        wg, c1, c2 = _fold_weights(blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.ln_2)
+        stat = ops.rowstat_finalize(part, D, blk.ln_2.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
+        ops.gemm(x16, wg, None, g, PV_EPI_BIAS_GELU_BF16, M=R, fold=(stat, c1, c2))
+        emit = next_ln is not None and next_ln.normalized_shape == (D,)
+        o16 = workspace.get("fold_o16", (R, D), _lib.operand_dtype(), dev) if emit else None
+        opart = workspace.get("fold_opart", (nt, R, 2), torch.float32, dev) if emit else None
+        ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D),
+                 x16_out=o16, rowstat_out=opart)
+        if emit:
+            out._pv_fold = (o16, opart, _ln_key(next_ln))
+        return out
 
     if handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
         h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue

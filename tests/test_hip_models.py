@@ -249,3 +249,23 @@ def test_forward_leaves_the_module_tree_untouched():
         m(torch.randn(2, 3, cfg["image_size"], cfg["image_size"], device="cuda:0"))
     assert list(m.state_dict().keys()) == keys and [n for n, _ in m.named_parameters()] == names
     assert not any("_pv" in k for k in keys)
+
+
+def test_layernorm_folding_opt_in(monkeypatch):
+    """PEEKVIT_AMD_FOLD_LN=1: same model, LayerNorm folded into the producer / consumer GEMM epilogues (no LayerNorm launch after the
+    first block): logits agree with the default path to the operand-rounding noise, and the fold path really ran."""
+    from peekvit_amd import engine, ops, synth
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_small"]
+    m = VisionTransformer(**cfg)
+    synth.load_synth_weights(m, cfg)
+    m = m.eval().to("cuda:0")
+    x = torch.from_numpy(synth.synth_images(12, cfg["image_size"], seed=0)).to("cuda:0")      # 12 x 197 = 2364 rows >= 2048
+    with torch.no_grad():
+        ref = m(x)
+        monkeypatch.setattr(engine, "_FOLD_LN", True)
+        with ops.KernelTimer() as kt:
+            got = m(x)
+    ks = kt.summary()
+    assert "pv_rowstat_finalize" in ks and ks["pv_layernorm_bf16"]["launches"] == 1          # only block 0's ln_1 is a LayerNorm launch
+    assert rel_l2(got.cpu(), ref.cpu()) < 1.2e-2
