@@ -31,15 +31,41 @@ from peekvit_amd import synth
 GOLD = os.path.join(REPO, "tests", "golden")
 
 
+REF_ROOT = "/root/reference"
+REF_FILES = ("models/blocks.py", "models/vit.py", "models/rankvit.py", "models/residualvit.py", "models/adapters.py")
+
+
+def _is_repo_path(p):
+    try:
+        return os.path.realpath(p or os.getcwd()) == os.path.realpath(REPO)
+    except OSError:
+        return False
+
+
+def reference_sha256():
+    import hashlib
+    return {f: hashlib.sha256(open(os.path.join(REF_ROOT, f), "rb").read()).hexdigest() for f in REF_FILES}
+
+
 def import_reference():
-    ref_root = "/root/reference"
-    if not os.path.isdir(ref_root):
+    """Import the REAL reference's three model classes; refuses to return anything that does not live under /root/reference.
+
+    The build ships its own regular package `peekvit/` (the `_target_` alias boundary) at the repo root; a regular package beats the
+    namespace portion /tmp/oracle_ref/peekvit -> /root/reference on sys.path, so the repo root (and '' when the cwd is the repo) is
+    taken OFF sys.path and every already-imported `peekvit` / `peekvit.*` module is purged before the reference is imported.
+    `peekvit_amd` (synth) is imported above, before this runs, and stays importable from sys.modules.
+    """
+    import inspect
+    if not os.path.isdir(REF_ROOT):
         raise SystemExit("reference checkout not present: golden vectors can only be made in the build container")
     link_dir = "/tmp/oracle_ref"
     os.makedirs(link_dir, exist_ok=True)
     link = os.path.join(link_dir, "peekvit")
     if not os.path.islink(link):
-        os.symlink(ref_root, link)
+        os.symlink(REF_ROOT, link)
+    for name in [n for n in sys.modules if n == "peekvit" or n.startswith("peekvit.")]:
+        del sys.modules[name]
+    sys.path[:] = [p for p in sys.path if not _is_repo_path(p)]
     sys.path.insert(0, link_dir)
     tv = types.ModuleType("torchvision")
     tvm = types.ModuleType("torchvision.models")
@@ -51,7 +77,12 @@ def import_reference():
     from peekvit.models.vit import VisionTransformer
     from peekvit.models.rankvit import RankVisionTransformer
     from peekvit.models.residualvit import ResidualVisionTransformer
-    return VisionTransformer, RankVisionTransformer, ResidualVisionTransformer
+    classes = (VisionTransformer, RankVisionTransformer, ResidualVisionTransformer)
+    for cls in classes:
+        src = os.path.realpath(inspect.getsourcefile(cls))
+        if not src.startswith(REF_ROOT + "/"):
+            raise SystemExit(f"import_reference resolved {cls.__name__} to {src}, not the reference: refusing to write fixtures")
+    return classes
 
 
 def _cls_hooks(model, store):
@@ -108,7 +139,8 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     VT, RVT, ResVT = import_reference()
     torch.set_num_threads(8)
-    meta = {"torch": torch.__version__, "reference": "alessiodevoto/peekvit @ 2024_08_07", "errors": {}}
+    meta = {"torch": torch.__version__, "reference": "alessiodevoto/peekvit @ 2024_08_07", "reference_sha256": reference_sha256(),
+            "errors": {}}
 
     # (1)-(3) plain ViT: micro (full tensors), tiny / small / B16 (logits + CLS rows), train-mode == eval-mode
     print("plain ViT")

@@ -24,6 +24,10 @@ import torch
 from make_golden import GOLD, import_reference
 from peekvit_amd import synth
 
+FULL_GRADS_BIG = ("head.bias", "class_tokens", "conv_proj.bias", "encoder.layers.0.ln_1.weight", "encoder.layers.0.ln_1.bias",
+                  "encoder.layers.0.self_attention.self_attention.in_proj_bias", "encoder.layers.1.mlp.fc2.bias", "encoder.ln.weight",
+                  "encoder.layers.11.mlp.fc1.bias", "encoder.layers.6.self_attention.self_attention.out_proj.bias",
+                  "encoder.layers.3.ln_2.weight")          # ViT-B/16-sized steps: vectors only (head.weight alone would be 3 MB)
 FULL_GRADS = ("head.weight", "head.bias", "class_tokens", "conv_proj.bias", "encoder.layers.0.ln_1.weight", "encoder.layers.0.ln_1.bias",
               "encoder.layers.0.self_attention.self_attention.in_proj_bias", "encoder.layers.1.mlp.fc2.bias", "encoder.ln.weight")
 
@@ -34,9 +38,12 @@ def main():
                      gate_bias=10, add_budget_token="learnable")
     out = {}
     # (tag, config, batch, class, extra kwargs, budget): the last row is RankViT (rankvit.py:55-101) pruning to half the tokens in layer 1
+    # vit_b_16 / rankvit_b_16 ([3,6,9] @ 0.5): BASELINE configs[2] / [3] as a whole fwd+bwd step at ViT-B/16 size (D 768, dh 64, S 197)
     for name, cname, batch, cls, extra, budget in (("vit_micro", "vit_micro", 6, VT, {}, None), ("vit_tiny", "vit_tiny", 3, VT, {}, None),
                                                    ("rankvit_micro", "vit_micro", 6, RVT, {"rankvit_layers": [1]}, 0.5),
-                                                   ("residualvit_micro", "vit_micro", 6, ResVT, res_extra, 0.5)):
+                                                   ("residualvit_micro", "vit_micro", 6, ResVT, res_extra, 0.5),
+                                                   ("vit_b_16", "vit_b_16", 2, VT, {}, None),
+                                                   ("rankvit_b_16", "vit_b_16", 2, RVT, {"rankvit_layers": [3, 6, 9]}, 0.5)):
         cfg = synth.MODEL_CONFIGS[cname]
         torch.manual_seed(0)
         m = cls(**cfg, **extra)
@@ -56,7 +63,7 @@ def main():
         gn = np.array([float(p.grad.norm()) for _, p in m.named_parameters()])
         total = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0))
         for n, p in m.named_parameters():
-            if n in FULL_GRADS:
+            if n in (FULL_GRADS_BIG if cname == "vit_b_16" else FULL_GRADS):
                 out[f"{name}/grad/{n}"] = p.grad.detach().numpy().copy()      # AFTER the clip (scaled by 1/total when total > 1)
         opt.step()
         out[f"{name}/logits"] = logits.detach().numpy()

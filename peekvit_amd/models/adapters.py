@@ -44,10 +44,14 @@ def _rename(sd: Dict[str, torch.Tensor], rules, num_classes: int) -> Dict[str, t
             if re.search(pat, new):
                 new = re.sub(pat, rep, new)
                 break
-        # a classifier trained for another label set is dropped (the reference keeps its own zero-initialised head)
-        if new.startswith("head.") and val.shape[0] != num_classes:
-            continue
         out[new] = val
+    # a classifier trained for another label set is replaced by a zero head of the requested size (reference adapters.py:109-113,
+    # 159-164: `torch.zeros`, to be fine-tuned); a checkpoint without a head raises KeyError as the reference does
+    width = out["head.weight"].shape[1]
+    if out["head.weight"].shape[0] != num_classes:
+        print("Loading weights for a different number of classes. Replacing head with random weights. You should fine-tune the model.")
+        out["head.weight"] = torch.zeros((num_classes, width))
+        out["head.bias"] = torch.zeros(num_classes)
     return out
 
 

@@ -137,26 +137,32 @@ def test_attribute_surface_and_surgery():
     assert any("gate" in n for n in names) and any("budget" in n for n in names) and any("class" in n for n in names)
 
 
-def test_adapters_rename_onto_reference_keys():
+def test_adapters_match_the_reference_adapters():
+    """peekvit_amd.models.adapters against the REAL reference's `adapt_torch_state_dict` / `adapt_timm_state_dict`
+    (models/adapters.py:75-166) run by oracle/make_golden_aux.py on torchvision- / timm-shaped key sets: same old->new key map,
+    same output order and shapes, same zero head when the label set differs (tests/golden/adapters.json)."""
     from peekvit_amd.models.adapters import adapt_timm_state_dict, adapt_torch_state_dict
+    cases = json.load(open(os.path.join(GOLDEN, "adapters.json")))["cases"]
+    assert len(cases) == 6
+    for tag, c in cases.items():
+        fn = adapt_timm_state_dict if tag.startswith("timm") else adapt_torch_state_dict
+        order = [k for k, _ in c["input_shapes"]]
+        sd = {k: torch.full(tuple(shape), float(i + 1)) for i, (k, shape) in enumerate(c["input_shapes"])}
+        out = fn(sd, c["num_classes"])
+        assert list(out.keys()) == c["order"], tag
+        assert {k: list(v.shape) for k, v in out.items()} == c["shapes"], tag
+        got = {}
+        for nk, v in out.items():
+            if float(v.abs().sum()) == 0.0:
+                assert nk in c["zeroed"], (tag, nk)
+            else:
+                got[order[int(v.flatten()[0]) - 1]] = nk
+        assert got == c["map"], tag
+        assert sorted(set(out) - set(got.values())) == c["zeroed"], tag
+    # the adapted keys are exactly the build's (= the reference's) state-dict keys for that architecture
     VT, _, _ = _models()
-    cfg = synth.MODEL_CONFIGS["vit_micro"]
-    ref = VT(**cfg).state_dict()
-    tv = {}
-    for k, v in ref.items():
-        k2 = k.replace("class_tokens", "class_token").replace("head.", "heads.head.")
-        k2 = re.sub(r"encoder\.layers\.(\d+)\.self_attention\.self_attention\.", r"encoder.layers.encoder_layer_\1.self_attention.", k2)
-        k2 = re.sub(r"encoder\.layers\.(\d+)\.mlp\.fc1\.", r"encoder.layers.encoder_layer_\1.mlp.linear_1.", k2)
-        k2 = re.sub(r"encoder\.layers\.(\d+)\.mlp\.fc2\.", r"encoder.layers.encoder_layer_\1.mlp.linear_2.", k2)
-        k2 = re.sub(r"encoder\.layers\.(\d+)\.ln_", r"encoder.layers.encoder_layer_\1.ln_", k2)
-        tv[k2] = v
-    assert set(adapt_torch_state_dict(tv, num_classes=10)) == set(ref)
-    assert "head.weight" not in adapt_torch_state_dict(tv, num_classes=1000)
-    timm = {"cls_token": ref["class_tokens"], "pos_embed": ref["encoder.pos_embedding"], "patch_embed.proj.weight": ref["conv_proj.weight"],
-            "blocks.0.attn.qkv.weight": ref["encoder.layers.0.self_attention.self_attention.in_proj_weight"],
-            "blocks.1.mlp.fc2.bias": ref["encoder.layers.1.mlp.fc2.bias"], "norm.weight": ref["encoder.ln.weight"]}
-    got = adapt_timm_state_dict(timm, num_classes=10)
-    assert set(got) <= set(ref) and len(got) == len(timm)
+    ref_keys = set(VT(image_size=32, patch_size=16, num_layers=12, num_heads=2, hidden_dim=32, mlp_dim=64, num_classes=10).state_dict())
+    assert set(cases["torch_C10"]["order"]) == ref_keys and set(cases["timm_C10"]["order"]) == ref_keys
 
 
 def test_flop_model_matches_baseline_table():
@@ -164,6 +170,35 @@ def test_flop_model_matches_baseline_table():
     assert abs(f("vit_tiny") - 2.800) < 2e-3 and abs(f("vit_small") - 6.171) < 2e-3 and abs(f("vit_b_16") - 35.128) < 2e-3
     seqs = [197] * 3 + [99] * 3 + [50] * 3 + [26] * 3
     assert abs(f("vit_b_16", seq_per_layer=seqs) - 16.508) < 5e-3
+
+
+def test_hook_macs_equal_the_reference_hooks():
+    """peekvit_amd.flops.hook_macs against the REAL reference's two counter hooks (utils/flops_count.py:27-145) fired on the REAL
+    reference's models by oracle/make_golden_aux.py: per-module and total MACs, integer-equal (tests/golden/flops_hooks.json).
+    Covers RankViT's shrinking sequences and ResidualViT's zero-row discounting (81 % / 92 % zero masks at gate_bias 0)."""
+    from peekvit_amd import flops
+    VT, RVT, ResVT = _models()
+    cases = json.load(open(os.path.join(GOLDEN, "flops_hooks.json")))["cases"]
+    assert len(cases) == 8
+    res_extra = dict(gate_temp=1, add_input=False, gate_type="sigmoid", gate_threshold=0.5, add_budget_token="learnable")
+    for tag, c in cases.items():
+        cfg = dict(synth.MODEL_CONFIGS[c["config"]])
+        if c["kind"] == "VisionTransformer":
+            m, scfg, fam = VT(**cfg), cfg, "vit"
+        elif c["kind"] == "RankVisionTransformer":
+            m, scfg, fam = RVT(**cfg, rankvit_layers=[3, 6, 9] if "b_16" in tag else [0, 1]), cfg, "vit"
+        else:
+            extra = dict(res_extra, gate_bias=10 if "gb10" in tag else 0, residual_layers=["attention+mlp"] * cfg["num_layers"])
+            m, scfg, fam = ResVT(**cfg, **extra), dict(cfg, **extra), "residualvit"
+        m.eval()
+        synth.load_synth_weights(m, scfg, fam, seed=0)
+        if c["budget"] is not None:
+            m.set_budget(c["budget"])
+        r = flops.hook_macs(m, torch.from_numpy(synth.synth_images(c["batch"], cfg["image_size"], seed=0)))
+        assert r["per_module_macs"] == c["per_module_macs"], tag
+        assert r["total_macs"] == c["total_macs"], tag
+        if "zero_rows_per_block" in c:
+            assert [int((b.mask == 0).sum()) for b in m.encoder.layers] == c["zero_rows_per_block"], tag
 
 
 def test_flop_accounting_conventions():

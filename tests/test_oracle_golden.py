@@ -113,20 +113,43 @@ def test_meta_has_reference_error_contract():
     assert "class_tokens" in meta["state_dict"]["vit_micro"]
 
 
-@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6)])
+def test_golden_recipe_imports_the_real_reference():
+    """oracle/make_golden.py:import_reference must resolve to /root/reference, never to the build's own `peekvit` alias package
+    (a regular package beats the namespace portion the symlink provides).  Runs in a child process: the import replaces `peekvit`
+    in sys.modules.  Skipped where the reference checkout does not exist (the GPU box)."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference checkout not present")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, inspect, json; sys.dont_write_bytecode = True; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import peekvit.models.vit as alias                      # worst case: the alias is already imported\n"
+            "assert 'peekvit_amd' in inspect.getsourcefile(alias.VisionTransformer)\n"
+            "import make_golden\n"
+            "for c in make_golden.import_reference():\n"
+            "    assert os.path.realpath(inspect.getsourcefile(c)).startswith('/root/reference/'), c\n"
+            "print(json.dumps(make_golden.reference_sha256()))\n") % (repo, os.path.join(repo, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=repo, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == meta["reference_sha256"], "fixtures were made from another reference revision"
+
+
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6), ("vit_b_16", 2), ("rankvit_b_16", 2)])
 def test_training_step_matches_the_reference(golden, name, batch):
     """One step of the reference's loop (train/train.py:112-121: CE loss, backward, clip_grad_norm_ 1.0, Adam 1e-3) on the REAL
     reference model (tests/golden/train_step.npz, oracle/make_golden_train.py) vs the oracle restatement under autograd."""
     g = golden("train_step")
     rank = name.startswith("rankvit")
-    cfg = synth.MODEL_CONFIGS["vit_micro" if rank else name]
+    cfg = synth.MODEL_CONFIGS[name.replace("rankvit", "vit")]
+    rank_layers = ([3, 6, 9] if name.endswith("b_16") else [1]) if rank else None
     names = [str(n) for n in g[f"{name}/names"]]
     sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.synth_state_dict(cfg).items()}
     x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0))
     y = torch.arange(batch) % cfg["num_classes"]
     params = [sd[n] for n in names]
     opt = torch.optim.Adam(params, lr=1e-3)
-    logits = O.vit_forward(x, sd, cfg, "fp32", rankvit_layers=[1] if rank else None, budget=0.5 if rank else 1.0)
+    logits = O.vit_forward(x, sd, cfg, "fp32", rankvit_layers=rank_layers, budget=0.5 if rank else 1.0)
     loss = torch.nn.functional.cross_entropy(logits, y)
     loss.backward()
     assert rel_l2(logits.detach().numpy(), g[f"{name}/logits"]) < 2e-6
