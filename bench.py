@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work: started WITHOUT a launcher and with --gpus N > 1, this process - before it makes any GPU call - starts
+`python -m torch.distributed.run` with N ranks as a child, relays the child's single JSON line and exits with its code.
+
 One process per GPU.  A "step" is ONE forward pass of the hot path (VisionTransformer.forward on the MI355X
 kernels) over one device-resident synthetic batch.  The path shards along the batch: every
 rank runs an independent replica on its own 2048-image batch, no data-path collective ("scaling": "weak");
@@ -19,6 +22,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,9 +53,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=8)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"],
-                    help="operand precision of the MFMA products: bf16 (headline), f16 (IEEE fp16 operands, same speed, meets the 1e-3 "
-                         "logits tolerance) or split bf16x3 (1e-5)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "bf16", "f16", "bf16x3"],
+                    help="operand precision of the MFMA products: auto (default = the package default: IEEE fp16 operands behind the "
+                         "operand-range guard with bf16 fallback for inference - meets the 1e-3 logits tolerance; bf16 operands for "
+                         "training), bf16 (4e-3), f16 (unguarded), bf16x3 (split operands, 1e-5)")
+    ap.add_argument("--streams", type=int, default=0, help="forward on this many batch slices / HIP streams (0 = package default)")
+    ap.add_argument("--bucket-kib", type=int, default=25 << 10, help="gradient all-reduce bucket size (KiB), --train with N > 1")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     return ap.parse_args()
 
@@ -76,12 +84,13 @@ def cpu_baseline(cfg, batch, iters, gpu_model=None, dev=None):
             O.vit_forward(x, sd, cfg, "fp32")
         dt = time.perf_counter() - t0
     out = {"value": round(batch * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{iters} forwards of batch {batch} (fp32, torch CPU, oracle/vit_oracle.py), {dt:.1f} s"}
+           "sample": f"{iters} forwards of batch {batch} (fp32, torch CPU, oracle/vit_oracle.py), {dt:.1f} s, on {torch.get_num_threads()} "
+                     f"threads (this job's CPU share) of a host with {os.cpu_count()} hardware threads"}
     if gpu_model is not None:
         from peekvit_amd import engine
         err = {}
         with torch.no_grad():
-            for mode in ("bf16", "f16"):
+            for mode in ("auto", "bf16", "f16"):
                 with engine.precision(mode):
                     got = gpu_model(x.to(dev)).float().cpu()
                 err[mode] = float(f"{((got - ref).norm() / ref.norm()).item():.3e}")
@@ -89,16 +98,45 @@ def cpu_baseline(cfg, batch, iters, gpu_model=None, dev=None):
     return out
 
 
+def self_launch(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD `python -m torch.distributed.run` (this process has made no GPU
+    call - replacing a process that has initialised the GPU is forbidden on this pool), relay its output, return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PV_BENCH_CHILD="1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    print(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+    return proc.returncode or 1
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     dist = world > 1
+    ndev = torch.cuda.device_count()
     if args.dist_backend == "gloo":
-        local = local % max(torch.cuda.device_count(), 1)       # rehearsal: several ranks may share one GPU
+        local = local % max(ndev, 1)       # rehearsal: several ranks may share one GPU
+    elif ndev < world:
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, found {ndev} (rehearse with --dist-backend gloo)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
@@ -150,18 +188,23 @@ def main():
         from peekvit_amd import dist as pvdist
         y = torch.randint(0, cfg["num_classes"], (args.batch,), generator=gen, device=dev)
         infer = model
-        reducer = pvdist.OverlappedGradReducer(infer.parameters()) if dist else None      # ~25 MB buckets leave during backward
+        n_buckets = 0
+        reducer = pvdist.OverlappedGradReducer(infer.parameters(), bucket_bytes=args.bucket_kib << 10) if dist else None      # ~25 MB buckets leave during backward
 
         def train_step(inp):
+            nonlocal n_buckets
             for p in infer.parameters():
                 p.grad = None
             logits = infer(inp)
             torch.nn.functional.cross_entropy(logits, y).backward()
             if dist:
-                reducer.finish()
+                n_buckets = reducer.finish()
             return logits.detach()
 
         model = train_step
+    if args.streams:
+        engine._STREAMS = args.streams
+    fallbacks0 = engine.fallback_count
     with (torch.enable_grad() if args.train else torch.no_grad()), engine.precision(args.precision):
         for _ in range(args.warmup):
             out = model(x)
@@ -190,6 +233,13 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed, elapsed_instr = float(t[0].item()), float(t[1].item())
 
+    # the 16-bit operand type the timed steps really computed in: training -> bf16; inference in mode auto -> fp16 unless the range
+    # guard sent forwards to the bf16 library
+    fallbacks = engine.fallback_count - fallbacks0
+    if args.precision == "auto":
+        dtype = "bf16" if (args.train or fallbacks or getattr(infer_model, "_pv_f16_unsafe", False)) else "f16"
+    else:
+        dtype = args.precision
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         ks = kt.summary()
@@ -209,7 +259,9 @@ def main():
         # HBM/fabric bytes per launch of this kernel from the committed PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r01_kernel_summary.json
         try:
-            summ = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_summary.json")))["kernels"]
+            prof = next(f for f in ("r02_kernel_summary.json", "r01_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            roof["traffic_source"] = "profiles/" + prof
+            summ = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
             fam = [v for k, v in summ.items() if k.startswith(dom.replace("_bf16", "").replace("pv_", "pv_")) and "hbm_read_MB" in v]
             if dom == "pv_gemm_bf16":
                 fam = [v for k, v in summ.items() if k.startswith("pv_gemm") and "hbm_read_MB" in v]
@@ -217,7 +269,7 @@ def main():
                 n = sum(v["launches"] for v in fam)
                 roof["traffic"] = round(sum((v["hbm_read_MB"] + v["hbm_write_MB"]) * 1e6 * v["launches"] for v in fam) / n)
                 roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted mean over the GEMM variants)"
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
@@ -229,19 +281,28 @@ def main():
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_instrumented": round(elapsed_instr / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
-                       "gflop_per_image": round(flops_img / 1e9, 3)},
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "global_batch": world * args.batch,
+                       "parallelism": (f"dp{world} (batch-sharded, gradient all-reduce over {args.dist_backend})" if args.train and dist
+                                       else f"replicas x{world} (batch-sharded, no collective)"),
+                       "gflop_per_image": round(flops_img / 1e9, 3), "precision_mode": args.precision, "streams": engine._STREAMS,
+                       "operands": {"f16": "IEEE fp16 operands, fp32 accumulate (same MFMA rate as bf16), range-guarded" if args.precision == "auto"
+                                    else "IEEE fp16 operands, fp32 accumulate", "bf16": "bf16 operands, fp32 accumulate",
+                                    "bf16x3": "split bf16 hi+lo operands (3 products), fp32 accumulate"}[dtype],
+                       "range_guard_fallbacks": fallbacks},
             "model_mfma_roofline_frac": round(value / world * flops_img / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roof,
             "kernels": kernels,
         }
+        if args.train and dist:
+            line["grad_allreduce"] = {"buckets_per_step": n_buckets, "launched_during_backward_total": reducer.launched_before_finish,
+                                      "bucket_bytes": reducer.bucket_bytes}
         if not args.no_cpu_baseline and world == 1:
             plain = args.rank_budget is None and not args.train
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters, infer_model if plain else None, dev)
-            if plain and args.precision == "bf16":
-                # the same forward with IEEE fp16 operands (libpeekvit_hip_f16.so): the mode that meets the 1e-3 logits tolerance
-                with torch.no_grad(), engine.precision("f16"):
+            if plain and args.precision == "auto":
+                # the same forward on bf16 operands (the explicit "bf16" mode), for the record
+                with torch.no_grad(), engine.precision("bf16"):
                     for _ in range(2):
                         infer_model(x)
                     torch.cuda.synchronize(dev)
@@ -249,9 +310,17 @@ def main():
                     for _ in range(args.steps):
                         infer_model(x)
                     torch.cuda.synchronize(dev)
-                    dt16 = time.perf_counter() - t2
-                line["f16_mode"] = {"value": round(args.batch * args.steps / dt16, 1), "unit": "images/sec",
-                                    "ms_per_step": round(dt16 / args.steps * 1e3, 3), "dtype": "f16"}
+                    dtb = time.perf_counter() - t2
+                line["bf16_mode"] = {"value": round(args.batch * args.steps / dtb, 1), "unit": "images/sec",
+                                     "ms_per_step": round(dtb / args.steps * 1e3, 3), "dtype": "bf16"}
+            err = line["cpu_baseline"].get("gpu_logits_rel_l2_vs_oracle", {}).get(args.precision)
+            if plain and err is not None:
+                line["logits_rel_l2_vs_oracle"] = err
+                line["logits_tolerance"] = 1e-3
+                if dtype == "f16" and not err <= 1e-3:
+                    # the reported operand type is the one that is supposed to meet BASELINE.json's contract: refuse to report otherwise
+                    print(json.dumps(line), file=sys.stderr, flush=True)
+                    raise SystemExit(f"bench.py: dtype {dtype} logits are {err:.2e} from the CPU oracle, outside the 1e-3 contract: no result line")
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

@@ -44,8 +44,10 @@ int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
  *   models/vit.py:212  `x = self.conv_proj(x)`  (+ reshape/permute 214-220).
  * x: fp32 [B,C,H,W] contiguous NCHW.  cols: bf16 [B*(H/P)*(W/P), C*P*P], K order (c,kh,kw) = the
  * conv weight's own layout, so conv_proj.weight viewed as [D, C*P*P] is the GEMM weight. */
+/* range_flag (ABI v5, optional, device uint32_t): operand-range guard of the fp16-operand build - the kernel ORs 1 into it
+ * when a value it packs is not finite in fp16 (|v| > 65504); the bf16 build never writes it.  See pv_gemm_args.range_flag. */
 int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P,
-                   void* stream);
+                   uint32_t* range_flag, void* stream);
 
 /* The same patch gather straight from the DataLoader's RAW image: x uint8 [B,H,W,3] (NHWC); ToTensor + Normalize of
  *   data/imagenette.py:73 (x/255, then (x - mean[c]) / std[c], fp32, this op order) are applied per element, so `cols` is
@@ -125,6 +127,16 @@ typedef struct pv_gemm_args {
     const float* fold_stat;
     const float* fold_c1;
     const float* fold_c2;
+    /* Operand-range guard (ABI v5, optional): device uint32_t the fp16-operand build ORs 1 into when a 16-bit OUTPUT value of
+     * this launch (PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, x16_out) is not finite in fp16, i.e. |v| > 65504 - where the bf16
+     * build would still be in range.  The caller zeroes it before a forward and reads it afterwards (peekvit_amd.engine mode
+     * "auto": repeat that forward on the bf16 library).  The bf16 build ignores it. */
+    uint32_t* range_flag;
+    /* RankViT row norms fused into the producer (ABI v5, optional; PV_EPI_BIAS_RES_F32, 256-row tile kernel only - ask
+     * pv_gemm_tile_rows): rowsq_out fp32 [ceil(N/256), M] receives, per column tile, the sum of squares of each finished output
+     * row's segment.  models/rankvit.py:63 `torch.norm(input, dim=-1)` of the NEXT block is then sqrt(sum over tiles)
+     * (pv_rank_topk_partials) and the separate pass over the tokens (pv_token_norm) disappears. */
+    float* rowsq_out;
 } pv_gemm_args;
 
 /* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length. */
@@ -232,6 +244,11 @@ int pv_token_norm(const float* x, float* norms, int64_t B, int64_t S, int64_t D,
  * norms fp32 [B,N] -> keep int32 [B,k] in sorted (descending) order; ties: lowest index first
  * (the reference sort is unstable).  N <= 4096. */
 int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_t k, void* stream);
+
+/* The same ranking from the per-column-tile sums of squares a producer GEMM left behind (pv_gemm_args.rowsq_out):
+ * rowsq fp32 [tiles, B*S] over the rows of x[B,S,D] (row 0 of every image = class token, not ranked); norm of token i of image b
+ * = sqrt(sum_t rowsq[t][b*S + 1 + i]).  keep int32 [B,k] as pv_rank_topk (N = S-1 <= 4096). */
+int pv_rank_topk_partials(const float* rowsq, int64_t tiles, int32_t* keep, int64_t B, int64_t S, int64_t k, void* stream);
 
 /* Compaction gather: models/rankvit.py:71,75-77 gather + slice + cat class token.
  * x fp32 [B,S_in,D], keep int32 [B,k] (indices into rows 1..S_in-1, i.e. 0-based among non-CLS tokens)

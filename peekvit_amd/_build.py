@@ -55,5 +55,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(tag: str, defs, force: bool = False) -> str:
+    """An EXPERIMENT build of the same sources: libpeekvit_hip_<tag>.so with extra -D flags (bf16 operands).  scripts/raster_ab.py
+    loads such builds side by side with the shipped library to A/B compile-time knobs (cache policy of the GEMM staging loads) in
+    one process; nothing in the package loads them."""
+    lib = os.path.join(HERE, f"libpeekvit_hip_{tag}.so")
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "peekvit_hip.h")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    objdir = os.path.join(HERE, "build_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *defs, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("qscale", _f32), ("epilogue", _i32),
                 ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32),
                 ("ksplit", _i32), ("colsum_partial", _p),
-                ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p)]
+                ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p), ("range_flag", _p), ("rowsq_out", _p)]
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
@@ -41,7 +41,7 @@ SIGNATURES = {
     "pv_arch": (C.c_char_p, []),
     "pv_error_string": (C.c_char_p, [C.c_int]),
     "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
-    "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p]),
     "pv_im2col_u8_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p]),
     "pv_split3_f32_bf16": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
     "pv_im2col_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
@@ -69,10 +69,12 @@ SIGNATURES = {
     "pv_head_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pv_token_norm": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
     "pv_rank_topk": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "pv_rank_topk_partials": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "pv_gather_tokens": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_residual_gate": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _i64, _i64, _i64, _p]),
 }
 
+ABI_VERSION = 5
 _lock = threading.Lock()
 _libs: dict = {}
 
@@ -114,6 +116,8 @@ def load(operand=None):
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
+        if lib.pv_version() != ABI_VERSION:
+            raise PeekvitHipError(f"{path} has ABI v{lib.pv_version()}, this package binds v{ABI_VERSION}: rebuild (python -m peekvit_amd._build)")
         if lib.pv_operand_type() != (1 if op == "f16" else 0):
             raise PeekvitHipError(f"{path} was built for a different operand type")
         _libs[op] = lib

@@ -244,10 +244,9 @@ template <int DH, int NKT>
 static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int lds = 2 * NKT * 16 * DHP * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
     return pv_check_launch();
@@ -485,10 +484,9 @@ __global__ __launch_bounds__(256) void pv_attn_f32_kernel(const float* __restric
 template <int DH, int NKT>
 static int pv_launch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
     constexpr int lds = 2 * NKT * 16 * (DH + 1) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_f32_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     PV_LAUNCH((pv_attn_f32_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
     return pv_check_launch();
@@ -776,10 +774,9 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
     constexpr int lds = 4 * NKT * 16 * DHP * 2 + 3 * NKT * 16 * 4;
     constexpr int NW = NKT <= 13 ? 8 : 4;
     static_assert(lds <= 160 * 1024, "Q, K, V, dO of one head must fit the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd_kernel<DH, NKT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     PV_LAUNCH((pv_attn_bwd_kernel<DH, NKT, NW>), dim3((unsigned)(B * H)), dim3(NW * 64), lds, stream, qkv, dout, dqkv, dbp, S, H, qscale);
     return pv_check_launch();

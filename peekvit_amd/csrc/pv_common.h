@@ -51,6 +51,28 @@ __device__ __forceinline__ uint32_t pv_pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float pv_unpack_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float pv_unpack_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 #endif
+// ---- operand-range guard (ABI v5) --------------------------------------------------------------------------------------
+// An fp16 operand overflows to +-inf above 65504 where bf16 would not.  The kernels of the fp16 build that turn DATA-DEPENDENT
+// fp32 values into operands (GEMM epilogues that emit q|k|v and the GELU activations, the patch gather of a float image) keep
+// the largest magnitude they pack in a register (one v_max3_f32 per two values) and, if it is not representable, OR 1 into the
+// caller's `range_flag` word: the host then repeats that forward on the bf16 library (peekvit_amd.engine, mode "auto").  The
+// other operand producers are bounded by construction and checked on the host once per parameter version: LayerNorm outputs
+// (|y| <= max|gamma| * sqrt(D) + max|beta|), attention outputs (convex combinations of v rows), weights.  The bf16 build compiles
+// the tracking away and never writes the flag.
+#ifdef PV_OPERAND_F16
+__device__ __forceinline__ void pv_range_track(float& m, float a, float b) { m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+__device__ __forceinline__ void pv_range_commit(float m, uint32_t* flag) {
+    if (flag != nullptr && !(m <= 65504.0f)) atomicOr(flag, 1u);
+}
+#else
+__device__ __forceinline__ void pv_range_track(float&, float, float) {}
+__device__ __forceinline__ void pv_range_commit(float, uint32_t*) {}
+#endif
+__device__ __forceinline__ uint32_t pv_pack_bf16x2_tracked(float lo, float hi, float& m) {
+    pv_range_track(m, lo, hi);
+    return pv_pack_bf16x2(lo, hi);
+}
+
 // split-precision helpers (precision mode "bf16x3"): v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi)
 struct PvHiLo { uint32_t hi, lo; };
 __device__ __forceinline__ PvHiLo pv_split2(float a, float b) {
@@ -189,6 +211,20 @@ __device__ __forceinline__ f32x2 pv_gelu_fast2(f32x2 x) {
     const f32x2 phi = {x[0] < 0.f ? h[0] : 1.0f - h[0], x[1] < 0.f ? h[1] : 1.0f - h[1]};
     return x * phi;
 }
+
+// once-per-DEVICE latch for per-device function attributes (hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the
+// CURRENT device only): `static PvPerDevice latch; if (latch.first_use()) hipFuncSetAttribute(...)`.  The current device is the
+// one the caller's stream belongs to (peekvit_amd.ops refuses to launch otherwise).  A benign race at worst repeats the call.
+struct PvPerDevice {
+    bool seen[64] = {};
+    bool first_use() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (seen[d]) return false;
+        seen[d] = true;
+        return true;
+    }
+};
 
 static inline int pv_check_launch() {
     return hipGetLastError() == hipSuccess ? PV_OK : PV_ERR_LAUNCH;

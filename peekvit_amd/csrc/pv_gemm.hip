@@ -52,6 +52,10 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
+    int gc;                    // column tiles per raster chunk (256^2 kernel): the tile list is chunk-major, so an XCD keeps the
+                               // same gc weight tiles while it streams the activation row panels of its share of the rows
+    uint32_t* range_flag;      // operand-range guard of the fp16 build (pv_common.h), or null
+    float* rowsq_out;          // PV_EPI_BIAS_RES_F32: [tiles_n][M] sum of squares of each output row's segment (RankViT norms), or null
     int k_last;                // TN kernel: K extent of the last split-K slice (the slices need not be equal)
     float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
     // LayerNorm folding (opt-in): the PRODUCER (PV_EPI_BIAS_RES_F32) also emits the 16-bit copy of its
@@ -90,10 +94,20 @@ extern "C" void pv_debug_set_stamp_buffer(void* p) { g_pv_dbg = (unsigned long l
 #define PV_STAMP(i)
 #endif
 
+// AUX = cache-policy bits of the load (0 default, 1 sc0, 2 nt, 16 sc1): a literal, hence a template argument
+template <int AUX = 0>
 __device__ __forceinline__ void pv_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
+// cache policy of the 256^2 kernel's activation (A) and weight (W) staging loads; build-time knobs for the L2 experiments
+// (scripts/bench_gemm.py loads differently built libraries side by side in one process)
+#ifndef PV_GEMM_A_AUX
+#define PV_GEMM_A_AUX 0
+#endif
+#ifndef PV_GEMM_W_AUX
+#define PV_GEMM_W_AUX 0
+#endif
 
 // XCD-aware bijective remap (8 XCDs, blocks b and b+8 share an XCD): every XCD walks a CONTIGUOUS range of the
 // tile list (n fastest), so co-resident blocks of one XCD share A panels and the weight matrix in that XCD's L2.
@@ -105,16 +119,16 @@ __device__ __forceinline__ int pv_xcd_remap(int bid, int nwg) {
 // Per-lane epilogue of the 128^2 kernel.  `acc` already contains the bias (accumulators are INITIALISED with it, in both
 // kernels, so that an output element is rounded identically whichever kernel/tile computes it: batch invariance).
 template <int EPI, bool GUARD = true>
-__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc) {
+__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc, float& vmax) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
     const float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
     if (EPI == PV_EPI_BIAS_BF16) {
         const float s = n < p.qcols ? p.qscale : 1.0f;
-        u32x2 o = {pv_pack_bf16x2(v0 * s, v1 * s), pv_pack_bf16x2(v2 * s, v3 * s)};
+        u32x2 o = {pv_pack_bf16x2_tracked(v0 * s, v1 * s, vmax), pv_pack_bf16x2_tracked(v2 * s, v3 * s, vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_GELU_BF16) {
         const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
-        u32x2 o = {pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
+        u32x2 o = {pv_pack_bf16x2_tracked(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab), vmax), pv_pack_bf16x2_tracked(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab), vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
         const float s = p.row_scale ? p.row_scale[m] : 1.0f;
@@ -246,26 +260,27 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p_in) 
 
     // ---- epilogue: lane holds out[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3] ---------------------------------
     const int em = m0 + wm * 64 + (lane & 15);
+    float vmax = 0.f;          // operand-range guard (fp16 build)
     if (m0 + G1_BM <= p.M && n0 + G1_BN <= p.N) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt]);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], vmax);
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt]);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], vmax);
     }
+    if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) pv_range_commit(vmax, p.range_flag);
 }
 
 template <int EPI>
 static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
-    static bool attr_set = false;
+    static PvPerDevice attr_set;
     const int lds = 2 * 2 * G1_TILE_BYTES;
-    if (!attr_set) {
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm128_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     PV_LAUNCH(pv_gemm128_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(256), lds, stream, p);
     return pv_check_launch();
@@ -325,13 +340,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     char* const lds_piece = smem + wid * 1024;       // + slot + j * 8192
     auto stage_a = [&](int buf, int h, int kt) {
         const char* src = a_blk + kt * (G2_BK * 2);
-        pv_glds16(src + oa[h][0], lds_piece + buf * G2_BUF + h * G2_HALF);
-        pv_glds16(src + oa[h][1], lds_piece + buf * G2_BUF + h * G2_HALF + 8192);
+        pv_glds16<PV_GEMM_A_AUX>(src + oa[h][0], lds_piece + buf * G2_BUF + h * G2_HALF);
+        pv_glds16<PV_GEMM_A_AUX>(src + oa[h][1], lds_piece + buf * G2_BUF + h * G2_HALF + 8192);
     };
     auto stage_b = [&](int buf, int h, int kt) {
         const char* src = w_blk + kt * (G2_BK * 2);
-        pv_glds16(src + ow[h][0], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF);
-        pv_glds16(src + ow[h][1], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF + 8192);
+        pv_glds16<PV_GEMM_W_AUX>(src + ow[h][0], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF);
+        pv_glds16<PV_GEMM_W_AUX>(src + ow[h][1], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF + 8192);
     };
 
     // ---- fragment read addresses: one LDS-address-space base per (buffer, k-step), every read = base + immediate ----
@@ -470,6 +485,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // PAIR (training forward): pass 0 stores bf16 of the raw pre-activation to plane 1 of the [M, 2N] output, pass 1 its GELU to plane 0.
         constexpr bool SPLIT = EPI == PV_EPI_BIAS_GELU_SPLIT_BF16;
         constexpr bool PAIR = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+        float vmax = 0.f;          // operand-range guard (fp16 build): largest magnitude this lane packs
         // folded LayerNorm (consumer): the lane's 2 x 8 column constants, fetched ONCE (columns en0 + 32u + 0..7, clamped reads)
         f32x4 fc1[2][2], fc2[2][2];
         if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
@@ -515,7 +531,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
                         }
-                        pk = (u32x4){pv_pack_bf16x2(lo[0], lo[1]), pv_pack_bf16x2(lo[2], lo[3]), pv_pack_bf16x2(hi[0], hi[1]), pv_pack_bf16x2(hi[2], hi[3])};
+                        pk = (u32x4){pv_pack_bf16x2_tracked(lo[0], lo[1], vmax), pv_pack_bf16x2_tracked(lo[2], lo[3], vmax),
+                                     pv_pack_bf16x2_tracked(hi[0], hi[1], vmax), pv_pack_bf16x2_tracked(hi[2], hi[3], vmax)};
                     } else if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
                         if (pass == 0) {
                             const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
@@ -527,11 +544,12 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                             const PvHiLo s0 = pv_split2(lo[0], lo[1]), s1 = pv_split2(lo[2], lo[3]), s2 = pv_split2(hi[0], hi[1]), s3 = pv_split2(hi[2], hi[3]);
                             pk = pass == 0 ? (u32x4){s0.hi, s1.hi, s2.hi, s3.hi} : (u32x4){s0.lo, s1.lo, s2.lo, s3.lo};
                         } else {
-                            pk = (u32x4){pv_pack_bf16x2(lo[0], lo[1]), pv_pack_bf16x2(lo[2], lo[3]), pv_pack_bf16x2(hi[0], hi[1]), pv_pack_bf16x2(hi[2], hi[3])};
+                            pk = (u32x4){pv_pack_bf16x2_tracked(lo[0], lo[1], vmax), pv_pack_bf16x2_tracked(lo[2], lo[3], vmax),
+                                         pv_pack_bf16x2_tracked(hi[0], hi[1], vmax), pv_pack_bf16x2_tracked(hi[2], hi[3], vmax)};
                         }
                     } else {
-                        pk = (u32x4){pv_pack_bf16x2(lo[0] * qs, lo[1] * qs), pv_pack_bf16x2(lo[2] * qs, lo[3] * qs),
-                                     pv_pack_bf16x2(hi[0] * qs, hi[1] * qs), pv_pack_bf16x2(hi[2] * qs, hi[3] * qs)};
+                        pk = (u32x4){pv_pack_bf16x2_tracked(lo[0] * qs, lo[1] * qs, vmax), pv_pack_bf16x2_tracked(lo[2] * qs, lo[3] * qs, vmax),
+                                     pv_pack_bf16x2_tracked(hi[0] * qs, hi[1] * qs, vmax), pv_pack_bf16x2_tracked(hi[2] * qs, hi[3] * qs, vmax)};
                     }
                     const int c = wc * 8 + u * 4 + g;
                     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
@@ -559,9 +577,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 }
             }
         }
+        if (!SPLIT) pv_range_commit(vmax, p.range_flag);
     } else {
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // PV_EPI_GELU_GRAD_BF16: this lane's 4 columns summed over the rows its wave stores
+        float vmax = 0.f;                           // operand-range guard of the x16_out copy (fp16 build)
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
@@ -628,10 +648,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     } else
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
                 }
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out) {    // (workgroup-uniform) token norms for the next block's ranking
+                    const bool ok = m0 + ps * 128 + row < p.M && col_ok;
+                    float q_ = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
+                    q_ = pv_wave_sum(q_);
+                    if (lane == 0 && m0 + ps * 128 + row < p.M) p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + orow[j]] = q_;
+                }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
                     const bool ok = m0 + ps * 128 + row < p.M && col_ok;
                     if (ok)
-                        *reinterpret_cast<u32x2*>(p.x16_out + orow[j] * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
+                        *reinterpret_cast<u32x2*>(p.x16_out + orow[j] * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
                     float s_ = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
                     float q_ = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
                     s_ = pv_wave_sum(s_); q_ = pv_wave_sum(q_);
@@ -640,6 +666,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 }
             }
         }
+        if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) pv_range_commit(vmax, p.range_flag);
         if (EPI == PV_EPI_GELU_GRAD_BF16 && p.colsum_partial) {      // (workgroup-uniform) combine the 8 waves through LDS: [8][256] floats
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // the last image has been consumed by every wave
@@ -682,10 +709,15 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
         if (slice) p.bias = nullptr;
     }
     const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
-    const int grp = tile / (p.gm * p.tiles_n), rem = tile - grp * (p.gm * p.tiles_n);
+    // chunk-major list: chunk c = column tiles [c*gc, c*gc + cw); inside a chunk groups of gm row panels, n slow inside a group
+    const int nfull = p.tiles_n / p.gc;
+    const int ch = min(tile / (p.gc * p.tiles_m), nfull);
+    const int r = tile - ch * p.gc * p.tiles_m;
+    const int cw = ch < nfull ? p.gc : p.tiles_n - nfull * p.gc;
+    const int grp = r / (p.gm * cw), rem = r - grp * (p.gm * cw);
     const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
-    const int tn = rem / gsz, tm = grp * p.gm + (rem - tn * gsz);
-    pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, tn * G2_BN);
+    const int tnl = rem / gsz, tm = grp * p.gm + (rem - tnl * gsz);
+    pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, (ch * p.gc + tnl) * G2_BN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,12 +932,11 @@ extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
     // K / 128 blocks of rows are dealt to the slices as evenly as whole blocks allow; the last slice takes the remainder
     p.ksplit = ks; p.k_slice = (int)(a->K / (2 * G2_BK) / ks) * (2 * G2_BK); p.k_last = (int)a->K - p.k_slice * (ks - 1);
     p.split_stride = a->M * a->ldo;
-    p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = 1;
+    p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = 1; p.gc = p.tiles_n;
     if ((int64_t)p.tiles_m * p.tiles_n * ks > 0x7fffffff) return PV_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-        attr_set = true;
     }
     PV_LAUNCH(pv_gemm256_tn_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n * ks)), dim3(512), G2_LDS, (hipStream_t)stream, p);
     return pv_check_launch();
@@ -989,11 +1020,10 @@ __global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
 
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
-    static bool attr_set = false;
+    static PvPerDevice attr_set;
     constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
-    if (!attr_set) {
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(512), lds, stream, p);
     return pv_check_launch();
@@ -1001,21 +1031,24 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
 
 template <int EPI>
 static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_rows_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-        attr_set = true;
     }
     PV_LAUNCH(pv_gemm256_rows_kernel<EPI>, dim3((unsigned)p.tiles_m), dim3(512), G2_LDS, stream, p);
     return pv_check_launch();
 }
+
+// tile-raster override for the L2 experiments (scripts/bench_gemm.py): gm / gc <= 0 restore the built-in choice
+static int g_pv_raster_gm = 0, g_pv_raster_gc = 0;
+extern "C" void pv_debug_set_gemm_raster(int gm, int gc) { g_pv_raster_gm = gm; g_pv_raster_gc = gc; }
 
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only);
 extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) { return pv_gemm_dispatch(a, stream, false); }
 extern "C" int pv_gemm_tile_rows(const pv_gemm_args* a) {
     if (!a) return PV_ERR_INVALID_ARG;
     pv_gemm_args q = *a;
-    q.colsum_partial = nullptr; q.x16_out = nullptr; q.rowstat_out = nullptr; q.fold_stat = nullptr;
+    q.colsum_partial = nullptr; q.x16_out = nullptr; q.rowstat_out = nullptr; q.fold_stat = nullptr; q.rowsq_out = nullptr;
     return pv_gemm_dispatch(&q, nullptr, true);
 }
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only) {
@@ -1024,7 +1057,11 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->K || a->ldw < a->K || a->ldo < a->N) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) || ((uintptr_t)a->out & 15) || (a->bias && ((uintptr_t)a->bias & 15))) return PV_ERR_INVALID_ARG;
     if (a->M > 0x7fffffff || a->N > 0x7fffffff || a->K > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    if ((uintptr_t)a->range_flag & 3) return PV_ERR_INVALID_ARG;
     GemmDev p;
+    p.range_flag = a->range_flag;
+    p.rowsq_out = a->rowsq_out;
+    if (a->rowsq_out && (a->epilogue != PV_EPI_BIAS_RES_F32 || ((uintptr_t)a->rowsq_out & 3) || a->ln_out)) return PV_ERR_INVALID_ARG;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.res = a->res; p.row_scale = a->row_scale; p.pos = a->pos;
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
@@ -1070,16 +1107,25 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
                                        (p.M >= 2048 || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
-    if ((a->colsum_partial || a->x16_out || a->fold_stat) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
+    if ((a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
     if (query_only) return big ? G2_BM : G1_BM;
     if ((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 4) return PV_ERR_UNSUPPORTED;
     static const int gm_env = [] { const char* e = getenv("PV_GEMM_GM"); return e ? atoi(e) : 0; }();
-    p.gm = gm_env > 0 ? gm_env : (p.N >= 6 * G2_BN ? 4 : 1);   // measured: +2 % for the wide-N GEMMs, -1 % for N = 768
     const int bm = big ? G2_BM : G1_BM, bn = big ? G2_BN : G1_BN;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
+    // tile raster of the 256^2 kernel, measured per shape at M = 403456 with interleaved rounds and PMC passes
+    // (scripts/raster_ab.py, profiles/r02_raster_ab.json): 12 column tiles (fc1) -> two chunks of 6 columns x groups of 6 row
+    // panels (+1.6 %), 9 column tiles (QKV) -> groups of 8 row panels (+1.8 %) over the r1 choice gm = 4; N = 768: gm = 1.
+    // None of the rasters / cache policies moves the L2-side fetch below ~4x the algorithmic read (4 MiB of L2 per XCD against
+    // 32 co-resident 256-wide tiles), and fetch volume does not order the timings: the package sits at its power cap in all of them.
+    p.gm = p.tiles_n >= 8 ? (p.tiles_n >= 12 ? 6 : 8) : (p.tiles_n >= 6 ? 4 : 1);
+    p.gc = p.tiles_n >= 12 ? 6 : p.tiles_n;
+    if (gm_env > 0) p.gm = gm_env;
+    if (g_pv_raster_gm > 0) p.gm = g_pv_raster_gm;
+    if (g_pv_raster_gc > 0) p.gc = g_pv_raster_gc < p.tiles_n ? g_pv_raster_gc : p.tiles_n;
     if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     if (a->ln_out) {
-        p.gm = 1;
+        p.gm = 1; p.gc = p.tiles_n;
         p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = p.N / G2_BN;
         return pv_launch_gemm256_rows<PV_EPI_BIAS_RES_F32>(p, s);
     }

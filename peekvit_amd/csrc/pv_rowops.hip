@@ -61,8 +61,9 @@ extern "C" int pv_split3_f32_bf16(const float* src, uint16_t* dst, int64_t rows,
 // ------------------------------------------------------------------------------------------------
 template <bool VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict__ x, uint16_t* __restrict__ cols, int64_t B, int C,
-                                                        int H, int W, int P) {
+                                                        int H, int W, int P, uint32_t* range_flag) {
     const int Hp = H / P, Wp = W / P, Np = Hp * Wp, K = C * P * P;
+    float vmax = 0.f;          // operand-range guard (fp16 build; compiled away otherwise)
     if (VEC) {
         const int K8 = K >> 3;
         const int64_t total = B * (int64_t)Np * K8;
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict_
                 *reinterpret_cast<u32x4*>(o + K) = lo;
                 *reinterpret_cast<u32x4*>(o + 2 * K) = hi;
             } else {
-                u32x4 o = {pv_pack_bf16x2(a.x, a.y), pv_pack_bf16x2(a.z, a.w), pv_pack_bf16x2(d.x, d.y), pv_pack_bf16x2(d.z, d.w)};
+                u32x4 o = {pv_pack_bf16x2_tracked(a.x, a.y, vmax), pv_pack_bf16x2_tracked(a.z, a.w, vmax), pv_pack_bf16x2_tracked(d.x, d.y, vmax),
+                           pv_pack_bf16x2_tracked(d.z, d.w, vmax)};
                 reinterpret_cast<u32x4*>(cols)[idx] = o;
             }
         }
@@ -95,29 +97,34 @@ __global__ __launch_bounds__(256) void pv_im2col_kernel(const float* __restrict_
             int c = k / (P * P), kh = (k / P) % P, kw = k % P;
             int64_t b = m / Np;
             int pi = (int)(m - b * Np), ph = pi / Wp, pw = pi - ph * Wp;
-            cols[idx] = pv_f2bf(x[((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw]);
+            const float v = x[((b * C + c) * H + (int64_t)ph * P + kh) * W + pw * P + kw];
+            pv_range_track(vmax, v, v);
+            cols[idx] = pv_f2bf(v);
         }
     }
+    if (!SPLIT) pv_range_commit(vmax, range_flag);
 }
 
 extern "C" int pv_im2col_split_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream) {
     if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || H % P || W % P) return PV_ERR_INVALID_ARG;
     if (P % 8 || W % 4 || ((uintptr_t)x & 15) || ((uintptr_t)cols & 15)) return PV_ERR_UNSUPPORTED;
     const int64_t work = B * (H / P) * (W / P) * (C * P * P / 8);
-    PV_LAUNCH((pv_im2col_kernel<true, true>), dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+    PV_LAUNCH((pv_im2col_kernel<true, true>), dim3(pv_stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P,
+              (uint32_t*)nullptr);
     return pv_check_launch();
 }
 
-extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, void* stream) {
-    if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0) return PV_ERR_INVALID_ARG;
+extern "C" int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, uint32_t* range_flag,
+                              void* stream) {
+    if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
     if (H % P || W % P) return PV_ERR_INVALID_ARG;
     const bool vec = (P % 8 == 0) && (W % 4 == 0) && !((uintptr_t)x & 15) && !((uintptr_t)cols & 15);
     const int64_t K = C * P * P, work = B * (H / P) * (W / P) * (vec ? K / 8 : K);
     dim3 grid(pv_stream_grid(work, 256));
     if (vec)
-        PV_LAUNCH(pv_im2col_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+        PV_LAUNCH(pv_im2col_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P, range_flag);
     else
-        PV_LAUNCH(pv_im2col_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P);
+        PV_LAUNCH(pv_im2col_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, cols, B, (int)C, (int)H, (int)W, (int)P, range_flag);
     return pv_check_launch();
 }
 
@@ -830,6 +837,39 @@ extern "C" int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_
     if (N > 4096) return PV_ERR_UNSUPPORTED;
     if (k == 0) return PV_OK;
     PV_LAUNCH(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)N * 4, (hipStream_t)stream, norms, keep, (int)N, (int)k);
+    return pv_check_launch();
+}
+
+// the same ranking with the norms assembled from a producer GEMM's per-column-tile sums of squares (no pass over the tokens)
+__global__ __launch_bounds__(256) void pv_rank_topk_partials_kernel(const float* __restrict__ rowsq, int tiles, int64_t rows, int32_t* __restrict__ keep,
+                                                                    int S, int k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+    const int64_t b = blockIdx.x;
+    const int N = S - 1;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        float s = 0.f;
+        for (int t = 0; t < tiles; ++t) s += rowsq[(int64_t)t * rows + b * S + 1 + i];
+        keys[i] = pv_sort_key(sqrtf(s));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const uint32_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) {
+            uint32_t kj = keys[j];
+            rank += (kj > ki) || (kj == ki && j < i);
+        }
+        if (rank < k) keep[b * k + rank] = i;
+    }
+}
+
+extern "C" int pv_rank_topk_partials(const float* rowsq, int64_t tiles, int32_t* keep, int64_t B, int64_t S, int64_t k, void* stream) {
+    if (!rowsq || !keep || B <= 0 || S < 2 || tiles <= 0 || k < 0 || k > S - 1) return PV_ERR_INVALID_ARG;
+    if (S - 1 > 4096 || tiles > 64) return PV_ERR_UNSUPPORTED;
+    if (k == 0) return PV_OK;
+    PV_LAUNCH(pv_rank_topk_partials_kernel, dim3((unsigned)B), dim3(256), (size_t)(S - 1) * 4, (hipStream_t)stream, rowsq, (int)tiles, B * S, keep, (int)S,
+              (int)k);
     return pv_check_launch();
 }
 

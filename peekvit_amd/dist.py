@@ -98,6 +98,8 @@ class OverlappedGradReducer:
         self._size = 0
         self._work = []
         self.buckets_launched = 0
+        self.launched_before_finish = 0      # cumulative: buckets that left from a gradient hook, i.e. while backward was still running
+        self._finishing = False
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _on_grad(self, p: torch.nn.Parameter):
@@ -111,13 +113,20 @@ class OverlappedGradReducer:
         if not self._bucket:
             return
         flat = torch.cat([p.grad.reshape(-1) for p in self._bucket])
+        if flat.is_cuda and td.get_backend() == "gloo":
+            # rehearsal backend (several ranks sharing one GPU, tests): gloo reduces on the host; RCCL ("nccl") reduces in place on
+            # the device over xGMI
+            flat = flat.cpu()
         self._work.append((td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True), flat, self._bucket))
         self._bucket, self._size = [], 0
         self.buckets_launched += 1
+        self.launched_before_finish += 0 if self._finishing else 1
 
     def finish(self) -> int:
         """Flush, wait, average, write back.  Returns the number of buckets of this step."""
+        self._finishing = True
         self._launch()
+        self._finishing = False
         world = td.get_world_size()
         for handle, flat, ps in self._work:
             handle.wait()
@@ -126,7 +135,7 @@ class OverlappedGradReducer:
             off = 0
             for p in ps:
                 n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                p.grad.copy_(flat[off:off + n].view_as(p.grad), non_blocking=False)
                 off += n
         n_buckets, self._work, self.buckets_launched = len(self._work), [], 0
         return n_buckets

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import math
 import os
+import threading
+import warnings
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -25,13 +27,19 @@ from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_
                    PV_EPI_BIAS_RES_F32, PeekvitHipError)
 
 # Operand precision of the MFMA products:
-#   "bf16"   (default) bf16 operands, fp32 accumulate: 4e-3 relative logits error vs the fp32 reference at random init
-#   "f16"    IEEE fp16 operands (libpeekvit_hip_f16.so: same kernels, same MFMA rate, 2^-11 instead of 2^-8 operand rounding),
-#            fp32 accumulate: 5e-4 relative logits error - meets BASELINE's 1e-3 at the speed of "bf16"; operand range 6e-5..65504
+#   "auto"   (default) INFERENCE runs on IEEE fp16 operands (libpeekvit_hip_f16.so: same kernels, same MFMA rate, 2^-11 instead
+#            of 2^-8 operand rounding, fp32 accumulate): 5e-4 relative logits error = inside BASELINE's 1e-3 contract at the
+#            speed of bf16 - behind an operand-range GUARD: fp16 overflows above 65504 where bf16 would not, so every forward
+#            carries a device flag that the kernels producing data-dependent operands raise (include/peekvit_hip.h range_flag),
+#            weights / LayerNorm bounds are checked once per parameter version, and a forward that trips either is REPEATED on
+#            bf16 operands (warning once).  TRAINING (autograd recording) runs on bf16 operands: fp16 gradients would need loss
+#            scaling.
+#   "bf16"   bf16 operands, fp32 accumulate: 4e-3 relative logits error vs the fp32 reference at random init (outside 1e-3)
+#   "f16"    fp16 operands unconditionally (no guard, no fallback): for A/B measurements
 #   "bf16x3" every GEMM operand split v = hi + lo and concatenated along K ([a_hi|a_lo|a_hi] . [w_hi|w_hi|w_lo]^T on the same
 #            MFMA kernel), exact-fp32 attention: meets BASELINE's 1e-3 (measured ~1e-5) at ~3x the GEMM work
-_PRECISION = os.environ.get("PEEKVIT_AMD_PRECISION", "bf16")
-_MODES = ("bf16", "f16", "bf16x3")
+_PRECISION = os.environ.get("PEEKVIT_AMD_PRECISION", "auto")
+_MODES = ("auto", "bf16", "f16", "bf16x3")
 if _PRECISION not in _MODES:
     raise ValueError(f"PEEKVIT_AMD_PRECISION={_PRECISION!r}: expected one of {_MODES}")
 _lib.OPERAND = "f16" if _PRECISION == "f16" else "bf16"
@@ -48,6 +56,136 @@ def precision(mode: str):
         yield
     finally:
         _PRECISION, _lib.OPERAND = old, old_op
+
+
+def inference_operand() -> str:
+    """The 16-bit operand type an INFERENCE forward uses in the current mode ("f16" for auto / f16, else "bf16")."""
+    return "f16" if _PRECISION in ("auto", "f16") else "bf16"
+
+
+class F16RangeError(PeekvitHipError):
+    """A parameter-derived operand bound does not fit fp16 (mode "auto" catches it and repeats the forward on bf16 operands)."""
+
+
+@contextlib.contextmanager
+def on_device(t: torch.Tensor):
+    """Make the tensor's device current for the launches inside (kernel attributes and streams are per device)."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        with torch.cuda.device(t.device):
+            yield
+    else:
+        yield
+
+
+_flags: Dict[torch.device, torch.Tensor] = {}
+_region = threading.local()
+_warned = set()
+fallback_count = 0          # forwards repeated on bf16 operands because the fp16 range guard tripped (tests / bench read it)
+
+
+def range_flag_for(device) -> torch.Tensor:
+    f = _flags.get(device)
+    if f is None:
+        f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def _warn_once(key: str, msg: str):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+# ------------------------------------------------------------------------------------------------
+# Two half-batches on two HIP streams (PEEKVIT_AMD_STREAMS=2): the token GEMMs hold the package at its power cap while the
+# LayerNorm / attention kernels between them are HBM-bound at about half that power; with two independent half-batches in flight
+# the workgroups of one half's HBM-bound kernels fill CUs next to the other half's GEMM tiles.  Images are independent (bit-exact
+# batch invariance, tests/test_hip_models.py), so the logits are the same bits as the single-stream forward.
+# ------------------------------------------------------------------------------------------------
+_STREAMS = int(os.environ.get("PEEKVIT_AMD_STREAMS", "1"))
+_STREAMS_MIN_BATCH = int(os.environ.get("PEEKVIT_AMD_STREAMS_MIN_BATCH", "256"))
+_side_streams: Dict[torch.device, list] = {}
+
+
+def forward_split(x: torch.Tensor, body):
+    """`body(x_part) -> logits_part` on `_STREAMS` batch slices, slice 0 on the current stream, the others on side streams."""
+    n = _STREAMS
+    if n <= 1 or x.shape[0] < max(_STREAMS_MIN_BATCH, n) or torch.cuda.is_current_stream_capturing():
+        return body(x)
+    dev = x.device
+    main = torch.cuda.current_stream(dev)
+    sides = _side_streams.setdefault(dev, [])
+    while len(sides) < n - 1:
+        sides.append(torch.cuda.Stream(device=dev))
+    parts = list(torch.chunk(x, n, dim=0))
+    outs = [None] * len(parts)
+    for i in range(1, len(parts)):
+        sides[i - 1].wait_stream(main)                      # x (and the weights) are ready on the main stream
+    # issue the slices layer-interleaved would need a scheduler; plain sequential issue is enough: the host runs far ahead of the GPU
+    # (a step is ~100 launches of ~1 ms), so both queues hold work almost all the time
+    for i in range(1, len(parts)):
+        with torch.cuda.stream(sides[i - 1]):
+            outs[i] = body(parts[i])
+    outs[0] = body(parts[0])
+    for i in range(1, len(parts)):
+        main.wait_stream(sides[i - 1])
+        outs[i].record_stream(main)
+    return torch.cat(outs, dim=0)
+
+
+def run_guarded(owner: nn.Module, x: torch.Tensor, fn):
+    """Run `fn()` (a sequence of C-ABI launches producing the result for input `x`) under the current precision mode.
+
+    Mode "auto": fp16 operands behind the range guard, repeated on bf16 operands when the guard trips (module docstring above).
+    Nested calls (a block inside a model forward) run inside the outer region.  Reading the flag synchronises the host with the
+    stream once per guarded forward; under stream capture (peekvit_amd.graph) the check is left to the replayer."""
+    global fallback_count
+    with on_device(x):
+        if _PRECISION != "auto" or getattr(_region, "active", False):
+            return fn()
+        _region.active = True
+        try:
+            if not getattr(owner, "_pv_f16_unsafe", False):
+                flag = range_flag_for(x.device)
+                flag.zero_()
+                ops.range_flag = flag
+                out = None
+                try:
+                    with precision("f16"):
+                        out = fn()
+                except F16RangeError as e:
+                    object.__setattr__(owner, "_pv_f16_unsafe", True)
+                    _warn_once(f"param:{id(owner)}", f"peekvit_amd: {e}; this module runs on bf16 operands from now on "
+                                                     "(logits then carry ~4e-3 relative operand-rounding error)")
+                finally:
+                    ops.range_flag = None
+                if out is not None:
+                    if torch.cuda.is_current_stream_capturing() or int(flag.item()) == 0:
+                        return out
+                    _warn_once("data", "peekvit_amd: an activation left the fp16 operand range (|v| > 65504); this forward was "
+                                       "repeated on bf16 operands (~4e-3 relative operand-rounding error instead of ~5e-4)")
+                fallback_count += 1
+            with precision("bf16"):
+                return fn()
+        finally:
+            _region.active = False
+
+
+_lnok: Dict[int, tuple] = {}
+
+
+def _check_ln_range(ln: nn.LayerNorm):
+    """fp16 operands only: |LayerNorm(x)| <= max|gamma| * sqrt(D) + max|beta| must fit fp16 (checked once per parameter version)."""
+    if _lib.OPERAND != "f16":
+        return
+    key, ver = id(ln), (ln.weight._version, ln.bias._version, ln.weight.data_ptr())
+    ent = _lnok.get(key)
+    if ent is None or ent[0] != ver:
+        D = ln.normalized_shape[0]
+        bound = float(ln.weight.detach().abs().max()) * math.sqrt(D) + float(ln.bias.detach().abs().max())
+        ent = _lnok[key] = (ver, bound)
+    if not ent[1] <= 65504.0:
+        raise F16RangeError(f"a LayerNorm output bound ({ent[1]:.3g}) exceeds the fp16 range")
 
 
 def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> str:
@@ -68,15 +206,19 @@ def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> s
 # workspace arena: named scratch buffers per device, grown on demand, reused across blocks/calls
 # ------------------------------------------------------------------------------------------------
 class _Workspace:
+    """Scratch buffers keyed by (name, device, STREAM): two streams (or threads on their own streams) never share scratch, and a
+    buffer is only ever touched by launches on the stream it was created for.  `use_workspace` swaps the arena the engine draws
+    from, so a captured hipGraph owns the buffers its nodes point at (peekvit_amd.graph)."""
+
     def __init__(self):
-        self._bufs: Dict[Tuple[str, torch.device], torch.Tensor] = {}
+        self._bufs: Dict[Tuple[str, torch.device, int], torch.Tensor] = {}
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
         n = 1
         for s in shape:
             n *= int(s)
         nbytes = n * torch.empty((), dtype=dtype).element_size()
-        key = (name, device)
+        key = (name, device, torch.cuda.current_stream(device).cuda_stream)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
@@ -89,23 +231,47 @@ class _Workspace:
 
 workspace = _Workspace()
 
+
+@contextlib.contextmanager
+def use_workspace(ws: "_Workspace"):
+    global workspace
+    old, workspace = workspace, ws
+    try:
+        yield ws
+    finally:
+        workspace = old
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 weight cache: one cast per (parameter storage, version)
 # ------------------------------------------------------------------------------------------------
-_wcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
+_wcache: Dict[tuple, tuple] = {}      # (id(param), operand) -> (weakref, version, data_ptr, cast tensor, (stream, event) | None)
 
 
 def bf16_weight(p: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes."""
+    """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes.  The cast is a launch on the
+    current stream: a hit from ANOTHER stream (forward_split) first waits for the event recorded behind that cast."""
     key = (id(p), _lib.OPERAND)
     ent = _wcache.get(key)
     if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+        if ent[4] is not None:
+            cur = torch.cuda.current_stream(p.device)
+            if ent[4][1].query():
+                _wcache[key] = ent[:4] + (None,)
+            elif cur.cuda_stream != ent[4][0]:
+                cur.wait_event(ent[4][1])
         return ent[3]
     src = p.detach()
     if not src.is_contiguous():
         src = src.contiguous()
     w = ops.cast_bf16(src.view(src.shape[0], -1))
-    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), p._version, p.data_ptr(), w)
+    if _lib.OPERAND == "f16" and not bool(torch.isfinite(w).all()):      # once per parameter version
+        raise F16RangeError("a weight does not fit the fp16 operand range (|w| > 65504 or non-finite)")
+    ev = None
+    if _STREAMS > 1 and not torch.cuda.is_current_stream_capturing():
+        ev = (torch.cuda.current_stream(p.device).cuda_stream, torch.cuda.Event())
+        ev[1].record()
+    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), p._version, p.data_ptr(), w, ev)
     return w
 
 
@@ -160,6 +326,9 @@ def _ln_key(ln: nn.LayerNorm):
 # in their epilogue: rstd * (acc - mean * c1) + c2.  Same math as LayerNorm -> Linear, but the operand that is rounded to 16 bits is
 # the raw row instead of the normalised one: +20 % logits error (5.6e-3 bf16, 6.8e-4 f16), hence opt-in.
 _FOLD_LN = os.environ.get("PEEKVIT_AMD_FOLD_LN", "0") == "1"
+# RankViT: the token norms of a ranked block come out of the previous block's fc2 epilogue (pv_gemm_args.rowsq_out) instead of a
+# separate pass over the tokens; PEEKVIT_AMD_FUSE_RANK_NORM=0 restores the standalone pv_token_norm kernel
+_FUSE_RANK_NORM = os.environ.get("PEEKVIT_AMD_FUSE_RANK_NORM", "1") == "1"
 _foldcache: Dict[Tuple[int, int, str], tuple] = {}
 
 
@@ -185,7 +354,7 @@ def _fold_ok(R: int, D: int, M: int) -> bool:
 
 
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
-                  next_ln: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+                  next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
 
     Launches: [LN1] -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual, fused LN2)
@@ -194,6 +363,8 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     private attribute `x._pv_ln = (h_bf16, key)` and is used only if `key` matches this block's ln_1 (same parameter
     object, versions and eps).  `next_ln`: the LayerNorm the consumer of the output will apply first (encoder hint).
     row_scale [B,S] (ResidualViT fwd_mask) multiplies LN1 out, the attention branch and LN2 out.
+    next_ranks: the consumer of the output is a RankViT block with an active budget (encoder hint): the fc2 epilogue then also leaves the
+    per-column-tile sums of squares of every output row (`out._pv_rowsq`), from which sort_and_drop ranks without a pass over the tokens.
     """
     if _PRECISION == "bf16x3":
         return _block_forward_x3(blk, x, eps, row_scale)
@@ -210,6 +381,8 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     dev = x.device
     R = B * S
 
+    _check_ln_range(blk.ln_1)
+    _check_ln_range(blk.ln_2)
     h2 = workspace.get("h2", (R, D), _lib.operand_dtype(), dev)
     qkv = workspace.get("qkv", (R, 3 * D), _lib.operand_dtype(), dev)
     att = workspace.get("att", (R, D), _lib.operand_dtype(), dev)
@@ -263,11 +436,16 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
     fuse_next = next_ln is not None and _ln_fusable(D, M) and next_ln.normalized_shape == (D,)
     hn = workspace.get("h", (R, D), _lib.operand_dtype(), dev) if fuse_next else None      # "h" is dead once QKV has consumed it
+    rowsq = None
+    if next_ranks and not fuse_next and _FUSE_RANK_NORM and ops.gemm_tile_rows(R, D, M, PV_EPI_BIAS_RES_F32) == 256:
+        rowsq = workspace.get("rowsq", ((D + 255) // 256, R), torch.float32, dev)
     ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-             res=x1.view(R, D),
+             res=x1.view(R, D), rowsq_out=rowsq,
              ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
     if fuse_next:
         out._pv_ln = (hn, _ln_key(next_ln))
+    if rowsq is not None:
+        out._pv_rowsq = (rowsq, out._version)          # valid only while nobody has modified `out` in place
     return out
 
 
@@ -314,6 +492,9 @@ def run_layers(layers: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
             # a PLAIN attribute (nn.Module.__setattr__ would register the neighbour's LayerNorm as a submodule of this block and
             # leak `layers.{i}._pv_next_ln.*` into named_parameters() / state_dict())
             object.__setattr__(layer, "_pv_next_ln", hint)
+            # the consumer ranks its input by token norm first (RankViT block with an active budget)
+            object.__setattr__(layer, "_pv_next_ranks", bool(nxt is not None and getattr(nxt, "_pv_ranks_input", None) is not None
+                                                             and nxt._pv_ranks_input()))
         x = layer(x)
     return x
 
@@ -368,10 +549,16 @@ def pool_and_head(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
 
 def sort_and_drop(x: torch.Tensor, budget: float):
     """RankViT token ranking + compaction (models/rankvit.py:55-77).  Returns (tokens [B,1+k,D], keep int32 [B,k])."""
+    hand = getattr(x, "_pv_rowsq", None)
+    if hand is not None and hand[1] != x._version:
+        hand = None
     if not x.is_contiguous():
-        x = x.contiguous()
-    N = x.shape[1] - 1
+        x, hand = x.contiguous(), None
+    B, S = x.shape[0], x.shape[1]
+    N = S - 1
     k = math.ceil(N * budget)
-    norms = ops.token_norm(x)
-    keep = ops.rank_topk(norms, k)
+    if hand is not None and hand[0].shape[1] == B * S and hand[0].device == x.device:
+        keep = ops.rank_topk_partials(hand[0], B, S, k)          # norms left behind by the producer's fc2 epilogue
+    else:
+        keep = ops.rank_topk(ops.token_norm(x), k)
     return ops.gather_tokens(x, keep), keep

@@ -9,30 +9,40 @@ from __future__ import annotations
 
 import torch
 
+from . import engine
+
 
 class GraphedForward:
     """Capture `model(x)` for one input shape and replay it: `y = GraphedForward(model, example)(x)`.
 
     The model must be in eval mode on a GPU (the HIP path); weights are read through their bf16 cache, so call
     `refresh()` after changing parameters.  Input is copied into a static buffer, the output tensor is static
-    (clone it if it must survive the next call)."""
+    (clone it if it must survive the next call).  The graph owns its scratch: warm-up and capture draw from a private workspace
+    arena, so a later eager forward that grows the shared arena cannot free memory the captured nodes point at.  Precision mode
+    "auto": the capture is the fp16-operand forward incl. the zeroing of the range flag; every replay reads the flag and a
+    forward that tripped it is repeated eagerly (on bf16 operands)."""
 
     def __init__(self, model: torch.nn.Module, example: torch.Tensor, warmup: int = 2):
         assert example.is_cuda and not model.training, "GraphedForward needs an eval-mode model and a GPU tensor"
         self.model = model
         self.static_in = example.clone()
+        self._ws = engine._Workspace()
+        self._flag = engine.range_flag_for(example.device)
         self._capture(warmup)
 
     def _capture(self, warmup: int):
+        # warm-up and capture run on ONE side stream (the workspace is keyed by stream): weights are cast and the private arena is
+        # populated outside the capture, the captured launches then find every buffer in place
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                 # populates the bf16 weight cache and the workspace arena OUTSIDE capture
-                self.model(self.static_in)
-        torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_out = self.model(self.static_in)
+        with engine.on_device(self.static_in), engine.use_workspace(self._ws), torch.no_grad():
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.model(self.static_in)
+            with torch.cuda.graph(self.graph, stream=side):
+                self.static_out = self.model(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
 
     def refresh(self):
         """Re-capture (after a parameter update or `set_budget`)."""
@@ -42,4 +52,6 @@ class GraphedForward:
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         self.static_in.copy_(x)
         self.graph.replay()
+        if engine._PRECISION == "auto" and int(self._flag.item()) != 0:      # the fp16 range guard tripped inside the replay
+            return self.model(self.static_in)
         return self.static_out

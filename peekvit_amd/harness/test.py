@@ -28,7 +28,9 @@ def evaluate(model, loader, device, budgets: Sequence, n_images: int) -> List[di
             model.set_budget(budget)
         correct, dev_ms = 0, 0.0
         start = time.time()
+        n_batches = 0
         for batch, labels in loader:
+            n_batches += 1
             batch, labels = batch.to(device), labels.to(device)
             if device.type == "cuda":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,6 +42,8 @@ def evaluate(model, loader, device, budgets: Sequence, n_images: int) -> List[di
                 dev_ms += e0.elapsed_time(e1)
             correct += int((out.argmax(1) == labels).sum().item())
         elapsed = time.time() - start
+        if n_batches == 0:
+            raise ValueError("evaluate(): the loader yielded no batch")
         fl, sparsity = flops.measured_flops(model, batch)
         results.append({"budget": budget, "accuracy": correct / n_images, "images_per_second": n_images / elapsed,
                         "device_images_per_second": n_images / (dev_ms * 1e-3) if dev_ms else None,

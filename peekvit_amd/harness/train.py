@@ -64,14 +64,20 @@ def main(argv: Sequence[str] = ()) -> dict:
     torch.nn.init.normal_(model.head.weight, std=0.02)        # the reference's zero head gives zero gradients to the trunk at step 0
     optimizer = instantiate(cfg["optimizer"], params=model.parameters())
     history = {"loss": [], "val_accuracy": []}
-    model_args = {k: v for k, v in cfg["model"].items() if k != "_target_"}
-    for epoch in range(tr["num_epochs"]):
+    model_args = dict(cfg["model"])                            # as the reference stores it (train.py: dict(cfg.model), `_target_` included)
+    start_epoch = 0
+    if cfg.get("load_from"):                                   # resume: weights, optimizer state and epoch of the last checkpoint
+        ck = checkpoint.get_checkpoint_path(cfg["load_from"])
+        if ck is not None:
+            _, st = checkpoint.load_state(ck, model=model, optimizer=optimizer)
+            start_epoch = int(st.get("epoch", -1)) + 1
+    for epoch in range(start_epoch, tr["num_epochs"]):
         history["loss"].append(train_epoch(model, loader, optimizer, device, tr.get("clip_grad_norm", 1.0), distributed))
         if (epoch + 1) % tr.get("eval_every", 1) == 0:
             budget = [1.0] if hasattr(model, "set_budget") and not getattr(model, "add_budget_token", False) else [None]
             history["val_accuracy"].append(evaluate(model, val_loader, device, budget, len(dataset.val_dataset))[0]["accuracy"])
         if cfg.get("experiment_dir") and (not distributed or td.get_rank() == 0):
-            history["checkpoint"] = checkpoint.save_state(cfg["experiment_dir"], model, model_args, epoch=epoch)
+            history["checkpoint"] = checkpoint.save_state(cfg["experiment_dir"], model, model_args, optimizer=optimizer, epoch=epoch)
     if not distributed or td.get_rank() == 0:
         print(json.dumps(history))
     if distributed:

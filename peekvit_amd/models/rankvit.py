@@ -33,7 +33,8 @@ class RankViTBlock(ViTBlock):
             out, self.last_keep = train_engine.sort_and_drop_train(input, self.current_budget)    # HIP ranking, scatter backward
             return out
         if engine.backend_for(input, self, self._p_drop) == "hip":
-            out, self.last_keep = engine.sort_and_drop(input, self.current_budget)
+            with engine.on_device(input):
+                out, self.last_keep = engine.sort_and_drop(input, self.current_budget)
             return out
         cls_tok, rest = input[:, :1], input[:, 1:]
         order = torch.argsort(torch.norm(rest, dim=-1), dim=-1, descending=True, stable=True)
@@ -53,6 +54,9 @@ class RankViTBlock(ViTBlock):
 
     def _pv_plain_ln1(self) -> bool:
         return self.current_budget == 1      # with an active budget the tokens are ranked / dropped before ln_1
+
+    def _pv_ranks_input(self) -> bool:
+        return self.current_budget != 1      # engine hint: the producer of this block's input may leave the token norms behind
 
 
 class RankViTEncoder(nn.Module):
@@ -100,11 +104,11 @@ class RankVisionTransformer(_ViTBase):
         self._check_image(x)
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
-            tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True)
-            return train_engine.pool_and_head_train(self, tokens)
+            with engine.on_device(x):
+                tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True)
+                return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            tokens = self.encoder(engine.embed_tokens(self, x), _pos_added=True)
-            return engine.pool_and_head(self, tokens)
+            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x), _pos_added=True)))
         return self._composite_head(self.encoder(self._composite_tokens(x)))
 
     def set_budget(self, budget: float):

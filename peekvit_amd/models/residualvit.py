@@ -126,13 +126,7 @@ class ResidualViTBlock(ResidualModule):
 
     def forward_skip_attention_mlp(self, input: torch.Tensor):
         if self._hip_gated(input):
-            x = input if input.is_contiguous() else input.contiguous()
-            gate, bgate = self.residual_gate.projection, self.budget_token_gate
-            masked = torch.empty_like(x)
-            self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
-                                                     bgate.weight.detach(), bgate.bias.detach(),
-                                                     self.residual_gate.temp, self.residual_gate.sigmoid_bias)
-            return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale)
+            return engine.run_guarded(self, input, lambda: self._hip_gated_block(input))
         special, img, btok = self._split(input)
         budget, threshold = None, None
         if self.budget_token:
@@ -147,6 +141,15 @@ class ResidualViTBlock(ResidualModule):
             y = y + torch.cat([torch.zeros_like(special), img * (1 - self.mask)], dim=1)
         return y
 
+    def _hip_gated_block(self, input: torch.Tensor):
+        x = input if input.is_contiguous() else input.contiguous()
+        gate, bgate = self.residual_gate.projection, self.budget_token_gate
+        masked = torch.empty_like(x)
+        self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
+                                                 bgate.weight.detach(), bgate.bias.detach(),
+                                                 self.residual_gate.temp, self.residual_gate.sigmoid_bias)
+        return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale)
+
     def plain_forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None):
         """Masked pre-LN block: the mask multiplies LN1's output, the attention branch and LN2's output
         (reference models/residualvit.py:249-260)."""
@@ -154,7 +157,7 @@ class ResidualViTBlock(ResidualModule):
             if train_engine.train_eligible(input, self, self._p_drop) and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]):
                 return train_engine.block_forward_train(self, input)
             if engine.backend_for(input, self, self._p_drop) == "hip":
-                return engine.block_forward(self, input, self.ln_1.eps)
+                return engine.run_guarded(self, input, lambda: engine.block_forward(self, input, self.ln_1.eps))
             mask = torch.tensor(1.0, device=input.device)
         elif (mask.dim() == 3 and mask.shape[:2] == input.shape[:2] and train_engine.train_eligible(input, self, self._p_drop)
               and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1])):
@@ -290,8 +293,7 @@ class ResidualVisionTransformer(_ViTBase):
             if self.add_budget_token == 'learnable':
                 assert self.current_budget is not None, 'Budget token not set. Call set_budget() before forward() to evaluate the model on a chosen budget.'
                 btok, budget = self.learnable_budget_token_1.detach().view(-1), float(self.current_budget)
-            tokens = self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True)
-            return engine.pool_and_head(self, tokens)
+            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True)))
         tokens = self._composite_tokens(x)
         if self.add_budget_token:
             tokens = self._add_budget_token(tokens)

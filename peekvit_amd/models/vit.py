@@ -36,6 +36,7 @@ class ViTBlock(nn.Module):
         # engine hint: the LayerNorm the next block applies first (fused into fc2's epilogue); always a plain attribute, never a
         # registered submodule (engine.run_layers)
         object.__setattr__(self, "_pv_next_ln", None)
+        object.__setattr__(self, "_pv_next_ranks", False)
 
     def _pv_plain_ln1(self) -> bool:
         """True when this block applies ln_1 directly to its input (so a producer may pre-compute it)."""
@@ -52,7 +53,8 @@ class ViTBlock(nn.Module):
                 train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]):
             return train_engine.block_forward_train(self, input)          # autograd records: HIP forward + HIP backward
         if engine.backend_for(input, self, self._p_drop) == "hip":
-            return engine.block_forward(self, input, self.ln_1.eps, next_ln=self._pv_next_ln)
+            return engine.run_guarded(self, input, lambda: engine.block_forward(self, input, self.ln_1.eps, next_ln=self._pv_next_ln,
+                                                                              next_ranks=self._pv_next_ranks))
         return self._composite(input)
 
 
@@ -180,11 +182,15 @@ class VisionTransformer(_ViTBase):
         self._check_image(x)
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
-            tokens = train_engine.embed_tokens_train(self, x)      # same kernels, recorded for loss.backward()
-            tokens = self.encoder(tokens, _pos_added=True)
-            return train_engine.pool_and_head_train(self, tokens)
+            with engine.on_device(x):
+                tokens = train_engine.embed_tokens_train(self, x)  # same kernels, recorded for loss.backward()
+                tokens = self.encoder(tokens, _pos_added=True)
+                return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            tokens = engine.embed_tokens(self, x)                  # im2col + GEMM (+bias +pos), cls rows
-            tokens = self.encoder(tokens, _pos_added=True)         # blocks dispatch themselves
-            return engine.pool_and_head(self, tokens)              # LN on CLS rows, sum, fp32 head
+            return engine.run_guarded(self, x, lambda: engine.forward_split(x, self._hip_forward))
         return self._composite_head(self.encoder(self._composite_tokens(x)))
+
+    def _hip_forward(self, x: torch.Tensor):
+        tokens = engine.embed_tokens(self, x)                      # im2col + GEMM (+bias +pos), cls rows
+        tokens = self.encoder(tokens, _pos_added=True)             # blocks dispatch themselves
+        return engine.pool_and_head(self, tokens)                  # LN on CLS rows, sum, fp32 head

@@ -69,7 +69,23 @@ class _timed:
 
 
 def _stream(t: torch.Tensor):
+    """torch's current stream on the tensor's device.  The launch goes to the CURRENT device (kernel attributes such as the > 64 KiB
+    LDS opt-in are per device), so a tensor on another device is refused loudly: the model-level entry points make the input's
+    device current (`engine.on_device`)."""
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.PeekvitHipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                                   "`with torch.cuda.device(tensor.device):`")
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# Operand-range guard (fp16-operand library, include/peekvit_hip.h `range_flag`): while `range_flag` holds a 1-element int32 GPU
+# tensor the data-dependent operand producers (QKV / GELU GEMM epilogues, the fp32 patch gather) OR 1 into it when a value does
+# not fit fp16.  engine.forward_auto zeroes it before and reads it after a forward.
+range_flag: Optional[torch.Tensor] = None
+
+
+def _flag(dev):
+    return C.c_void_p(range_flag.data_ptr()) if range_flag is not None and range_flag.device == dev else C.c_void_p(0)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -105,7 +121,7 @@ def im2col(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
     _chk(x, torch.float32, "x")
     B, Cc, H, W = x.shape
     with _timed("pv_im2col_bf16", x.device, 0.0, 6.0 * x.numel()):
-        check(_lib.load().pv_im2col_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _stream(x)), "pv_im2col_bf16")
+        check(_lib.load().pv_im2col_bf16(_ptr(x), _ptr(out), B, Cc, H, W, patch, _flag(x.device), _stream(x)), "pv_im2col_bf16")
     _count()
     return out
 
@@ -143,7 +159,7 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None, x16_out=None, rowstat_out=None, fold=None):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None, x16_out=None, rowstat_out=None, fold=None, rowsq_out=None):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
     ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
     x16_out / rowstat_out (PV_EPI_BIAS_RES_F32) and fold = (stat [M,2], c1 [N], c2 [N]) (PV_EPI_BIAS_BF16 / _GELU_BF16, bias None): the
@@ -168,7 +184,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     ln_row_scale=ln[4].data_ptr() if ln and ln[4] is not None else 0,
                     ln_out=ln[3].data_ptr() if ln else 0, ln_eps=float(ln[2]) if ln else 0.0, ksplit=int(ksplit), colsum_partial=0,
                     x16_out=x16_out.data_ptr() if x16_out is not None else 0, rowstat_out=rowstat_out.data_ptr() if rowstat_out is not None else 0,
-                    fold_stat=fold[0].data_ptr() if fold else 0, fold_c1=fold[1].data_ptr() if fold else 0, fold_c2=fold[2].data_ptr() if fold else 0)
+                    fold_stat=fold[0].data_ptr() if fold else 0, fold_c1=fold[1].data_ptr() if fold else 0, fold_c2=fold[2].data_ptr() if fold else 0,
+                    range_flag=range_flag.data_ptr() if range_flag is not None and range_flag.device == a.device else 0,
+                    rowsq_out=rowsq_out.data_ptr() if rowsq_out is not None else 0)
     part = None
     if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
         part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)
@@ -418,6 +436,23 @@ def rank_topk(norms: torch.Tensor, k: int) -> torch.Tensor:
     keep = torch.empty((B, k), dtype=torch.int32, device=norms.device)
     with _timed("pv_rank_topk", norms.device, 0.0, 4.0 * (norms.numel() + B * k)):
         check(_lib.load().pv_rank_topk(_ptr(norms), _ptr(keep), B, N, k, _stream(norms)), "pv_rank_topk")
+    _count()
+    return keep
+
+
+def gemm_tile_rows(M: int, N: int, K: int, epilogue: int) -> int:
+    """The M-tile height (256 or 128) pv_gemm_bf16 would choose for this shape (features such as rowsq_out need 256)."""
+    args = GemmArgs(A=16, W=16, out=16, res=16, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, qscale=1.0, epilogue=epilogue)
+    return int(_lib.load().pv_gemm_tile_rows(C.byref(args)))
+
+
+def rank_topk_partials(rowsq: torch.Tensor, B: int, S: int, k: int) -> torch.Tensor:
+    """keep int32 [B,k] from a producer GEMM's per-column-tile row sums of squares (rowsq fp32 [tiles, B*S])."""
+    _chk(rowsq, torch.float32, "rowsq")
+    tiles = rowsq.shape[0]
+    keep = torch.empty((B, k), dtype=torch.int32, device=rowsq.device)
+    with _timed("pv_rank_topk", rowsq.device, 0.0, 4.0 * (rowsq.numel() + B * k)):
+        check(_lib.load().pv_rank_topk_partials(_ptr(rowsq), tiles, _ptr(keep), B, S, k, _stream(rowsq)), "pv_rank_topk_partials")
     _count()
     return keep
 

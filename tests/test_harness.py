@@ -37,3 +37,34 @@ def test_train_steps_and_checkpoint_round_trip(tmp_path):
     assert type(model).__name__ == "VisionTransformer" and model.hidden_dim == 64
     res = htest.main(MICRO + [f"load_from={tmp_path}"])
     assert res[0]["accuracy"] == hist["val_accuracy"][-1]
+
+
+def test_loads_a_checkpoint_shaped_like_the_reference_writes_it(tmp_path):
+    """utils/utils.py:198-215 stores model_args = dict(cfg.model): Hydra's `_target_` and the pretrained-weight keys included,
+    optimizer None (skip_optimizer=True); utils/utils.py:236-238 pops those keys before rebuilding and loads with strict=False."""
+    from peekvit_amd.models.vit import VisionTransformer
+    args = dict(image_size=32, patch_size=8, num_layers=2, num_heads=2, hidden_dim=64, mlp_dim=128, num_classes=10)
+    src = VisionTransformer(**args)
+    torch.nn.init.normal_(src.head.weight, std=0.02)
+    ref_style = {"model_class": "VisionTransformer", "noise_args": None,
+                 "model_args": dict(args, _target_="peekvit.models.vit.VisionTransformer", torch_pretrained_weights="ViT_B_16_Weights.IMAGENET1K_V1",
+                                    timm_pretrained_weights=None, dropout=0.0, attention_dropout=0.0),
+                 "state_dict": src.state_dict(), "optimizer": None, "epoch": 7}
+    os.makedirs(tmp_path / "checkpoints")
+    torch.save(ref_style, tmp_path / "checkpoints" / "epoch_007.pth")
+    model, state = checkpoint.load_state(checkpoint.get_checkpoint_path(str(tmp_path)))
+    assert state["epoch"] == 7 and all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), src.state_dict().values()))
+    # strict=False like the reference: a checkpoint of a plain ViT loads into a model with extra parameters
+    sd = dict(src.state_dict()); sd.pop("head.bias")
+    torch.save(dict(ref_style, state_dict=sd), tmp_path / "checkpoints" / "epoch_008.pth")
+    model2, _ = checkpoint.load_state(checkpoint.get_checkpoint_path(str(tmp_path)))
+    assert torch.equal(model2.head.weight, src.head.weight)
+
+
+def test_training_resumes_with_optimizer_state(tmp_path):
+    base = MICRO + ["training.train_batch_size=8", f"experiment_dir={tmp_path}"]
+    htrain.main(base + ["training.num_epochs=1"])
+    st = torch.load(checkpoint.get_checkpoint_path(str(tmp_path)), weights_only=False)
+    assert st["optimizer"] is not None and st["model_args"]["_target_"].endswith("VisionTransformer")       # stored as the reference stores it
+    hist = htrain.main(base + ["training.num_epochs=3", f"load_from={tmp_path}"])
+    assert len(hist["loss"]) == 2 and checkpoint.get_checkpoint_path(str(tmp_path)).endswith("epoch_002.pth")   # epochs 1 and 2 only

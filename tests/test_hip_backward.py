@@ -291,17 +291,18 @@ def test_rankvit_training_step(monkeypatch):
         assert rel_l2(ph.grad, pr.grad) < 6e-2, (n, rel_l2(ph.grad, pr.grad))
 
 
-@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6)])
+@pytest.mark.parametrize("name,batch", [("vit_micro", 6), ("vit_tiny", 3), ("rankvit_micro", 6), ("vit_b_16", 2), ("rankvit_b_16", 2)])
 def test_training_step_vs_reference_golden(golden, name, batch):
     """The HIP training path against ONE step of the REAL reference model (tests/golden/train_step.npz, made by
-    oracle/make_golden_train.py from /root/reference): loss, every parameter's gradient norm, complete gradients of nine parameters."""
+    oracle/make_golden_train.py from /root/reference): loss, every parameter's gradient norm, complete gradients of nine parameters.
+    vit_b_16 / rankvit_b_16 ([3,6,9] @ 0.5) are BASELINE configs[2] / [3] as a whole `loss.backward()` at D 768, dh 64, S 197."""
     from peekvit_amd import ops, synth
     from peekvit_amd.models.vit import VisionTransformer
     g = golden("train_step")
     if name.startswith("rankvit"):                       # the reference's RankViT (rankvit_layers=[1]) at budget 0.5
         from peekvit_amd.models.rankvit import RankVisionTransformer
-        cfg = synth.MODEL_CONFIGS["vit_micro"]
-        m = RankVisionTransformer(**cfg, rankvit_layers=[1])
+        cfg = synth.MODEL_CONFIGS[name.replace("rankvit", "vit")]
+        m = RankVisionTransformer(**cfg, rankvit_layers=[3, 6, 9] if name.endswith("b_16") else [1])
         m.set_budget(0.5)
     else:
         cfg = synth.MODEL_CONFIGS[name]

@@ -13,17 +13,25 @@ from peekvit_amd import synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+# The DEFAULT path is what these tests run: precision mode "auto" = fp16 operands behind the range guard (engine.py).
 # Tolerances (relative L2).
+# TOL_CONTRACT: BASELINE.json north_star - logits within 1e-3 relative of the reference's fp32 forward, asserted against the golden
+#   vectors captured from the REAL reference (measured 5.4e-4 .. 6.7e-4 with fp16 operands).
 # TOL_BLOCK: ONE block on IDENTICAL inputs, HIP vs the oracle's same-rounding-points mode: only fp32 summation
-#   order / exp ulps differ, re-rounded to bf16 a few times (measured 4e-5..7e-5 over all rows).
-# TOL_E2E: whole-model logits.  bf16 MFMA operands + fp32 accumulate + fp32 residual stream is measured at
-#   4.3e-3 (ViT-B/16) .. 7e-3 (vit_tiny) against the fp32 reference at random init - the same as the CPU
-#   oracle's bf16 mode (4.1e-3 .. 7e-3, SURVEY 7 H1 predicted 3.6e-3..4.8e-3).  Logits depend on the CLS row only,
-#   whose norm is ~15x smaller than patch rows, so bf16 rounding noise decorrelates between two bf16
-#   implementations: HIP-vs-oracle(bf16) is no tighter than HIP-vs-fp32.  BASELINE's 1e-3 needs split-precision
-#   operands.
+#   order / exp ulps differ, re-rounded to 16 bits a few times (measured 4e-5..7e-5 over all rows).
+# TOL_SAME: whole-model logits vs the oracle restatement with the SAME operand rounding points: with fp16 operands the rounding noise
+#   (~6e-4) is of the order of the implementation differences (fp32 accumulation order, exp2 softmax, table GELU).
+# TOL_BF16: the explicit "bf16" mode (4.3e-3 ViT-B/16 .. 7e-3 vit_tiny against the fp32 reference: 8-bit operand mantissas).
+TOL_CONTRACT = 1e-3
 TOL_BLOCK = 3e-4
-TOL_E2E = 1.2e-2
+TOL_SAME = 1.5e-3
+TOL_BF16 = 1.2e-2
+
+
+def _op():
+    """Operand type of the default inference path ("f16" in mode auto): the oracle mode with the same rounding points."""
+    from peekvit_amd import engine
+    return engine.inference_operand()
 
 
 def _model(kind, name, **extra):
@@ -51,9 +59,13 @@ def test_vit_forward_parity(golden, name):
         logits = m(x.to(DEV)).cpu().numpy()
     assert ops.launch_count - n0 >= 4 + 7 * cfg["num_layers"], "the HIP kernels did not run"
     sd = synth.synth_state_dict(cfg)
-    same = O.vit_forward(x, sd, cfg, "bf16").numpy()
-    assert rel_l2(logits, same) < TOL_E2E
-    assert rel_l2(logits, golden(name)["logits"]) < TOL_E2E          # vs the REAL reference's fp32 logits
+    same = O.vit_forward(x, sd, cfg, _op()).numpy()
+    assert rel_l2(logits, same) < TOL_SAME
+    assert rel_l2(logits, golden(name)["logits"]) < TOL_CONTRACT     # vs the REAL reference's fp32 logits: the north_star tolerance
+    from peekvit_amd import engine
+    with torch.no_grad(), engine.precision("bf16"):                  # the explicit bf16-operand mode stays available
+        lb = m(x.to(DEV)).cpu().numpy()
+    assert rel_l2(lb, golden(name)["logits"]) < TOL_BF16 and rel_l2(lb, O.vit_forward(x, sd, cfg, "bf16").numpy()) < TOL_BF16
 
 
 def test_vit_micro_per_block_activations(golden):
@@ -66,7 +78,7 @@ def test_vit_micro_per_block_activations(golden):
     for h in hooks:
         h.remove()
     for i, o in enumerate(outs):
-        assert rel_l2(o.numpy(), g["block_out"][i]) < 6e-3
+        assert rel_l2(o.numpy(), g["block_out"][i]) < TOL_CONTRACT
 
 
 def test_block_level_standalone_and_surgery():
@@ -75,7 +87,7 @@ def test_block_level_standalone_and_surgery():
     x = torch.from_numpy(synth.tensor("blk/x", (2, 17, 128), "normal", seed=3, bf16=False))
     with torch.no_grad():
         y = m.encoder.layers[0](x.to(DEV)).cpu()
-    ref = O.vit_block(x, synth.synth_state_dict(cfg), "encoder.layers.0.", cfg["num_heads"], 1e-5, "bf16")
+    ref = O.vit_block(x, synth.synth_state_dict(cfg), "encoder.layers.0.", cfg["num_heads"], 1e-5, _op())
     assert rel_l2(y.numpy(), ref.numpy()) < TOL_BLOCK
     m.remove_layers([1])
     assert len(m.encoder.layers) == 1
@@ -104,11 +116,17 @@ def test_rankvit_parity(golden, name, layers, b):
     for li in layers:
         _, keep = O.sort_and_drop(ins[li], b)
         assert np.array_equal(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), keep.numpy())
-    assert rel_l2(logits, g[f"{name}_b{b}_logits"]) < 2.5e-2          # e2e indices may legitimately differ after bf16 layers
+    # END-TO-END against the REAL reference: where every layer's kept SET equals the reference's the logits meet the contract
+    # tolerance; a near-tie at the keep boundary that the 16-bit layers before it resolve the other way swaps one survivor and costs more
+    same_sets = all(np.array_equal(np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1),
+                                   np.sort(g[f"{name}_b{b}_keep{li}"], axis=1)) for li in layers)
+    err = rel_l2(logits, g[f"{name}_b{b}_logits"])
+    print(f"rankvit {name} b={b}: keep sets {'equal' if same_sets else 'differ'}, logits rel-L2 {err:.2e}")
+    assert err < (TOL_CONTRACT if same_sets else 2.5e-2), (same_sets, err)
     m.set_budget(1.0)
     with torch.no_grad():
         full = m(x.to(DEV)).cpu().numpy()
-    assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_E2E
+    assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_CONTRACT
 
 
 @pytest.mark.parametrize("tag,name,gb", [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_micro", 0), ("vit_b_16", "vit_b_16", 10)])
@@ -124,11 +142,15 @@ def test_residualvit_parity(golden, tag, name, gb):
             logits = m(x.to(DEV)).cpu().numpy()
         masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
         tr = {}
-        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "bf16", trace=tr).numpy()
-        assert rel_l2(logits, same) < TOL_E2E
+        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, _op(), trace=tr).numpy()
+        assert rel_l2(logits, same) < TOL_SAME
         assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
         assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
-        assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_E2E
+        assert np.abs(masks - g[f"{tag}_b{b}_masks"]).max() < 2e-3            # every block's mask vs the REAL reference's
+        if np.linalg.norm(g[f"{tag}_b{b}_logits"]) > 0:
+            # the contract tolerance holds on the BASELINE-sized model; the 2-layer, 18-token toy has no averaging over tokens / width
+            # behind its soft masks and sits at 1.1e-3 with fp16 operands (measured)
+            assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < (TOL_CONTRACT if name == "vit_b_16" else 2 * TOL_CONTRACT)
 
 
 def test_error_contract_matches_reference():
@@ -183,12 +205,12 @@ def test_every_block_on_identical_inputs(name):
     cfg, m = _model("vit", name)
     sd = synth.synth_state_dict(cfg)
     x = _x(cfg)
-    t = O.embed_tokens(x, sd, cfg, "bf16") + torch.from_numpy(sd["encoder.pos_embedding"])
+    t = O.embed_tokens(x, sd, cfg, _op()) + torch.from_numpy(sd["encoder.pos_embedding"])
     with torch.no_grad():
         from peekvit_amd import engine
         assert rel_l2(engine.embed_tokens(m, x.to(DEV)).cpu().numpy(), t.numpy()) < 1e-6
         for i, blk in enumerate(m.encoder.layers):
-            ref = O.vit_block(t, sd, f"encoder.layers.{i}.", cfg["num_heads"], 1e-5, "bf16")
+            ref = O.vit_block(t, sd, f"encoder.layers.{i}.", cfg["num_heads"], 1e-5, _op())
             got = blk(t.to(DEV)).cpu()
             assert rel_l2(got.numpy(), ref.numpy()) < TOL_BLOCK, i
             t = ref
@@ -269,3 +291,54 @@ def test_layernorm_folding_opt_in(monkeypatch):
     ks = kt.summary()
     assert "pv_rowstat_finalize" in ks and ks["pv_layernorm_bf16"]["launches"] == 1          # only block 0's ln_1 is a LayerNorm launch
     assert rel_l2(got.cpu(), ref.cpu()) < 1.2e-2
+
+
+def test_rank_norms_come_from_the_fc2_epilogue(monkeypatch):
+    """RankViT: the token norms of a ranked block are left behind by the previous block's fc2 epilogue (pv_gemm_args.rowsq_out ->
+    pv_rank_topk_partials): no pv_token_norm pass, the same kept tokens as the standalone norm kernel, bit-identical block outputs."""
+    from peekvit_amd import engine, ops
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    m.set_budget(0.5)
+    x = torch.from_numpy(synth.synth_images(48, cfg["image_size"], seed=0)).to(DEV)      # 48 x 50 rows >= 2048 even before layer 9
+    with torch.no_grad(), ops.KernelTimer() as kt:
+        fused = m(x)
+    torch.cuda.synchronize()
+    ks = kt.summary()
+    assert "pv_token_norm" not in ks and ks["pv_rank_topk"]["launches"] == 3
+    keep_f = [m.encoder.layers[li].last_keep.clone() for li in (3, 6, 9)]
+    monkeypatch.setattr(engine, "_FUSE_RANK_NORM", False)
+    with torch.no_grad(), ops.KernelTimer() as kt:
+        plain = m(x)
+    torch.cuda.synchronize()
+    assert kt.summary()["pv_token_norm"]["launches"] == 3
+    keep_p = [m.encoder.layers[li].last_keep for li in (3, 6, 9)]
+    same = [torch.equal(a, b) for a, b in zip(keep_f, keep_p)]
+    # the two norm computations sum the squares in different orders: only exact near-ties (1 ulp) may rank differently
+    for a, b in zip(keep_f, keep_p):
+        assert (a != b).float().mean().item() < 2e-3
+    if all(same):
+        assert torch.equal(fused, plain)
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 768, 3072), (4000, 384, 1536)])
+def test_gemm_rowsq_out(M, N, K):
+    """pv_gemm_args.rowsq_out: per-column-tile sums of squares of the finished fp32 rows, vs the rows themselves."""
+    from peekvit_amd import ops
+    from peekvit_amd._lib import PV_EPI_BIAS_RES_F32
+    g = torch.Generator(device=DEV).manual_seed(M)
+    a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
+    bias, res = torch.randn(N, generator=g, device=DEV), torch.randn(M, N, generator=g, device=DEV)
+    out, out2 = torch.empty((M, N), device=DEV), torch.empty((M, N), device=DEV)
+    tiles = (N + 255) // 256
+    rowsq = torch.full((tiles, M), float("nan"), device=DEV)
+    assert ops.gemm_tile_rows(M, N, K, PV_EPI_BIAS_RES_F32) == 256
+    ops.gemm(a, w, bias, out, PV_EPI_BIAS_RES_F32, res=res, rowsq_out=rowsq)
+    ops.gemm(a, w, bias, out2, PV_EPI_BIAS_RES_F32, res=res)
+    assert torch.equal(out, out2)                                        # the extra reduction does not touch the output
+    for t in range(tiles):
+        ref = (out[:, t * 256:(t + 1) * 256].double() ** 2).sum(1)
+        assert rel_l2(rowsq[t].double(), ref) < 1e-6
+    keep = ops.rank_topk_partials(rowsq, M // 8, 8, 4)                   # 8-token "images": rank rows 1..7 of each by norm
+    norms = out.double().pow(2).sum(1).sqrt().view(M // 8, 8)[:, 1:]
+    assert torch.equal(keep.long().cpu(), norms.argsort(dim=1, descending=True, stable=True)[:, :4].cpu())

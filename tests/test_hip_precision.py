@@ -137,10 +137,15 @@ def test_rankvit_and_residualvit_f16_within_tolerance(golden):
     with torch.no_grad(), engine.precision("f16"):
         logits = m(x).cpu().numpy()
     g = golden("rankvit")
+    same_sets = True
     for li in (3, 6, 9):
         got = np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1)
-        assert (got == np.sort(g[f"vit_b_16_b0.5_keep{li}"], axis=1)).mean() > 0.97
-    assert rel_l2(logits, g["vit_b_16_b0.5_logits"]) < 3 * TOL_NORTH_STAR       # a swapped near-tie changes which token survives
+        ref = np.sort(g[f"vit_b_16_b0.5_keep{li}"], axis=1)
+        assert (got == ref).mean() > 0.97
+        same_sets = same_sets and np.array_equal(got, ref)
+    err = rel_l2(logits, g["vit_b_16_b0.5_logits"])
+    print(f"rankvit_b_16 f16: keep sets {'equal' if same_sets else 'differ'}, logits rel-L2 {err:.2e}")
+    assert err < (TOL_NORTH_STAR if same_sets else 3 * TOL_NORTH_STAR)       # a swapped near-tie changes which token survives
     extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5)
     cfg, m = _model("res", "vit_b_16", **extra)
     m.set_budget(0.5)
@@ -164,3 +169,112 @@ def test_f16_mode_matches_its_oracle_restatement():
     # with fp16 operands the rounding noise (~6e-4) is no longer far above the implementation differences between the kernels and
     # the restatement (fp32 accumulation order, exp2-based softmax, table GELU): both sit at the same few 1e-4
     assert rel_l2(logits, ref16) < 1.5e-3
+
+
+# ---- mode "auto" (the default): fp16 operands behind the operand-range guard, bf16 fallback ---------------------------------
+def test_default_mode_is_auto_and_meets_the_contract(golden):
+    """The DEFAULT inference path (no precision context): fp16 operands, logits within 1e-3 of the REAL reference on every config."""
+    from peekvit_amd import engine, _lib
+    assert engine._PRECISION == "auto" and engine.inference_operand() == "f16" and _lib.OPERAND == "bf16"     # training / op-level default
+    n0 = engine.fallback_count
+    for name in ("vit_micro", "vit_tiny", "vit_small", "vit_b_16"):
+        cfg, m = _model("vit", name)
+        x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+        with torch.no_grad():
+            auto = m(x)
+            with engine.precision("f16"):
+                f16 = m(x)
+        assert torch.equal(auto, f16)                                   # auto IS the fp16-operand path when the guard stays quiet
+        assert rel_l2(auto.cpu().numpy(), golden(name)["logits"]) < TOL_NORTH_STAR
+    assert engine.fallback_count == n0
+
+
+def test_range_flag_is_raised_by_the_fp16_kernels_only():
+    """include/peekvit_hip.h `range_flag`: QKV / GELU epilogues (256-row and 128-row kernels) and the fp32 patch gather OR 1 into
+    the word when a packed value leaves the fp16 range; the bf16 library never writes it; in-range launches leave it 0."""
+    from peekvit_amd import engine, ops
+    from peekvit_amd._lib import PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for M, N, K in ((300, 256, 128), (4096, 768, 256)):                 # 128-row kernel, 256-row kernel
+        a, w = T(f"ra{M}{K}", (M, K)), T(f"rw{N}{K}", (N, K), "uniform", 1.0 / math.sqrt(K))
+        big_bias = torch.zeros(N); big_bias[N // 2 + 3] = 7.0e4        # one column past 65504
+        for lib in ("f16", "bf16"):
+            with engine.precision(lib):
+                a16, w16 = ops.cast_bf16(a.to(DEV)), ops.cast_bf16(w.to(DEV))
+                out = torch.empty((M, N), dtype=a16.dtype, device=DEV)
+                ops.range_flag = flag
+                try:
+                    for epi in (PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16):
+                        flag.zero_()
+                        ops.gemm(a16, w16, torch.zeros(N, device=DEV), out, epi)
+                        assert int(flag.item()) == 0, (lib, epi, M)
+                        ops.gemm(a16, w16, big_bias.to(DEV), out, epi)
+                        assert int(flag.item()) == (1 if lib == "f16" else 0), (lib, epi, M)
+                        if lib == "bf16":
+                            assert torch.isfinite(out.float()).all()
+                finally:
+                    ops.range_flag = None
+    img = torch.zeros(2, 3, 32, 32)
+    cols = torch.empty((2 * 16, 3 * 64), dtype=torch.float16, device=DEV)
+    with engine.precision("f16"):
+        ops.range_flag = flag
+        try:
+            flag.zero_(); ops.im2col(img.to(DEV), 8, cols); assert int(flag.item()) == 0
+            img[1, 2, 17, 5] = -1.0e5
+            ops.im2col(img.to(DEV), 8, cols); assert int(flag.item()) == 1
+        finally:
+            ops.range_flag = None
+
+
+def test_auto_mode_falls_back_to_bf16_when_an_activation_overflows_fp16():
+    """A model whose fc1 activations exceed 65504 (scaled weights): the guarded forward notices, repeats on bf16 operands, and returns
+    exactly what the explicit bf16 mode returns - finite logits where unguarded fp16 operands give inf / NaN."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_tiny")
+    with torch.no_grad():
+        blk = m.encoder.layers[1]
+        blk.mlp.fc1.bias.add_(1.0e5)                                       # gelu(fc1) ~ 1e5 > 65504 everywhere
+        blk.mlp.fc2.weight.mul_(1.0e-4)                                    # keep the residual stream in a sane range
+    x = torch.from_numpy(synth.synth_images(3, cfg["image_size"], seed=0)).to(DEV)
+    n0 = engine.fallback_count
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="fp16 operand range") if "data" not in engine._warned else _nullcontext():
+            auto = m(x)
+        with engine.precision("bf16"):
+            ref = m(x)
+        with engine.precision("f16"):
+            raw = m(x)
+    assert engine.fallback_count == n0 + 1
+    assert torch.isfinite(auto).all() and torch.equal(auto, ref)
+    assert not torch.isfinite(raw).all()                                   # what the guard protects from
+
+
+def test_auto_mode_checks_parameter_bounds_once():
+    """Weights / LayerNorm bounds outside the fp16 range are found on the host at cast time: the module is pinned to bf16 operands."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_micro")
+    with torch.no_grad():
+        m.encoder.layers[0].mlp.fc2.weight[3, 5] = 1.0e5
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="bf16 operands from now on"):
+        a = m(x)
+    assert getattr(m, "_pv_f16_unsafe", False)
+    with torch.no_grad():
+        b = m(x)
+        with engine.precision("bf16"):
+            c = m(x)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+    cfg, m2 = _model("vit", "vit_micro")
+    with torch.no_grad():
+        m2.encoder.layers[1].ln_2.weight.fill_(1.0e4)                      # 1e4 * sqrt(128) > 65504
+        with pytest.warns(RuntimeWarning, match="LayerNorm output bound"):
+            out = m2(x)
+    assert torch.isfinite(out).all() and getattr(m2, "_pv_f16_unsafe", False)
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -20,16 +20,17 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
-    assert lib.pv_version() == 4 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
+    assert lib.pv_version() == _lib.ABI_VERSION == 5 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
     assert b"launch" in lib.pv_error_string(-3)
     lib16 = _lib.load("f16")                            # the fp16-operand build of the same sources exports the same ABI
-    assert lib16.pv_version() == 4 and lib16.pv_operand_type() == 1
+    assert lib16.pv_version() == 5 and lib16.pv_operand_type() == 1
 
 
 def test_gemm_args_struct_matches_header_layout():
     import ctypes as C
     from peekvit_amd._lib import GemmArgs
-    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers
+    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8 + 2 * 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers, range_flag, rowsq_out
+    assert GemmArgs.range_flag.offset == C.sizeof(GemmArgs) - 16 and GemmArgs.rowsq_out.offset == C.sizeof(GemmArgs) - 8
     assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
     assert GemmArgs.ln_gamma.offset == 19 * 8 and GemmArgs.ln_eps.offset == 23 * 8
 
