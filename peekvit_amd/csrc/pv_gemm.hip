@@ -13,18 +13,20 @@
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-// exact-erf GELU by table: Phi(x) linearly interpolated from 4096 samples on [-8, 8) (pv_gelu_table.h; |error| <= 5e-7, the
-// same class as torch's fp32 F.gelu).  ~7 VALU + one 8-byte gather per value instead of ~20 issue slots for the erfc
-// polynomial (rcp + exp).  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2 kernel), so both
-// kernels round an element identically.
+// exact-erf GELU by table: Phi(x) as a piecewise cubic on 64 intervals of [-8, 8) (pv_gelu_table.h pv_gelu_cub; |error| <= 8.7e-7,
+// relative L2 1.4e-7 vs fp64 - the class of torch's fp32 F.gelu).  9 VALU + ONE 16-byte gather per value; every 16-byte entry is
+// stored 16 times and a lane reads replica (lane & 15), so the ds_read_b128 lane groups (16 lanes each) are bank-conflict free
+// whatever intervals the lanes need (the previous 4096-entry linear table's 8-byte gathers conflicted ~4-way and the LDS, not
+// the VALU, set the epilogue's pace).  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2 kernel),
+// so both kernels round an element identically.  `tab` = table base + this lane's replica (f32x4 elements).
 template <typename TabPtr>
 __device__ __forceinline__ float pv_gelu_lut(float x, TabPtr tab) {
-    float t = fmaf(x, 256.0f, 2048.0f);
-    t = __builtin_amdgcn_fmed3f(t, 0.0f, 4095.9998f);
+    float t = fmaf(x, (float)PV_GELU_CUB_N / 16.0f, (float)PV_GELU_CUB_N / 2.0f);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PV_GELU_CUB_N - 0.001f);
     const int i = (int)t;
-    const float fr = t - (float)i;
-    const pv_f32x2_t e = tab[i];
-    return x * fmaf(fr, e[1], e[0]);
+    const float fr = __builtin_amdgcn_fractf(t);
+    const f32x4 c = tab[i * PV_GELU_CUB_REP];
+    return x * fmaf(fmaf(fmaf(c[3], fr, c[2]), fr, c[1]), fr, c[0]);
 }
 
 // gelu'(x) = Phi(x) + x * phi(x) from its own table on the same grid (pv_gelu_grad_tab): the same 7 VALU + one gather
@@ -127,7 +129,7 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         u32x2 o = {pv_pack_bf16x2_tracked(v0 * s, v1 * s, vmax), pv_pack_bf16x2_tracked(v2 * s, v3 * s, vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_GELU_BF16) {
-        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
         u32x2 o = {pv_pack_bf16x2_tracked(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab), vmax), pv_pack_bf16x2_tracked(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab), vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
@@ -139,14 +141,14 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         const float s = n < p.qcols ? p.qscale : 1.0f;
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0 * s, v1 * s, v2 * s, v3 * s);
     } else if (EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
-        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
         const PvHiLo a = pv_split2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), b = pv_split2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab));
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
         *reinterpret_cast<u32x2*>(o) = (u32x2){a.hi, b.hi};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){a.lo, b.lo};
         *reinterpret_cast<u32x2*>(o + 2 * p.N) = (u32x2){a.hi, b.hi};
     } else if (EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
-        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_tab);
+        const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
         *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
@@ -444,11 +446,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 8 + 6] = rt_; }
 #endif
     if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) {
-        // GELU table (32 KiB) into the LDS above the staging buffers: the OLDEST operations of the kernel, so every later
-        // counted wait covers them and nothing else changes
+        // GELU table (16 KiB replicated cubic; 32 KiB linear table for gelu') into the LDS above the staging buffers: the OLDEST
+        // operations of the kernel, so every later counted wait covers them and nothing else changes
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            pv_glds16(reinterpret_cast<const char*>(EPI == PV_EPI_GELU_GRAD_BF16 ? pv_gelu_grad_tab : pv_gelu_tab) + (i * 512 + tid) * 16,
+        for (int i = 0; i < (EPI == PV_EPI_GELU_GRAD_BF16 ? 4 : 2); ++i)
+            pv_glds16(reinterpret_cast<const char*>(EPI == PV_EPI_GELU_GRAD_BF16 ? pv_gelu_grad_tab : pv_gelu_cub) + (i * 512 + tid) * 16,
                       smem + G2_LDS + (i * 512 + wid * 64) * 16);
     }
     stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
@@ -527,7 +529,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     u32x4 pk;
                     if (PAIR) {
                         if (pass == 1) {
-                            const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+                            const __attribute__((address_space(3))) f32x4* tab = (const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
                         }
@@ -535,7 +537,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                                      pv_pack_bf16x2_tracked(hi[0], hi[1], vmax), pv_pack_bf16x2_tracked(hi[2], hi[3], vmax)};
                     } else if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
                         if (pass == 0) {
-                            const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
+                            const __attribute__((address_space(3))) f32x4* tab = (const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
                             if (SPLIT) { acc[2 * u][mt] = lo; acc[2 * u + 1][mt] = hi; }
@@ -1021,7 +1023,9 @@ __global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
-    constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) ? PV_GELU_TAB_N * 8 : 0);     // + 32 KiB GELU table = all 160 KiB
+    constexpr int lds = G2_LDS + (EPI == PV_EPI_GELU_GRAD_BF16 ? PV_GELU_TAB_N * 8      // + 32 KiB gelu' table = all 160 KiB
+                                  : (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)
+                                        ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);                  // + 16 KiB replicated cubic GELU table
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
