@@ -120,8 +120,27 @@ __device__ __forceinline__ int pv_xcd_remap(int bid, int nwg) {
 
 // Per-lane epilogue of the 128^2 kernel.  `acc` already contains the bias (accumulators are INITIALISED with it, in both
 // kernels, so that an output element is rounded identically whichever kernel/tile computes it: batch invariance).
+// second operand of the 128^2 kernel's epilogue for output element group (m, n .. n+3): the residual / positional row segment or the
+// saved pre-activation (as fp32).  Fetched for ALL 16 groups of a lane before the first store (a store may alias the residual, so
+// the compiler would otherwise serialise load -> wait -> store sixteen times); out-of-range groups read a clamped address.
+template <int EPI>
+__device__ __forceinline__ f32x4 pv_epilogue_fetch(const GemmDev& p, int m, int n) {
+    m = m < p.M ? m : p.M - 1;
+    n = n + 4 <= p.N ? n : p.N - 4;
+    if (EPI == PV_EPI_BIAS_RES_F32) {
+        return *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
+    } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + n);
+        return (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]), pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
+    } else if (EPI == PV_EPI_BIAS_POS_F32) {
+        const int img = m / p.rpi, pi = m - img * p.rpi;
+        return *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + n);
+    }
+    return (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 template <int EPI, bool GUARD = true>
-__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc, float& vmax) {
+__device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n, f32x4 acc, f32x4 r, float row_scale, float& vmax) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
     const float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
     if (EPI == PV_EPI_BIAS_BF16) {
@@ -133,9 +152,8 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         u32x2 o = {pv_pack_bf16x2_tracked(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab), vmax), pv_pack_bf16x2_tracked(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab), vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
-        const float s = p.row_scale ? p.row_scale[m] : 1.0f;
-        float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.ldr + n);
-        float4 o = make_float4(fmaf(s, v0, r.x), fmaf(s, v1, r.y), fmaf(s, v2, r.z), fmaf(s, v3, r.w));
+        const float s = row_scale;
+        float4 o = make_float4(fmaf(s, v0, r[0]), fmaf(s, v1, r[1]), fmaf(s, v2, r[2]), fmaf(s, v3, r[3]));
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_F32) {
         const float s = n < p.qcols ? p.qscale : 1.0f;
@@ -154,23 +172,23 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
     } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
         const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_grad_tab);
-        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + n);
-        const float x0 = pv_unpack_lo(w[0]), x1 = pv_unpack_hi(w[0]);
-        const float x2 = pv_unpack_lo(w[1]), x3 = pv_unpack_hi(w[1]);
+        const float x0 = r[0], x1 = r[1], x2 = r[2], x3 = r[3];
         u32x2 o = {pv_pack_bf16x2(v0 * pv_gelu_grad_lut(x0, tab), v1 * pv_gelu_grad_lut(x1, tab)),
                    pv_pack_bf16x2(v2 * pv_gelu_grad_lut(x2, tab), v3 * pv_gelu_grad_lut(x3, tab))};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else {   // PV_EPI_BIAS_POS_F32
         const int img = m / p.rpi, pi = m - img * p.rpi;
         const int64_t orow = (int64_t)img * p.rpo + p.row_off + pi;
-        float4 r = *reinterpret_cast<const float4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + n);
-        float4 o = make_float4(r.x + v0, r.y + v1, r.z + v2, r.w + v3);
+        float4 o = make_float4(r[0] + v0, r[1] + v1, r[2] + v2, r[3] + v3);
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// 128 x 128 x 64 tile, 4 waves (2 x 2), 64 x 64 per wave = 4 x 4 MFMA 16x16x32 tiles, 2 LDS buffers (64 KiB)
+// 128 x 128 x 64 tile, 4 waves (2 x 2), 64 x 64 per wave = 4 x 4 MFMA 16x16x32 tiles, 2 LDS buffers (64 KiB), 2 workgroups / CU
+// (measured dead end, r2: the same tile with K steps of 32 through a 4-stage LDS-DMA ring, counted vmcnt and ONE raw barrier per
+// step - bit-identical - is 0-10 % SLOWER on every small / short-K shape tried (scripts/gemm128_ab.py, profiles/r02_gemm128_ab.json):
+// a barrier per 16 MFMAs costs more than the deeper prefetch returns when two workgroups per CU already overlap each other)
 // ------------------------------------------------------------------------------------------------
 constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 64;
 constexpr int G1_TILE_BYTES = G1_BM * G1_BK * 2;   // 16 KiB per operand per stage
@@ -263,16 +281,34 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p_in) 
     // ---- epilogue: lane holds out[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3] ---------------------------------
     const int em = m0 + wm * 64 + (lane & 15);
     float vmax = 0.f;          // operand-range guard (fp16 build)
+    f32x4 rr[4][4];
+    float rs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) rs[mt] = p.row_scale[em + mt * 16 < p.M ? em + mt * 16 : p.M - 1];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) rr[mt][nt] = pv_epilogue_fetch<EPI>(p, em + mt * 16, en + nt * 16);
+    }
+    if (EPI == PV_EPI_BIAS_RES_F32 || EPI == PV_EPI_GELU_GRAD_BF16 || EPI == PV_EPI_BIAS_POS_F32) {
+        // every fetch has returned before the first store is issued (keeps the 16 loads in flight together)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(rr[mt][nt]));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(rs[mt]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (m0 + G1_BM <= p.M && n0 + G1_BN <= p.N) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], vmax);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], rr[mt][nt], rs[mt], vmax);
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], vmax);
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], rr[mt][nt], rs[mt], vmax);
     }
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) pv_range_commit(vmax, p.range_flag);
 }
@@ -1107,9 +1143,17 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     const bool n_ok = p.N % 128 == 0 && (int64_t)tn256 * G2_BN * 3 <= (int64_t)p.N * 4;
     // (the 256^2 epilogue applies the q-scale per 8-column chunk, the 128^2 one per 4 columns)
     const int k_eff = p.ksplit > 1 ? p.k_slice : p.K;
+    // "enough rows to fill the chip", measured per shape (scripts/gemm128_ab.py, profiles/r02_gemm128_epilogue_ab.json): the 256^2 tile
+    // wins from ~128 tiles on (vit_tiny at batch 32: 153 tiles 12.9 vs 14.9 us) and loses below (51 tiles: 16.9 vs 9.8 us); with a
+    // quarter of the last column tile empty AND a short K (N = 384, K = 384: out-proj of vit_small) the 128^2 tile wins as well
+    // (96.9 vs 107.7 us), at K = 1536 the two tie.
+    const int64_t tiles256 = (int64_t)((p.M + G2_BM - 1) / G2_BM) * tn256;
+    const bool ragged_short = (int64_t)tn256 * G2_BN * 3 >= (int64_t)p.N * 4 && k_eff <= 512;
+    // an epilogue feature only the 256-row tile kernel has (the caller asked pv_gemm_tile_rows, or insists): take that kernel if the shape allows
+    const bool feat = a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out;
     const bool big = !((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 8) &&
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
-                                       (p.M >= 2048 || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
+                                       ((tiles256 >= 128 && !ragged_short) || feat || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
     if ((a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
     if (query_only) return big ? G2_BM : G1_BM;

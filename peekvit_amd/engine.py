@@ -350,7 +350,10 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
 
 def _fold_ok(R: int, D: int, M: int) -> bool:
     """Folding needs the 256-row tile kernel for all four token GEMMs (include/peekvit_hip.h): enough rows, 128-multiples."""
-    return _FOLD_LN and _PRECISION in ("bf16", "f16") and R >= 2048 and D % 128 == 0 and M % 128 == 0
+    if not (_FOLD_LN and _PRECISION in ("bf16", "f16") and D % 128 == 0 and M % 128 == 0):
+        return False
+    return all(ops.gemm_tile_rows(R, n, k, epi) == 256 for n, k, epi in ((3 * D, D, PV_EPI_BIAS_BF16), (D, D, PV_EPI_BIAS_RES_F32),
+                                                                      (M, D, PV_EPI_BIAS_GELU_BF16), (D, M, PV_EPI_BIAS_RES_F32)))
 
 
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,

@@ -15,8 +15,8 @@ rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --k
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $out/${tag}_pmc_fetch -o run -- python3 bench.py $args > $out/${tag}_pmc_fetch.log 2>&1 || { echo "pmc fetch run failed"; exit 1; }
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $out/${tag}_pmc_write -o run -- python3 bench.py $args > $out/${tag}_pmc_write.log 2>&1 || { echo "pmc write run failed"; exit 1; }
 python3 scripts/summarize_profiles.py $tag > $out/${tag}_kernel_summary.json
-f=$(ls $out/${tag}_prof/*/*kernel_stats.csv 2>/dev/null | head -1)
+f=$(find $out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats.csv
 # keep the merged output small: the raw traces are tens of MB
-rm -rf $out/${tag}_prof/*/*kernel_trace.csv $out/${tag}_pmc_*/*/*kernel_trace.csv $out/${tag}_pmc_*/*/*counter_collection.csv $out/${tag}_prof/*/*.db 2>/dev/null
+find $out/${tag}_prof $out/${tag}_pmc_sq $out/${tag}_pmc_fetch $out/${tag}_pmc_write \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*.db" \) -delete 2>/dev/null
 echo "summary: $out/${tag}_kernel_summary.json"

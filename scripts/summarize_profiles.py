@@ -10,7 +10,7 @@ def short(name):
     return (m.group(1) + (m.group(3) or "")) if m else None
 
 def load(sub, pattern):
-    f = glob.glob(os.path.join(root, f"{tag}_{sub}", "*", pattern))
+    f = glob.glob(os.path.join(root, f"{tag}_{sub}", "**", pattern), recursive=True)
     return list(csv.DictReader(open(f[0]))) if f else []
 
 out = {"note": "FETCH_SIZE is doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact; both KiB -> bytes",

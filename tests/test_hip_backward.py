@@ -315,7 +315,7 @@ def test_training_step_vs_reference_golden(golden, name, batch):
     loss = torch.nn.functional.cross_entropy(m(x), y)
     loss.backward()
     assert ops.launch_count - n0 > 20 * cfg["num_layers"], "the HIP training path did not run"
-    assert abs(loss.item() - float(g[f"{name}/loss"])) < 2e-3
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-3 * float(g[f"{name}/loss"])      # bf16-operand training path
     named = dict(m.named_parameters())
     names = [str(n) for n in g[f"{name}/names"]]
     total_ref = float(g[f"{name}/total_norm"])

@@ -278,11 +278,11 @@ def test_layernorm_folding_opt_in(monkeypatch):
     first block): logits agree with the default path to the operand-rounding noise, and the fold path really ran."""
     from peekvit_amd import engine, ops, synth
     from peekvit_amd.models.vit import VisionTransformer
-    cfg = synth.MODEL_CONFIGS["vit_small"]
+    cfg = synth.MODEL_CONFIGS["vit_b_16"]
     m = VisionTransformer(**cfg)
     synth.load_synth_weights(m, cfg)
     m = m.eval().to("cuda:0")
-    x = torch.from_numpy(synth.synth_images(12, cfg["image_size"], seed=0)).to("cuda:0")      # 12 x 197 = 2364 rows >= 2048
+    x = torch.from_numpy(synth.synth_images(56, cfg["image_size"], seed=0)).to("cuda:0")      # 56 x 197 rows: every token GEMM on 256-row tiles
     with torch.no_grad():
         ref = m(x)
         monkeypatch.setattr(engine, "_FOLD_LN", True)
@@ -299,7 +299,8 @@ def test_rank_norms_come_from_the_fc2_epilogue(monkeypatch):
     from peekvit_amd import engine, ops
     cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
     m.set_budget(0.5)
-    x = torch.from_numpy(synth.synth_images(48, cfg["image_size"], seed=0)).to(DEV)      # 48 x 50 rows >= 2048 even before layer 9
+    # 224 images: even the fc2 before layer 9 (224 x 50 rows x 3 column tiles = 132 tiles) runs on the 256-row tile kernel
+    x = torch.randn(224, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(5)).to(DEV)
     with torch.no_grad(), ops.KernelTimer() as kt:
         fused = m(x)
     torch.cuda.synchronize()
@@ -332,8 +333,7 @@ def test_gemm_rowsq_out(M, N, K):
     out, out2 = torch.empty((M, N), device=DEV), torch.empty((M, N), device=DEV)
     tiles = (N + 255) // 256
     rowsq = torch.full((tiles, M), float("nan"), device=DEV)
-    assert ops.gemm_tile_rows(M, N, K, PV_EPI_BIAS_RES_F32) == 256
-    ops.gemm(a, w, bias, out, PV_EPI_BIAS_RES_F32, res=res, rowsq_out=rowsq)
+    ops.gemm(a, w, bias, out, PV_EPI_BIAS_RES_F32, res=res, rowsq_out=rowsq)          # the feature selects the 256-row tile kernel
     ops.gemm(a, w, bias, out2, PV_EPI_BIAS_RES_F32, res=res)
     assert torch.equal(out, out2)                                        # the extra reduction does not touch the output
     for t in range(tiles):
