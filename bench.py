@@ -171,7 +171,7 @@ def main():
     infer_model = model
     flops_img = synth.fwd_flops_per_image(cfg, seqs) * (3 if args.train else 1)      # backward = dgrad + wgrad = 2x forward
     if args.train:
-        workload = workload.replace("forward", "fwd+bwd (cross-entropy, parameter gradients" + (", RCCL all-reduce)" if world > 1 else ")"))
+        workload = workload.replace("forward", "fwd+bwd (cross-entropy, parameter gradients" + (f", gradient all-reduce over {args.dist_backend})" if world > 1 else ")"))
 
     # random (never zero-filled) device-resident input, bf16-representable like the parity fixtures
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)

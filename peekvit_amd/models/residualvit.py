@@ -294,6 +294,16 @@ class ResidualVisionTransformer(_ViTBase):
                 assert self.current_budget is not None, 'Budget token not set. Call set_budget() before forward() to evaluate the model on a chosen budget.'
                 btok, budget = self.learnable_budget_token_1.detach().view(-1), float(self.current_budget)
             return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True)))
+        if (self.training and train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout))
+                and train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length + (1 if self.add_budget_token else 0))):
+            # training on the MI355X kernels end to end: patch embedding (+ class tokens, + pos_embedding) and its backward are the
+            # ViT's EmbedFn; the budget token row is appended behind it (it carries no positional embedding, residualvit.py:338-345);
+            # the gated blocks dispatch themselves (MaskedBlockFn); final LayerNorm + head on the class rows only
+            with engine.on_device(x):
+                tokens = train_engine.embed_tokens_train(self, x)
+                if self.add_budget_token:
+                    tokens = self._add_budget_token(tokens)
+                return train_engine.pool_and_head_train(self, self.encoder(tokens, _pos_added=True))
         tokens = self._composite_tokens(x)
         if self.add_budget_token:
             tokens = self._add_budget_token(tokens)
