@@ -142,10 +142,13 @@ __device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __rest
     }
 }
 
-// normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros)
+// normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros).  gamma / beta already in registers
+// (the lane's NCH float4 of each): ONE arithmetic for the standalone kernel and the GEMM-fused passes.
 template <int NCH>
-__device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restrict__ gamma, const float* __restrict__ beta, int D,
-                                          int nvec, int lane, float eps) {
+__device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
+    // every operation rounded on its own: which multiply-adds hipcc contracts into FMAs depends on the code this is inlined into, and the
+    // standalone kernel and the GEMM-fused passes must agree to the bit (tests/test_hip_ops.py found a last-bit difference at N = 512)
+#pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
@@ -163,13 +166,32 @@ __device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restri
     for (int j = 0; j < NCH; ++j) {
         int idx = lane + 64 * j;
         if (idx < nvec) {
-            float4 g = reinterpret_cast<const float4*>(gamma)[idx], b = reinterpret_cast<const float4*>(beta)[idx];
+            const float4 g = gm[j], b = bt[j];
             r.v[j].x = (r.v[j].x - mean) * rstd * g.x + b.x;
             r.v[j].y = (r.v[j].y - mean) * rstd * g.y + b.y;
             r.v[j].z = (r.v[j].z - mean) * rstd * g.z + b.z;
             r.v[j].w = (r.v[j].w - mean) * rstd * g.w + b.w;
         }
     }
+}
+
+template <int NCH>
+__device__ __forceinline__ void pv_ln_load_affine(float4 (&gm)[NCH], float4 (&bt)[NCH], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int nvec, int lane) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int idx = lane + 64 * j < nvec ? lane + 64 * j : nvec - 1;
+        gm[j] = reinterpret_cast<const float4*>(gamma)[idx];
+        bt[j] = reinterpret_cast<const float4*>(beta)[idx];
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void pv_ln_row(RowRegs<NCH>& r, const float* __restrict__ gamma, const float* __restrict__ beta, int D,
+                                          int nvec, int lane, float eps) {
+    float4 gm[NCH], bt[NCH];
+    pv_ln_load_affine<NCH>(gm, bt, gamma, beta, nvec, lane);
+    pv_ln_row_regs<NCH>(r, gm, bt, D, nvec, lane, eps);
 }
 
 // hipGetLastError() is per-thread and sticky across ALL users of the runtime (PyTorch leaves benign errors such as

@@ -1079,9 +1079,207 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
     return pv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Full-row tile for NARROW hidden dims: 128 rows x N (N = 256, 384 or 512 = the whole output row), 8 waves as 2 (M) x 4 (N),
+// 64 x N/4 outputs per wave, A 128 x 64 + W N x 64 per K tile in two LDS buffers (96 / 128 / 160 KiB), one workgroup per CU.
+// The residual GEMMs of vit_small / vit_tiny widths (out-proj, fc2: PV_EPI_BIAS_RES_F32) are memory- and epilogue-bound, not
+// MFMA- or power-bound (rocprof, profiles/r02_vit_small_*: MFMA busy 25 %, 2.3 GHz); with the whole row in one workgroup
+//   - N = 384 wastes no quarter-empty 256-wide column tile,
+//   - the LayerNorm that consumes the row next (ln_2 after out-proj, the next block's ln_1 after fc2) runs on the finished fp32
+//     values while they are still in the workgroup's LDS: its launch and its re-read of the residual stream disappear
+//     (models/vit.py:51+53, :55 + the next block's :48).  The per-row arithmetic is pv_ln_row (the standalone kernel's), the
+//     residual add is the 256^2 epilogue's fmaf, K is accumulated in the same order: outputs are bit-identical to
+//     pv_gemm_bf16 followed by pv_layernorm_bf16 (tests/test_hip_ops.py).
+// K loop: 2 buffers, LDS-DMA of tile kt+1 in flight under the MFMAs of tile kt, one barrier per K tile (the 128^2 kernel's
+// structure: these shapes have 6 - 24 K tiles per output tile and the epilogue moves 10 bytes per output element).
+// Epilogue: two passes of 64 rows; the wave group that owns the rows writes bias-initialised accumulators to an fp32 LDS image
+// (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 WHOLE rows: residual row from HBM, fmaf, fp32 row
+// store (N * 4 contiguous bytes), LayerNorm, 16-bit row store.
+// ------------------------------------------------------------------------------------------------
+template <int NT>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave
+__global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
+    constexpr int N = 64 * NT, BM = 128, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2;                  // 16 KiB
+    constexpr int BUF = A_BYTES + N * BK * 2;             // one K-tile buffer
+    constexpr int NCH = (N / 4 + 63) / 64;                // float4 per lane of a whole row (pv_ln_row)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int m0 = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
+    const int g = lane >> 4, i16 = lane & 15;
+
+    // accumulators start from the bias (ordinary loads, consumed before any LDS-DMA is issued)
+    f32x4 acc[NT][4];   // [nt][mt]: out[row wm*64 + mt*16 + i16][col wn*16*NT + nt*16 + 4g + 0..3]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 16 * NT + nt * 16 + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- LDS-DMA sources: 1-KiB pieces of 8 rows x 128 B per wave, swizzled chunk (chunk ^ (row & 7)) on the source side ----
+    const int srow = wid * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const uint16_t* ga[2];
+    const uint16_t* gw[NT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int ra = m0 + j * 64 + srow; ra = ra < p.M ? ra : p.M - 1;
+        ga[j] = p.A + (int64_t)ra * p.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gw[j] = p.W + (int64_t)(j * 64 + srow) * p.ldw + schunk * 8;
+    auto stage = [&](int buf, int kt) {
+        char* l = smem + buf * BUF + wid * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pv_glds16(ga[j] + kt * BK, l + j * 8192);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) pv_glds16(gw[j] + kt * BK, l + A_BYTES + j * 8192);
+    };
+
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    const int fx0 = ((lane >> 4) ^ (lane & 7)) << 4;
+    lds_cc* a_rd = (lds_cc*)smem + (wm * 64 + i16) * 128 + fx0;                      // + buf * BUF + mt * 2048, ks: ^ 64
+    lds_cc* w_rd = (lds_cc*)smem + A_BYTES + (wn * 16 * NT + i16) * 128 + fx0;       // + buf * BUF + nt * 2048
+    asm volatile("" : "+v"(a_rd));
+    asm volatile("" : "+v"(w_rd));
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // tile kt has landed for every wave; buffer cur ^ 1 is no longer read
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[4], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                xf[mt] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((lds_cc*)((uintptr_t)a_rd ^ (ks << 6)) + cur * BUF + mt * 2048);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((lds_cc*)((uintptr_t)w_rd ^ (ks << 6)) + cur * BUF + nt * 2048);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = PV_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    typedef __attribute__((address_space(3))) char lds_c;
+    lds_c* const cimg = (lds_c*)smem;
+    const int nvec = N / 4;
+    float4 ln_g[NCH], ln_b[NCH];                           // the lane's LayerNorm affine parameters, fetched once
+    if (p.ln_out) pv_ln_load_affine<NCH>(ln_g, ln_b, p.ln_gamma, p.ln_beta, nvec, lane);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        // this wave's 8 rows of the pass: their residual segments first (NCH x 16 B per lane and row, whole contiguous rows)
+        f32x4 rr[8][NCH];
+        float sc[8], lsc[8];
+        int mrow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + ps * 64 + wid * 8 + j;
+            mrow[j] = m < p.M ? m : p.M - 1;
+            sc[j] = 1.0f; lsc[j] = 1.0f;
+        }
+        if (p.row_scale) {                                 // (workgroup-uniform; hoisted so that the row loads below are branch-free)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc[j] = p.row_scale[mrow[j]];
+        }
+        if (p.ln_row_scale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lsc[j] = p.ln_row_scale[mrow[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int idx = lane + 64 * c < nvec ? lane + 64 * c : nvec - 1;       // lanes beyond the row re-read its last chunk (never stored)
+                rr[j][c] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)mrow[j] * p.ldr + idx * 4);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // K loop (ps = 0) / the previous pass's image reads (ps = 1) are done
+        if (wm == ps) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = mt * 16 + i16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = wn * 4 * NT + nt * 4 + g;                 // 16-byte chunk of the row
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = wid * 8 + j;
+            const int m = m0 + ps * 64 + row;
+            RowRegs<NCH> r;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int idx = lane + 64 * c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < nvec) v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((idx ^ (row & 7)) << 4));
+                r.v[c] = idx < nvec ? make_float4(fmaf(sc[j], v[0], rr[j][c][0]), fmaf(sc[j], v[1], rr[j][c][1]), fmaf(sc[j], v[2], rr[j][c][2]),
+                                                  fmaf(sc[j], v[3], rr[j][c][3]))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
+            }
+            if (m < p.M) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int idx = lane + 64 * c;
+                    if (idx < nvec) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4) = r.v[c];
+                }
+            }
+            if (p.ln_out) {                                // (workgroup-uniform)
+                // p.N (= N), not the constant: the standalone kernel divides by a RUN-TIME D, and hipcc's division by a run-time value and by
+                // a power-of-two constant differ in the last bit (found by the bit-identity test at N = 512)
+                pv_ln_row_regs<NCH>(r, ln_g, ln_b, p.N, nvec, lane, p.ln_eps);
+                if (m < p.M) {
+                    u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * N);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int idx = lane + 64 * c;
+                        if (idx < nvec) {
+                            u32x2 pk = {pv_pack_bf16x2(r.v[c].x * lsc[j], r.v[c].y * lsc[j]), pv_pack_bf16x2(r.v[c].z * lsc[j], r.v[c].w * lsc[j])};
+                            o[idx] = pk;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
+    static PvPerDevice attr_set;
+    constexpr int lds = 2 * (128 * 64 * 2 + 64 * NT * 64 * 2);
+    if (attr_set.first_use()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    PV_LAUNCH(pv_gemm_fullrow_kernel<NT>, dim3((unsigned)p.tiles_m), dim3(512), lds, stream, p);
+    return pv_check_launch();
+}
+
 // tile-raster override for the L2 experiments (scripts/bench_gemm.py): gm / gc <= 0 restore the built-in choice
 static int g_pv_raster_gm = 0, g_pv_raster_gc = 0;
 extern "C" void pv_debug_set_gemm_raster(int gm, int gc) { g_pv_raster_gm = gm; g_pv_raster_gc = gc; }
+static int g_pv_fullrow = -1;      // -1: PV_GEMM_FULLROW / default; 0 / 1: A/B override (scripts/fullrow_ab.py)
+extern "C" void pv_debug_set_gemm_fullrow(int on) { g_pv_fullrow = on; }
 
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only);
 extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) { return pv_gemm_dispatch(a, stream, false); }
@@ -1127,7 +1325,8 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     if (a->ln_out) {
         // fused LayerNorm: whole rows per workgroup -> N is the hidden dim, a multiple of 256, K a multiple of 128
         if (a->epilogue != PV_EPI_BIAS_RES_F32 || !a->ln_gamma || !a->ln_beta) return PV_ERR_INVALID_ARG;
-        if (a->N % G2_BN || a->N > 4096 || a->K % (2 * G2_BK) || a->ldo != a->N) return PV_ERR_UNSUPPORTED;
+        if (!(a->N == 256 || a->N == 384 || a->N == 512) && (a->N % G2_BN || a->N > 4096 || a->K % (2 * G2_BK))) return PV_ERR_UNSUPPORTED;
+        if (a->ldo != a->N) return PV_ERR_UNSUPPORTED;
         if (((uintptr_t)a->ln_out & 7) || ((uintptr_t)a->ln_gamma & 15) || ((uintptr_t)a->ln_beta & 15)) return PV_ERR_INVALID_ARG;
     }
     if (a->epilogue == PV_EPI_BIAS_RES_F32 && (!a->res || a->ldr % 4 || a->ldr < a->N || ((uintptr_t)a->res & 15))) return PV_ERR_INVALID_ARG;
@@ -1172,6 +1371,14 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     if (g_pv_raster_gm > 0) p.gm = g_pv_raster_gm;
     if (g_pv_raster_gc > 0) p.gc = g_pv_raster_gc < p.tiles_n ? g_pv_raster_gc : p.tiles_n;
     if ((int64_t)p.tiles_m * p.tiles_n > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    // full-row tile (128 x N, N = 256 / 384 / 512): the residual GEMMs of narrow models, with or without the fused LayerNorm
+    static const int fullrow_env = [] { const char* e = getenv("PV_GEMM_FULLROW"); return e ? atoi(e) : 1; }();
+    const bool fullrow_shape = a->epilogue == PV_EPI_BIAS_RES_F32 && (p.N == 256 || p.N == 384 || p.N == 512) && p.ksplit <= 1 && !feat &&
+                               (g_pv_fullrow >= 0 ? g_pv_fullrow != 0 : fullrow_env != 0) && force == 0;
+    if (fullrow_shape && (a->ln_out || (p.M + 127) / 128 >= 96)) {
+        p.tiles_m = (p.M + 127) / 128; p.tiles_n = 1;
+        return p.N == 256 ? pv_launch_gemm_fullrow<4>(p, s) : p.N == 384 ? pv_launch_gemm_fullrow<6>(p, s) : pv_launch_gemm_fullrow<8>(p, s);
+    }
     if (a->ln_out) {
         p.gm = 1; p.gc = p.tiles_n;
         p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = p.N / G2_BN;

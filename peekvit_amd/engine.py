@@ -312,8 +312,16 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _FUSE_LN = os.environ.get("PEEKVIT_AMD_FUSE_LN", "0") == "1"
 
 
+# Narrow models (hidden dim 256 / 384 / 512: vit_tiny, vit_small widths): the residual GEMMs run on the FULL-ROW tile kernel
+# (pv_gemm_fullrow_kernel) and the LayerNorm that consumes their rows is computed in its epilogue - bit-identical to the separate
+# kernels, one launch and one pass over the residual stream less per LayerNorm.  PEEKVIT_AMD_FULLROW_LN=0 disables.
+_FULLROW_LN = os.environ.get("PEEKVIT_AMD_FULLROW_LN", "1") == "1"
+
+
 def _ln_fusable(D: int, K: int) -> bool:
-    """Shapes the row-block GEMM with fused LayerNorm accepts (include/peekvit_hip.h pv_gemm_args.ln_out)."""
+    """Shapes a GEMM with fused LayerNorm accepts (include/peekvit_hip.h pv_gemm_args.ln_out)."""
+    if _FULLROW_LN and D in (256, 384, 512) and K % 64 == 0:
+        return True
     return _FUSE_LN and D % 256 == 0 and D <= 4096 and K % 128 == 0
 
 

@@ -342,3 +342,37 @@ def test_gemm_rowsq_out(M, N, K):
     keep = ops.rank_topk_partials(rowsq, M // 8, 8, 4)                   # 8-token "images": rank rows 1..7 of each by norm
     norms = out.double().pow(2).sum(1).sqrt().view(M // 8, 8)[:, 1:]
     assert torch.equal(keep.long().cpu(), norms.argsort(dim=1, descending=True, stable=True)[:, :4].cpu())
+
+
+def test_graph_owns_its_scratch():
+    """A captured forward must survive later eager forwards that grow the shared workspace arena (the graph's nodes point into a
+    private arena that the GraphedForward object keeps alive)."""
+    from peekvit_amd.graph import GraphedForward
+    cfg, m = _model("vit", "vit_tiny")
+    x = _x(cfg, 4).to(DEV)
+    with torch.no_grad():
+        eager = m(x).clone()
+    g = GraphedForward(m, x)
+    big = torch.randn(24, 3, cfg["image_size"], cfg["image_size"], device=DEV)
+    with torch.no_grad():
+        for _ in range(2):
+            m(big)                                   # replaces every shared scratch buffer by a larger one
+        junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]      # and lets the allocator hand the freed blocks out again
+    assert torch.equal(g(x), eager)
+    del junk
+
+
+def test_two_stream_forward_is_bit_identical(monkeypatch):
+    """PEEKVIT_AMD_STREAMS=2 (opt-in): two half-batches on two HIP streams give the same bits."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_tiny")
+    x = torch.randn(300, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        one = m(x).clone()
+        monkeypatch.setattr(engine, "_STREAMS", 2)
+        two = m(x)
+        torch.cuda.synchronize()
+        assert torch.equal(one, two)
+        with torch.no_grad():
+            m.encoder.layers[0].mlp.fc1.weight.mul_(1.0)          # new parameter version: the cast happens on one stream, both use it
+        assert torch.equal(m(x), one)

@@ -152,9 +152,12 @@ def test_gemm_kernels_agree_bitwise(ops):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048 + 77, 768, 768), (1000, 768, 3072), (520, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048 + 77, 768, 768), (1000, 768, 3072), (520, 1024, 256),
+                                   (3000, 384, 384), (1001, 384, 1536), (2100, 256, 768), (700, 512, 512), (128 * 97 + 5, 384, 64), (50, 512, 1536)])
 def test_gemm_fused_layernorm_bit_identical_to_separate_kernels(ops, M, N, K):
-    """Row-block GEMM with fused LayerNorm == plain GEMM followed by pv_layernorm_bf16, bit for bit (with and without row scale)."""
+    """GEMM with fused LayerNorm (full-row tile for N = 256 / 384 / 512, row-block kernel otherwise) == plain GEMM followed by
+    pv_layernorm_bf16, bit for bit (with and without row scale); N = 384 ... also cover the full-row kernel WITHOUT LayerNorm against the
+    128^2 / 256^2 kernels (PV_GEMM_FULLROW-independent: an element rounds identically in every kernel)."""
     from peekvit_amd._lib import PV_EPI_BIAS_RES_F32
     a, w = bf(T(f"fa{M}{K}", (M, K))), bf(T(f"fw{N}{K}", (N, K), "uniform", 1.0 / math.sqrt(K)))
     bias, res = T(f"fb{N}", (N,), "uniform", 0.1).to(DEV), T(f"fr{M}{N}", (M, N), bf16=False).to(DEV)
