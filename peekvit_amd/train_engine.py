@@ -77,6 +77,26 @@ def _wgrad_transposed(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, accu
     return ops.sum_slices(part, out, accumulate)
 
 
+_SPLITK_MODE = os.environ.get("PEEKVIT_AMD_WGRAD_SPLIT", "balanced")      # "balanced" (r2) | "pow2" (r1)
+
+
+def _tn_slices(R: int, tiles: int, No: int, Ni: int, cus: int = 256) -> int:
+    """Number of split-K slices of the weight-gradient GEMM.  A launch is tiles x slices workgroups of equal length on `cus` CUs, so its
+    time is ROUNDS x one workgroup: r1 took the first power of two with >= 512 workgroups (fc1 / fc2: 36 tiles x 16 = 576 = 2.25 rounds -> 3
+    rounds at 75 %, out-proj: 9 x 32 = 288 = 1.125 -> 2 rounds at 56 %).  Now: the slice count (<= 32, whole 128-row blocks, the kernel
+    gives the last slice the remainder) that minimises rounds x rows-per-slice + the fp32 partial-slab traffic it causes."""
+    best, best_t = 1, float("inf")
+    for s_ in range(1, 33):
+        if R // (s_ * 2) < 256 and s_ > 1:
+            break
+        rounds = -(-(tiles * s_) // cus)
+        t_gemm = rounds * (R / s_) * (2.0 * 256 * 256) / 4.1e12          # one 256^2 tile-row at ~1.05 PFLOP/s / 256 CUs
+        t_part = s_ * No * Ni * 8.0 / 5.5e12                              # slabs written once, read once by pv_sum_slices_f32
+        if t_gemm + t_part < best_t:
+            best, best_t = s_, t_gemm + t_part
+    return best
+
+
 def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
     """(dW fp32 [No, Ni] = dy^T . x,  db fp32 [No] = column sums of dy) for bf16 dy [R, No], x [R, Ni] (row-strided views
     allowed).  128-multiples of features: the TN kernel reads the row-major activations directly, split-K over the rows; the
@@ -88,9 +108,12 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
     db = torch.empty((No,), dtype=torch.float32, device=dev) if bias_grad else None
     if No % 128 == 0 and Ni % 128 == 0 and R >= 256 and not _NO_TN:
         tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
-        s_ = 1
-        while s_ < 32 and tiles * s_ < 512 and R // (s_ * 2) >= 256:
-            s_ *= 2
+        if _SPLITK_MODE == "pow2":
+            s_ = 1
+            while s_ < 32 and tiles * s_ < 512 and R // (s_ * 2) >= 256:
+                s_ *= 2
+        else:
+            s_ = _tn_slices(R, tiles, No, Ni)
         r_main = R // 128 * 128                      # the TN kernel deals whole 128-row blocks to the slices (last slice: the rest)
         part = workspace.get("wg_part", (s_, No, Ni), torch.float32, dev)
         ops.gemm_tn(dy[:r_main], x[:r_main], part, s_)

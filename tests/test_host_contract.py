@@ -257,3 +257,17 @@ def test_residualvit_training_step_matches_the_reference():
     assert names == [n for n, _ in m.named_parameters()]
     gn = np.array([float(named[n].grad.norm()) if named[n].grad is not None else 0.0 for n in names])
     assert np.allclose(gn, g[f"{name}/grad_norms"], rtol=2e-4, atol=1e-7)
+
+
+def test_wgrad_slice_count_fills_whole_rounds():
+    """train_engine._tn_slices: the split-K slice count of the weight-gradient GEMM is chosen so that tiles x slices workgroups fill
+    whole rounds of the 256 CUs (r1's power-of-two rule left 25-44 % of the last round idle on the ViT-B/16 shapes)."""
+    from peekvit_amd.train_engine import _tn_slices
+    R = 2048 * 197
+    for No, Ni in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+        tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
+        s = _tn_slices(R, tiles, No, Ni)
+        blocks = tiles * s
+        assert 1 <= s <= 32 and R // (2 * s) >= 256
+        assert blocks / (256 * -(-blocks // 256)) > 0.95, (No, Ni, s)          # >= 95 % of the last round busy
+    assert _tn_slices(394, 9, 768, 768) == 1                                   # tiny batch: nothing to split
