@@ -51,8 +51,9 @@ def parse():
                     help="BASELINE.json configs[2]/[4]: a step = forward + cross-entropy + backward (HIP backward kernels); with N > 1 "
                          "ranks the parameter gradients are all-reduced over RCCL (data-parallel training path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=64, help="images of the CPU-oracle sample (64: large enough that the GPU path scored "
+                                                                "against it takes the same kernels / LayerNorm folding as the timed batch)")
+    ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--precision", default="auto", choices=["auto", "bf16", "f16", "bf16x3"],
                     help="operand precision of the MFMA products: auto (default = the package default: IEEE fp16 operands behind the "
                          "operand-range guard with bf16 fallback for inference - meets the 1e-3 logits tolerance; bf16 operands for "

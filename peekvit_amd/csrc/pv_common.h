@@ -115,6 +115,23 @@ __device__ __forceinline__ float pv_wave_sum(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// v[r] (r = 0..15) per lane -> the sum over all 64 lanes of v[r], delivered to lanes 4r .. 4r+3: a reduce-scatter that halves the
+// number of rows a lane carries at every step (8 + 4 + 2 + 1 exchanges) and finishes with two plain steps: 17 cross-lane operations
+// instead of 16 separate wave reductions.
+__device__ __forceinline__ float pv_reduce16_rows(const float (&v)[16], int lane) {
+    float t8[8], t4[4], t2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t4[i] = (b4 ? t8[i + 4] : t8[i]) + __shfl_xor(b4 ? t8[i] : t8[i + 4], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t2[i] = (b3 ? t4[i + 2] : t4[i]) + __shfl_xor(b3 ? t4[i] : t4[i + 2], 8, 64);
+    float t1 = (b2 ? t2[1] : t2[0]) + __shfl_xor(b2 ? t2[0] : t2[1], 4, 64);
+    t1 += __shfl_xor(t1, 2, 64);
+    t1 += __shfl_xor(t1, 1, 64);
+    return t1;                       // row ((lane >> 2) & 15)
+}
 __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

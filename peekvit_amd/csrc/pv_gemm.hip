@@ -534,6 +534,20 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 fc2[u][0] = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb); fc2[u][1] = *reinterpret_cast<const f32x4*>(p.fold_c2 + cb + 4);
             }
         }
+        // folded LayerNorm (consumer): the (mean, rstd) of this lane's 8 rows, fetched together BEFORE the image loop (inside it every
+        // load would be followed by its own wait: eight L2 round trips per tile)
+        float f_mean8[8], f_rstd8[8];
+        if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int row_ = wr * 128 + mt * 16 + i16;
+                const int mrow = m0 + row_ < p.M ? m0 + row_ : p.M - 1;
+                const float2 st = *reinterpret_cast<const float2*>(p.fold_stat + 2 * (int64_t)mrow);
+                f_mean8[mt] = st.x; f_rstd8[mt] = st.y;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) { asm volatile("" : "+v"(f_mean8[mt])); asm volatile("" : "+v"(f_rstd8[mt])); }
+        }
 #pragma unroll
         for (int pass = 0; pass < (SPLIT || PAIR ? 2 : 1); ++pass) {
             if (pass == 1) {
@@ -544,11 +558,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             for (int mt = 0; mt < 8; ++mt) {
                 const int row = wr * 128 + mt * 16 + i16;
                 float f_mean = 0.f, f_rstd = 1.f;
-                if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) {
-                    const int mrow = m0 + row < p.M ? m0 + row : p.M - 1;
-                    const float2 st = *reinterpret_cast<const float2*>(p.fold_stat + 2 * (int64_t)mrow);
-                    f_mean = st.x; f_rstd = st.y;
-                }
+                if ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat) { f_mean = f_mean8[mt]; f_rstd = f_rstd8[mt]; }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 lo = acc[2 * u][mt], hi = acc[2 * u + 1][mt];
@@ -625,6 +635,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
             f32x4 rr[16];
             int64_t orow[16];
+            float fs[16], fq[16];          // LayerNorm folding (producer): per-lane partial (sum, sum of squares) of the 16 rows
             const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
             const int ncol = col_ok ? n0 + lane * 4 : 0;
 #pragma unroll
@@ -688,20 +699,30 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out) {    // (workgroup-uniform) token norms for the next block's ranking
                     const bool ok = m0 + ps * 128 + row < p.M && col_ok;
-                    float q_ = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
-                    q_ = pv_wave_sum(q_);
-                    if (lane == 0 && m0 + ps * 128 + row < p.M) p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + orow[j]] = q_;
+                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the loop
                 }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
                     const bool ok = m0 + ps * 128 + row < p.M && col_ok;
                     if (ok)
                         *reinterpret_cast<u32x2*>(p.x16_out + orow[j] * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
-                    float s_ = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
-                    float q_ = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
-                    s_ = pv_wave_sum(s_); q_ = pv_wave_sum(q_);
-                    if (lane == 0 && m0 + ps * 128 + row < p.M)
-                        *reinterpret_cast<float2*>(p.rowstat_out + ((int64_t)(n0 / G2_BN) * p.M + orow[j]) * 2) = make_float2(s_, q_);
+                    // this lane's share of row j's (sum, sum of squares); the 64-lane reduction of all 16 rows follows the loop
+                    fs[j] = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
+                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
                 }
+            }
+            if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out && !p.x16_out) {
+                const float tq = pv_reduce16_rows(fq, lane);
+                const int r_ = (lane >> 2) & 15;
+                if ((lane & 3) == 0 && m0 + ps * 128 + wid * 16 + r_ < p.M)
+                    p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + (m0 + ps * 128 + wid * 16 + r_)] = tq;
+            }
+            if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {
+                // 16 rows x 64 lanes -> 16 totals in 17 cross-lane steps per quantity (halving the rows a lane carries at every step)
+                // instead of 16 full wave reductions; lanes 4r .. 4r+3 end up with row r's totals
+                const float ts = pv_reduce16_rows(fs, lane), tq = pv_reduce16_rows(fq, lane);
+                const int r_ = (lane >> 2) & 15;
+                if ((lane & 3) == 0 && m0 + ps * 128 + wid * 16 + r_ < p.M)
+                    *reinterpret_cast<float2*>(p.rowstat_out + ((int64_t)(n0 / G2_BN) * p.M + (m0 + ps * 128 + wid * 16 + r_)) * 2) = make_float2(ts, tq);
             }
         }
         if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) pv_range_commit(vmax, p.range_flag);
@@ -1299,7 +1320,7 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     GemmDev p;
     p.range_flag = a->range_flag;
     p.rowsq_out = a->rowsq_out;
-    if (a->rowsq_out && (a->epilogue != PV_EPI_BIAS_RES_F32 || ((uintptr_t)a->rowsq_out & 3) || a->ln_out)) return PV_ERR_INVALID_ARG;
+    if (a->rowsq_out && (a->epilogue != PV_EPI_BIAS_RES_F32 || ((uintptr_t)a->rowsq_out & 3) || a->ln_out || a->x16_out)) return PV_ERR_INVALID_ARG;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.res = a->res; p.row_scale = a->row_scale; p.pos = a->pos;
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
