@@ -795,11 +795,20 @@ __global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GemmDev p = p_in;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int slice = blockIdx.x / ntiles;
+    // (slice, tile) list in slice-major order; every XCD (blocks b, b + 8, ...) walks a CONTIGUOUS range of it, so the ~32 workgroups an XCD
+    // runs together are (nearly) one K slice: each dY column block they stream is shared by tiles_n of them and each X column block by
+    // tiles_m of them in that XCD's L2.  (r1 remapped inside a slice with the slice's local block index as "XCD", which is the real
+    // XCD only for slices that start at a multiple of 8 blocks.)   PV_TN_RASTER=0 restores it for A/B.
+    int slice, tile;
+    if (p.gm != 0) {
+        const int l = pv_xcd_remap(blockIdx.x, ntiles * p.ksplit);
+        slice = l / ntiles; tile = l - slice * ntiles;
+    } else {
+        slice = blockIdx.x / ntiles; tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
+    }
     p.A += (int64_t)slice * p.k_slice * p.lda; p.W += (int64_t)slice * p.k_slice * p.ldw;
     p.K = slice == p.ksplit - 1 ? p.k_last : p.k_slice;          // the last slice takes the remainder
     p.out = reinterpret_cast<float*>(p.out) + slice * p.split_stride;
-    const int tile = pv_xcd_remap(blockIdx.x - slice * ntiles, ntiles);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * G2_BM, n0 = tn * G2_BN;
 
@@ -991,7 +1000,8 @@ extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
     // K / 128 blocks of rows are dealt to the slices as evenly as whole blocks allow; the last slice takes the remainder
     p.ksplit = ks; p.k_slice = (int)(a->K / (2 * G2_BK) / ks) * (2 * G2_BK); p.k_last = (int)a->K - p.k_slice * (ks - 1);
     p.split_stride = a->M * a->ldo;
-    p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = 1; p.gc = p.tiles_n;
+    static const int tn_raster = [] { const char* e = getenv("PV_TN_RASTER"); return e ? atoi(e) : 1; }();
+    p.tiles_m = (p.M + G2_BM - 1) / G2_BM; p.tiles_n = (p.N + G2_BN - 1) / G2_BN; p.gm = tn_raster; p.gc = p.tiles_n;
     if ((int64_t)p.tiles_m * p.tiles_n * ks > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     static PvPerDevice attr_set;
     if (attr_set.first_use()) {
