@@ -590,6 +590,9 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { cq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ck[dt] = cq[dt]; cv[dt] = cq[dt]; }
 
+#if defined(PV_ATTN_BWD_STOP) && PV_ATTN_BWD_STOP == 1
+    if (S > 0) return;                       // diagnostic build: staging only
+#endif
     // =============================== pass 1: per 16-query tile ===============================
     for (int qt = wid; qt < nqt; qt += NW) {
         const int q0 = qt << 4;
@@ -675,6 +678,9 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     }
     __syncthreads();
 
+#if defined(PV_ATTN_BWD_STOP) && PV_ATTN_BWD_STOP == 2
+    if (S > 0) return;                       // diagnostic build: staging + pass 1
+#endif
     // =============================== pass 2: per 16-key tile ===============================
     for (int kt = wid; kt < nqt; kt += NW) {
         const int k0 = kt << 4;
