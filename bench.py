@@ -272,6 +272,7 @@ def main():
                 roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted mean over the GEMM variants)"
         except (OSError, KeyError, ValueError, StopIteration):
             pass
+        flops_exec = sum(v["flops"] for v in ks.values()) / (args.steps * args.batch)
         kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                        "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
@@ -286,12 +287,17 @@ def main():
             "config": {"workload": workload, "global_batch": world * args.batch,
                        "parallelism": (f"dp{world} (batch-sharded, gradient all-reduce over {args.dist_backend})" if args.train and dist
                                        else f"replicas x{world} (batch-sharded, no collective)"),
-                       "gflop_per_image": round(flops_img / 1e9, 3), "precision_mode": args.precision, "streams": engine._STREAMS,
+                       "gflop_per_image": round(flops_img / 1e9, 3), "gflop_per_image_executed": round(flops_exec / 1e9, 3),
+                       "last_block": ("class-token rows only (k|v for all tokens; q, out-proj, MLP for the rows the head reads; same logits)"
+                                      if "pv_attention_rows_bf16" in ks else "all rows"),
+                       "precision_mode": args.precision, "streams": engine._STREAMS,
                        "operands": {"f16": "IEEE fp16 operands, fp32 accumulate (same MFMA rate as bf16), range-guarded" if args.precision == "auto"
                                     else "IEEE fp16 operands, fp32 accumulate", "bf16": "bf16 operands, fp32 accumulate",
                                     "bf16x3": "split bf16 hi+lo operands (3 products), fp32 accumulate"}[dtype],
                        "range_guard_fallbacks": fallbacks},
-            "model_mfma_roofline_frac": round(value / world * flops_img / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+            # MFMA FLOPs the kernels really executed per second (their own algorithmic counts) over the dense bf16 peak - NOT the
+            # reference formula's FLOPs, of which the last block skips the rows nobody reads
+            "model_mfma_roofline_frac": round(value / world * flops_exec / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roof,
             "kernels": kernels,
         }
@@ -314,6 +320,23 @@ def main():
                     dtb = time.perf_counter() - t2
                 line["bf16_mode"] = {"value": round(args.batch * args.steps / dtb, 1), "unit": "images/sec",
                                      "ms_per_step": round(dtb / args.steps * 1e3, 3), "dtype": "bf16"}
+            if plain and engine._LAST_BLOCK_ROWS:
+                # the same forward with the last block computing all S rows, as the reference does (PEEKVIT_AMD_LAST_BLOCK_ROWS=0)
+                engine._LAST_BLOCK_ROWS = False
+                try:
+                    with torch.no_grad(), engine.precision(args.precision):
+                        for _ in range(2):
+                            infer_model(x)
+                        torch.cuda.synchronize(dev)
+                        t2 = time.perf_counter()
+                        for _ in range(args.steps):
+                            infer_model(x)
+                        torch.cuda.synchronize(dev)
+                        dta = time.perf_counter() - t2
+                finally:
+                    engine._LAST_BLOCK_ROWS = True
+                line["all_rows_mode"] = {"value": round(args.batch * args.steps / dta, 1), "unit": "images/sec",
+                                         "ms_per_step": round(dta / args.steps * 1e3, 3), "gflop_per_image": round(flops_img / 1e9, 3)}
             err = line["cpu_baseline"].get("gpu_logits_rel_l2_vs_oracle", {}).get(args.precision)
             if plain and err is not None:
                 line["logits_rel_l2_vs_oracle"] = err

@@ -161,6 +161,13 @@ int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
  * with an online softmax; dh in {80,96,128}: the streaming kernel for every S. */
 int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
 
+/* The same attention for the FIRST nq ROWS of every image only (queries) against all S keys: the last encoder block, of whose output
+ * only the class-token rows are read (models/vit.py:242-246; the reference computes all S rows and drops the rest).
+ * q: 16-bit [B*nq rows, ldq] (already scaled), kv: 16-bit [B*S rows, ldkv] with k in columns [0, H*dh) and v in [H*dh, 2*H*dh),
+ * out: 16-bit [B*nq rows, ldo].  dh in {32,48,64,80,96,128}, any S; ld* in elements, multiples of 8. */
+int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B,
+                           int64_t S, int64_t nq, int64_t H, int64_t dh, void* stream);
+
 /* ---- precision mode "bf16x3" (opt-in): split operands v = hi + lo, concatenated along K so that the
  * SAME bf16 MFMA GEMM computes a_hi.w_hi + a_lo.w_hi + a_hi.w_lo; meets the 1e-3 logits tolerance at ~3x the GEMM work. ---- */
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pv_gemm_tile_rows": (C.c_int, [C.POINTER(GemmArgs)]),
     "pv_rowstat_finalize": (C.c_int, [_p, _p, _i64, _i64, _i64, _f32, _p]),
     "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_attention_rows_bf16": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "pv_cls_pool": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_head_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pv_token_norm": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
@@ -74,7 +75,7 @@ SIGNATURES = {
     "pv_residual_gate": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _i64, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lock = threading.Lock()
 _libs: dict = {}
 

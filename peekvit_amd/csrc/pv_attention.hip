@@ -823,6 +823,112 @@ extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, 
     }
 }
 
+// ---- attention for the FIRST nq ROWS of every image only (queries), against all S keys -----------------------------------------------
+// The last encoder block of a ViT: only the class-token rows of its output are consumed (models/vit.py:242-246), so its attention needs
+// q for those rows alone but k, v of every token.  HBM-bound: K and V of the head are read once (2 * S * dh operands), nothing is staged.
+// One wave per (image, head, query row).  CPL lanes share a key (one 16-byte chunk of the head dimension each), 64 / CPL keys per step;
+// every lane group runs its own online softmax over its keys, the groups are merged at the end.  All arithmetic fp32 (p is not rounded).
+template <int DH>
+__global__ __launch_bounds__(256) void pv_attn_rows_kernel(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kv, int64_t ldkv,
+                                                           uint16_t* __restrict__ out, int64_t ldo, int S, int H, int nq, int64_t total) {
+    constexpr int NCH = DH / 8;
+    constexpr int CPL = NCH <= 4 ? 4 : (NCH <= 8 ? 8 : 16);
+    constexpr int KPI = 64 / CPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total) return;
+    const int qi = (int)(w % nq);
+    const int64_t bh = w / nq;
+    const int h = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int c = lane % CPL, g = lane / CPL;
+    const bool act = c < NCH;
+    const int cc = act ? c : 0;
+    const int64_t vcol = (int64_t)H * DH;
+
+    float qf[8];
+    {
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (b * nq + qi) * ldq + h * DH + cc * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qf[2 * i] = act ? pv_unpack_lo(qv[i]) : 0.f;
+            qf[2 * i + 1] = act ? pv_unpack_hi(qv[i]) : 0.f;
+        }
+    }
+    const uint16_t* kbase = kv + (b * S) * ldkv + h * DH + cc * 8;
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll 4
+    for (int j0 = 0; j0 < S; j0 += KPI) {
+        const int key = j0 + g;
+        const bool valid = key < S;
+        const int64_t off = (int64_t)(valid ? key : S - 1) * ldkv;
+        const u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + off);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(kbase + off + vcol);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += qf[2 * i] * pv_unpack_lo(kk[i]) + qf[2 * i + 1] * pv_unpack_hi(kk[i]);
+#pragma unroll
+        for (int d = 1; d < CPL; d <<= 1) s += __shfl_xor(s, d, 64);
+        if (valid) {
+            const float mn = fmaxf(m, s);
+            const float sc = __expf(m - mn), pr = __expf(s - mn);        // first key of the group: m = -inf, sc = 0
+            l = l * sc + pr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = o[2 * i] * sc + pr * pv_unpack_lo(vv[i]);
+                o[2 * i + 1] = o[2 * i + 1] * sc + pr * pv_unpack_hi(vv[i]);
+            }
+            m = mn;
+        }
+    }
+    // merge the KPI lane groups (a group that saw no key keeps m = -inf, l = 0 and contributes nothing)
+#pragma unroll
+    for (int d = CPL; d < 64; d <<= 1) {
+        const float m2 = __shfl_xor(m, d, 64), l2 = __shfl_xor(l, d, 64);
+        const float mn = fmaxf(m, m2);
+        const float a = m == -INFINITY ? 0.f : __expf(m - mn), a2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        l = l * a + l2 * a2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], d, 64) * a2;
+        m = mn;
+    }
+    if (g == 0 && act) {
+        const float inv = 1.0f / l;
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = pv_pack_bf16x2(o[2 * i] * inv, o[2 * i + 1] * inv);
+        *reinterpret_cast<u32x4*>(out + (b * nq + qi) * ldo + h * DH + c * 8) = r;
+    }
+}
+
+template <int DH>
+static int pv_launch_attn_rows(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B, int S, int nq,
+                               int H, hipStream_t stream) {
+    const int64_t total = B * H * nq;
+    PV_LAUNCH(pv_attn_rows_kernel<DH>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, q, ldq, kv, ldkv, out, ldo, S, H, nq, total);
+    return pv_check_launch();
+}
+
+extern "C" int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B,
+                                      int64_t S, int64_t nq, int64_t H, int64_t dh, void* stream) {
+    if (!q || !kv || !out || B <= 0 || S <= 0 || nq <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)out & 15) || (ldq & 7) || (ldkv & 7) || (ldo & 7)) return PV_ERR_INVALID_ARG;
+    if (ldq < H * dh || ldo < H * dh || ldkv < 2 * H * dh) return PV_ERR_INVALID_ARG;
+    if (B * H * nq > 0x7fffffffLL * 4 || S > 0x3fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 32: return pv_launch_attn_rows<32>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 48: return pv_launch_attn_rows<48>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 64: return pv_launch_attn_rows<64>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 80: return pv_launch_attn_rows<80>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 96: return pv_launch_attn_rows<96>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 128: return pv_launch_attn_rows<128>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return PV_ERR_INVALID_ARG;

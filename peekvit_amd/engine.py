@@ -474,6 +474,76 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     return out
 
 
+_LAST_BLOCK_ROWS = os.environ.get("PEEKVIT_AMD_LAST_BLOCK_ROWS", "1") != "0"
+
+
+def rows_only_ok(blk: nn.Module) -> bool:
+    """May the LAST block of a model forward compute only the rows its consumer reads (block_forward_rows)?  Not in mode "bf16x3", and not
+    when someone observes the block's output through a forward hook (they would see [B,nq,D] instead of [B,S,D])."""
+    import torch.nn.modules.module as _m
+    return (_LAST_BLOCK_ROWS and _PRECISION != "bf16x3" and not blk._forward_hooks and not blk._forward_pre_hooks
+            and not _m._global_forward_hooks and not _m._global_forward_pre_hooks)
+
+
+def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int) -> torch.Tensor:
+    """The block's output for the FIRST `nq` ROWS of every image only: [B,S,D] -> [B,nq,D].
+
+    For the last encoder block of a model forward, whose consumer (pool_and_head) reads the class-token rows alone
+    (models/vit.py:242-246; the reference computes all S rows and drops S - nq of them).  Rows of a block are independent except
+    through attention, which needs k and v of every token but q of the wanted rows only - so the all-token work left is LN1 and the
+    k|v two thirds of the in-projection; out-proj, LN2 and the MLP run on B*nq rows.  Same arithmetic per surviving row as block_forward
+    (fp32 softmax weights instead of 16-bit ones in the attention)."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    fold_in, handoff = getattr(x, "_pv_fold", None), getattr(x, "_pv_ln", None)
+    if fold_in is not None and fold_in[3] != x._version:
+        fold_in = None
+    if not x.is_contiguous():
+        x, fold_in, handoff = x.contiguous(), None, None
+    B, S, D = x.shape
+    mha = blk.self_attention.self_attention
+    H = mha.num_heads
+    dh = D // H
+    M = blk.mlp.fc1.out_features
+    dev, R, Rq, od = x.device, B * S, B * nq, _lib.operand_dtype()
+    _check_ln_range(blk.ln_1)
+    _check_ln_range(blk.ln_2)
+    g1, b1 = _f32(blk.ln_1.weight), _f32(blk.ln_1.bias)
+
+    # k | v of every token
+    kv = workspace.get("qkv", (R, 2 * D), od, dev)
+    if fold_in is not None and fold_in[2] == _ln_key(blk.ln_1) and fold_in[0].shape == (R, D):
+        wg, c1, c2 = _fold_weights(mha.in_proj_weight, mha.in_proj_bias, blk.ln_1)
+        stat = ops.rowstat_finalize(fold_in[1], D, blk.ln_1.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
+        ops.gemm(fold_in[0], wg[D:], None, kv, PV_EPI_BIAS_BF16, M=R, fold=(stat, c1[D:], c2[D:]))
+    else:
+        if handoff is not None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
+            h = handoff[0]
+        else:
+            h = workspace.get("h", (R, D), od, dev)
+            ops.layernorm_bf16(x, g1, b1, eps, h, None)
+        ops.gemm(h, bf16_weight(mha.in_proj_weight)[D:], _f32(mha.in_proj_bias)[D:], kv, PV_EPI_BIAS_BF16, M=R)
+
+    # q of the wanted rows, then everything else on B*nq rows
+    xq = workspace.get("rows_x", (B, nq, D), torch.float32, dev)
+    xq.copy_(x[:, :nq])
+    xq = xq.view(Rq, D)
+    hq = workspace.get("rows_h", (Rq, D), od, dev)
+    ops.layernorm_bf16(xq, g1, b1, eps, hq, None)
+    qb = workspace.get("rows_q", (Rq, D), od, dev)
+    ops.gemm(hq, bf16_weight(mha.in_proj_weight)[:D], _f32(mha.in_proj_bias)[:D], qb, PV_EPI_BIAS_BF16, M=Rq, qcols=D, qscale=float(dh) ** -0.5)
+    att = workspace.get("rows_att", (Rq, D), od, dev)
+    ops.attention_rows(qb, kv, att, B, S, nq, H, dh)
+    x1 = workspace.get("rows_x1", (Rq, D), torch.float32, dev)
+    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, PV_EPI_BIAS_RES_F32, M=Rq, res=xq)
+    ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, hq, None)
+    g = workspace.get("rows_g", (Rq, M), od, dev)
+    ops.gemm(hq, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=Rq)
+    out = torch.empty((B, nq, D), dtype=torch.float32, device=dev)
+    ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(Rq, D), PV_EPI_BIAS_RES_F32, M=Rq, res=x1)
+    return out
+
+
 def _block_forward_x3(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor]) -> torch.Tensor:
     """The same block in precision mode "bf16x3": split LN outputs / GELU outputs / attention outputs, split weights,
     fp32 q|k|v and exact-fp32 attention.  Residual stream, LayerNorm, softmax, GELU are fp32 as in the default mode."""
@@ -502,13 +572,19 @@ def _block_forward_x3(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Op
     return out
 
 
-def run_layers(layers: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+def run_layers(layers: nn.Sequential, x: torch.Tensor, last_rows: int = 0) -> torch.Tensor:
     """Run an encoder's `layers` on the MI355X path, telling every block which LayerNorm its consumer applies first so the
     producer can fuse it (peephole over ADJACENT blocks only: `layers` stays an ordinary nn.Sequential).
     A consumer that transforms its input before ln_1 (RankViT block with an active budget, ResidualViT gated block,
-    NoiseBlock, ...) gets no hint and simply normalises itself."""
+    NoiseBlock, ...) gets no hint and simply normalises itself.
+    last_rows = n > 0: the caller reads the first n rows of every image of the result only (a model forward: the class tokens), so a
+    last block that knows how (`_pv_forward_rows`) returns [B,n,D] instead of [B,S,D]."""
     mods = list(layers)
     for i, layer in enumerate(mods):
+        if last_rows > 0 and i + 1 == len(mods) and x.shape[1] > last_rows and getattr(layer, "_pv_forward_rows", None) is not None:
+            rows = layer._pv_forward_rows(x, last_rows)
+            if rows is not None:
+                return rows
         nxt = mods[i + 1] if i + 1 < len(mods) else None
         hint = None
         if nxt is not None and getattr(nxt, "_pv_plain_ln1", None) is not None and nxt._pv_plain_ln1():

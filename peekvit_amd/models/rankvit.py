@@ -49,6 +49,14 @@ class RankViTBlock(ViTBlock):
             input = self.sort_and_drop(input)
         return super().forward(input)
 
+    def _pv_forward_rows(self, input: torch.Tensor, nq: int):
+        """Last block of a model forward: rank / drop as forward() does, then only the class-token row of the block's output."""
+        if type(self) is not RankViTBlock or nq != 1 or not self._pv_rows_ok(input):
+            return None
+        if self.current_budget != 1:
+            input = self.sort_and_drop(input)
+        return engine.run_guarded(self, input, lambda: engine.block_forward_rows(self, input, self.ln_1.eps, nq))
+
     def set_budget(self, budget: float):
         self.current_budget = budget
 
@@ -73,10 +81,10 @@ class RankViTEncoder(nn.Module):
                                                                          attention_dropout), num_layers)
         self.ln = nn.LayerNorm(hidden_dim)
 
-    def forward(self, input: torch.Tensor, _pos_added: bool = False):
+    def forward(self, input: torch.Tensor, _pos_added: bool = False, _rows: int = 0):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
-            return engine.run_layers(self.layers, input)
+            return engine.run_layers(self.layers, input, last_rows=_rows)
         return self.ln(self.layers(self.dropout(input + self.pos_embedding)))
 
 
@@ -108,7 +116,8 @@ class RankVisionTransformer(_ViTBase):
                 tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True)
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x), _pos_added=True)))
+            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x), _pos_added=True,
+                                                                                                   _rows=self.num_class_tokens)))
         return self._composite_head(self.encoder(self._composite_tokens(x)))
 
     def set_budget(self, budget: float):

@@ -42,6 +42,15 @@ class ViTBlock(nn.Module):
         """True when this block applies ln_1 directly to its input (so a producer may pre-compute it)."""
         return True
 
+    def _pv_forward_rows(self, input: torch.Tensor, nq: int):
+        """engine.run_layers, last block of a model forward: the output rows [0, nq) of every image only, or None (= run forward())."""
+        if type(self) is not ViTBlock or not self._pv_rows_ok(input):
+            return None
+        return engine.run_guarded(self, input, lambda: engine.block_forward_rows(self, input, self.ln_1.eps, nq))
+
+    def _pv_rows_ok(self, input: torch.Tensor) -> bool:
+        return input.dim() == 3 and engine.rows_only_ok(self) and engine.backend_for(input, self, self._p_drop) == "hip"
+
     def _composite(self, tokens: torch.Tensor) -> torch.Tensor:
         attn = self.dropout(self.self_attention(self.ln_1(tokens)))
         mid = attn + tokens
@@ -74,13 +83,14 @@ class ViTEncoder(nn.Module):
             lambda i: ViTBlock(num_heads, hidden_dim, mlp_dim, dropout, attention_dropout), num_layers)
         self.ln = nn.LayerNorm(hidden_dim)
 
-    def forward(self, input: torch.Tensor, _pos_added: bool = False):
+    def forward(self, input: torch.Tensor, _pos_added: bool = False, _rows: int = 0):
         """`_pos_added` is private to this package: the fused patch-embedding epilogue has already added
-        pos_embedding, so the add (and the inactive dropout) is skipped."""
+        pos_embedding, so the add (and the inactive dropout) is skipped.  `_rows` (private too): the caller reads rows [0, _rows) of
+        every image only, the last block may return just those."""
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
             # MI355X path: the final LayerNorm is applied to the class-token rows only, by pool_and_head
-            return engine.run_layers(self.layers, input)
+            return engine.run_layers(self.layers, input, last_rows=_rows)
         return self.ln(self.layers(self.dropout(input + self.pos_embedding)))
 
 
@@ -192,5 +202,5 @@ class VisionTransformer(_ViTBase):
 
     def _hip_forward(self, x: torch.Tensor):
         tokens = engine.embed_tokens(self, x)                      # im2col + GEMM (+bias +pos), cls rows
-        tokens = self.encoder(tokens, _pos_added=True)             # blocks dispatch themselves
+        tokens = self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens)      # blocks dispatch themselves
         return engine.pool_and_head(self, tokens)                  # LN on CLS rows, sum, fp32 head

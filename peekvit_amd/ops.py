@@ -234,6 +234,21 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: 
     return out
 
 
+def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int, S: int, nq: int, H: int, dh: int):
+    """softmax(q k^T) v for the first `nq` rows of every image only: q 16-bit [B*nq, H*dh] (scaled), kv 16-bit [B*S, >= 2*H*dh] (k | v),
+    out 16-bit [B*nq, H*dh].  Row strides are taken from the tensors (2-D views of wider buffers allowed)."""
+    for t, name in ((q, "q"), (kv, "kv"), (out, "out")):
+        if not (t.is_cuda and t.dtype == _lib.operand_dtype() and t.dim() == 2 and t.stride(1) == 1):
+            raise _lib.PeekvitHipError(f"attention_rows: {name} must be a 2-D GPU tensor of the operand type with unit column stride")
+    if q.shape[0] != B * nq or out.shape[0] != B * nq or kv.shape[0] != B * S or kv.shape[1] < 2 * H * dh:
+        raise _lib.PeekvitHipError("attention_rows: shape mismatch")
+    with _timed("pv_attention_rows_bf16", q.device, 4.0 * B * H * nq * S * dh, 4.0 * B * S * H * dh + 4.0 * B * nq * H * dh):
+        check(_lib.load().pv_attention_rows_bf16(_ptr(q), q.stride(0), _ptr(kv), kv.stride(0), _ptr(out), out.stride(0),
+                                                 B, S, nq, H, dh, _stream(q)), "pv_attention_rows_bf16")
+    _count()
+    return out
+
+
 def cls_pool(x: torch.Tensor, gamma, beta, eps: float, num_cls: int) -> torch.Tensor:
     B, S, D = x.shape
     pooled = torch.empty((B, D), dtype=torch.float32, device=x.device)

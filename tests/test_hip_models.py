@@ -207,7 +207,8 @@ def test_full_batch_properties_vit_b_16(monkeypatch):
 
 
 def test_default_path_with_fused_layernorm_meets_the_contract():
-    """At larger batches the default path has ONE LayerNorm launch (block 0's ln_1): ViT-B/16 folds the others into its GEMMs
+    """At larger batches the default path has ONE all-token LayerNorm launch (block 0's ln_1; plus the last block's two launches on its
+    class-token rows): ViT-B/16 folds the others into its GEMMs
     (pv_rowstat_finalize runs), the narrow models compute them in the full-row GEMM epilogue.  Logits against the fp32 CPU oracle (= the
     reference's arithmetic) at BASELINE's 1e-3."""
     from peekvit_amd import ops
@@ -219,7 +220,7 @@ def test_default_path_with_fused_layernorm_meets_the_contract():
             got = m(x.to(DEV)).float().cpu()
         torch.cuda.synchronize()
         ks = kt.summary()
-        assert ("pv_rowstat_finalize" in ks) == folds and ks["pv_layernorm_bf16"]["launches"] == 1, (name, sorted(ks))
+        assert ("pv_rowstat_finalize" in ks) == folds and ks["pv_layernorm_bf16"]["launches"] == 1 + 2, (name, sorted(ks))
         torch.set_num_threads(16)
         with torch.no_grad():
             ref = O.vit_forward(x, sd, cfg, "fp32")
@@ -321,9 +322,41 @@ def test_layernorm_folding_on_off(monkeypatch):
             ref = m(x)
     torch.cuda.synchronize()
     ks, ks0 = kt.summary(), kt0.summary()
-    assert "pv_rowstat_finalize" in ks and ks["pv_layernorm_bf16"]["launches"] == 1          # only block 0's ln_1 is a LayerNorm launch
-    assert "pv_rowstat_finalize" not in ks0 and ks0["pv_layernorm_bf16"]["launches"] == 2 * cfg["num_layers"]
+    # all-token LayerNorm launches: block 0's ln_1 only; the last block normalises its class-token rows in two small launches more
+    assert "pv_rowstat_finalize" in ks and ks["pv_layernorm_bf16"]["launches"] == 1 + 2
+    assert "pv_rowstat_finalize" not in ks0 and ks0["pv_layernorm_bf16"]["launches"] == 2 * cfg["num_layers"] + 1
     assert rel_l2(got.cpu(), ref.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("kind,name,batch,extra", [("vit", "vit_b_16", 56, {}), ("vit", "vit_tiny", 5, {}), ("vit", "vit_micro", 3, {"num_class_tokens": 2}),
+                                                   ("rank", "vit_b_16", 56, {"rankvit_layers": [3, 6, 9]}),
+                                                   ("rank", "vit_tiny", 4, {"rankvit_layers": [1, 3]})])
+def test_last_block_computes_class_token_rows_only(monkeypatch, kind, name, batch, extra):
+    """A model forward reads only the class-token rows of the last block's output (models/vit.py:242-246), so that block computes k | v for
+    every token but q, out-proj and the MLP for the class-token rows alone (engine.block_forward_rows).  Same logits as the all-rows
+    block to the operand-rounding noise; a forward hook on the block (someone looks at its output) switches the shortcut off."""
+    from peekvit_amd import engine, ops
+    cfg, m = _model(kind, name, **extra)
+    if kind == "rank":
+        m.set_budget(0.5)
+    x = _x(cfg, batch).to(DEV)
+    with torch.no_grad():
+        with ops.KernelTimer() as kt:
+            got = m(x)
+        seen = []
+        h = m.encoder.layers[-1].register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+        with ops.KernelTimer() as kth:
+            hooked = m(x)
+        h.remove()
+        monkeypatch.setattr(engine, "_LAST_BLOCK_ROWS", False)
+        with ops.KernelTimer() as kt0:
+            ref = m(x)
+    torch.cuda.synchronize()
+    assert kt.summary()["pv_attention_rows_bf16"]["launches"] == 1 and kt.summary()["pv_attention_bf16"]["launches"] == cfg["num_layers"] - 1
+    assert "pv_attention_rows_bf16" not in kt0.summary() and kt0.summary()["pv_attention_bf16"]["launches"] == cfg["num_layers"]
+    assert "pv_attention_rows_bf16" not in kth.summary() and len(seen) == 1 and seen[0][0] == batch and seen[0][1] > extra.get("num_class_tokens", 1)
+    assert torch.equal(hooked, ref)
+    assert rel_l2(got.cpu(), ref.cpu()) < 5e-4
 
 
 def test_rank_norms_come_from_the_fc2_epilogue(monkeypatch):

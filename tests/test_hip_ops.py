@@ -232,6 +232,47 @@ def test_attention_spiked_scores(ops):
     assert rel_l2(out.float().cpu(), ref) < 3e-3
 
 
+@pytest.mark.parametrize("B,S,H,dh,nq", [(3, 197, 12, 64, 1), (2, 197, 3, 64, 2), (2, 26, 12, 64, 1), (1, 1, 1, 64, 1), (2, 5, 2, 32, 1),
+                                         (2, 401, 8, 32, 3), (2, 99, 8, 48, 1), (1, 577, 2, 128, 1), (2, 50, 3, 96, 2), (1, 7, 4, 80, 1)])
+def test_attention_rows(ops, B, S, H, dh, nq):
+    """Attention for the first nq rows of every image only (the last encoder block): k | v of all tokens in a [B*S, 2D] buffer,
+    q of the wanted rows in its own; softmax weights stay fp32, so the only rounding is the 16-bit output."""
+    D = H * dh
+    qkv = T(f"rqkv{S}{H}{dh}", (B, S, 3 * D), scale=1.0)
+    qkv[..., :D] *= dh ** -0.5
+    qkv[0, 0, :dh] = 3.0                   # a query with a few dominant keys (running-max rescale inside and across the lane groups)
+    qkv[0, S - 1, D:D + dh] = 3.0
+    qkv = qkv.to(torch.bfloat16).float()
+    q = qkv[:, :nq, :D].reshape(B * nq, D).contiguous()
+    wide = torch.zeros((B * S, 2 * D + 64), dtype=torch.bfloat16, device=DEV)      # row stride wider than 2D: a view into a larger buffer
+    wide[:, :2 * D] = qkv[..., D:].reshape(B * S, 2 * D).to(torch.bfloat16).to(DEV)
+    out = torch.full((B * nq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention_rows(bf(q), wide[:, :2 * D], out, B, S, nq, H, dh)
+    qh, kh, vh = (t.reshape(B, S, H, dh).transpose(1, 2).double() for t in qkv.split(D, dim=-1))
+    exact = (torch.softmax(qh[:, :, :nq] @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B * nq, D)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), exact) < 3e-3
+    # the full kernel's rows agree (it rounds the softmax weights to 16 bits, this one does not)
+    full = torch.empty((B, S, D), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(torch.bfloat16).to(DEV), full, B, S, H, dh)
+    assert rel_l2(out.float().cpu(), full[:, :nq].reshape(B * nq, D).float().cpu()) < 8e-3
+
+
+def test_attention_rows_rejects_bad_arguments(ops):
+    from peekvit_amd._lib import PeekvitHipError
+    q = torch.zeros((2, 64), dtype=torch.bfloat16, device=DEV)
+    kv = torch.zeros((10, 128), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros((2, 64), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(PeekvitHipError):
+        ops.attention_rows(q, kv[:, :64], out, 2, 5, 1, 1, 64)          # no room for v
+    with pytest.raises(PeekvitHipError):
+        ops.attention_rows(q, kv, out, 2, 4, 1, 1, 64)                  # B*S rows expected
+    with pytest.raises(PeekvitHipError):
+        ops.attention_rows(q.float(), kv, out, 2, 5, 1, 1, 64)          # operand type
+    with pytest.raises(PeekvitHipError):
+        ops.attention_rows(q, kv, out, 2, 5, 1, 1, 40)                  # head width not built
+
+
 def test_cls_pool_and_head(ops):
     B, S, D, C = 5, 9, 256, 1000
     x = T("cp", (B, S, D), scale=1.5, bf16=False)
