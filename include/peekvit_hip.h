@@ -168,6 +168,13 @@ int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, 
 int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B,
                            int64_t S, int64_t nq, int64_t H, int64_t dh, void* stream);
 
+/* Backward of pv_attention_rows_bf16 for nq = 1 (one class token; other nq: PV_ERR_UNSUPPORTED).  out = the forward's result, dout = its
+ * gradient; dq [B, lddq] is the gradient of the UNSCALED q (times qscale, like pv_attention_bwd_bf16), dkv [B*S, lddkv] = dk | dv of every
+ * token.  Part of loss.backward() (train/train.py:118) for the last encoder block. */
+int pv_attention_rows_bwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, const uint16_t* out, int64_t ldo,
+                               const uint16_t* dout, int64_t lddo, uint16_t* dq, int64_t lddq, uint16_t* dkv, int64_t lddkv, int64_t B,
+                               int64_t S, int64_t nq, int64_t H, int64_t dh, float qscale, void* stream);
+
 /* ---- precision mode "bf16x3" (opt-in): split operands v = hi + lo, concatenated along K so that the
  * SAME bf16 MFMA GEMM computes a_hi.w_hi + a_lo.w_hi + a_hi.w_lo; meets the 1e-3 logits tolerance at ~3x the GEMM work. ---- */
 

@@ -929,6 +929,156 @@ extern "C" int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint
     }
 }
 
+// Backward of pv_attn_rows_kernel for ONE query row per image (nq = 1: the class token).  One wave per (image, head):
+//   pass 1  (m, l) of the softmax over the keys (same online form as the forward), delta = dout . out
+//   pass 2  per key j: p = exp(s_j - m) / l, dp = dout . v_j, ds = p (dp - delta);  dv_j = p dout,  dk_j = ds q  (written straight to the key's row
+//           of dkv: no reduction, every key has one query),  dq += ds k_j (reduced over the lane groups at the end, times qscale: the
+//           gradient of the UNSCALED in-projection output, like pv_attn_bwd_kernel).
+// HBM-bound: k | v read twice (the second pass from the L2 / MALL for most heads), dk | dv written once.
+template <int DH>
+__global__ __launch_bounds__(256) void pv_attn_rows_bwd_kernel(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kv, int64_t ldkv,
+                                                               const uint16_t* __restrict__ out, int64_t ldo, const uint16_t* __restrict__ dout, int64_t lddo,
+                                                               uint16_t* __restrict__ dq, int64_t lddq, uint16_t* __restrict__ dkv, int64_t lddkv,
+                                                               int S, int H, float qscale, int64_t total) {
+    constexpr int NCH = DH / 8;
+    constexpr int CPL = NCH <= 4 ? 4 : (NCH <= 8 ? 8 : 16);
+    constexpr int KPI = 64 / CPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= total) return;
+    const int h = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int c = lane % CPL, g = lane / CPL;
+    const bool act = c < NCH;
+    const int cc = act ? c : 0;
+    const int64_t vcol = (int64_t)H * DH;
+    const int col = h * DH + cc * 8;
+
+    float qf[8], df[8];
+    float delta = 0.f;
+    {
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + b * ldq + col);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(dout + b * lddo + col);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(out + b * ldo + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qf[2 * i] = act ? pv_unpack_lo(qv[i]) : 0.f;
+            qf[2 * i + 1] = act ? pv_unpack_hi(qv[i]) : 0.f;
+            df[2 * i] = act ? pv_unpack_lo(dv[i]) : 0.f;
+            df[2 * i + 1] = act ? pv_unpack_hi(dv[i]) : 0.f;
+            delta += df[2 * i] * pv_unpack_lo(ov[i]) + df[2 * i + 1] * pv_unpack_hi(ov[i]);
+        }
+#pragma unroll
+        for (int d = 1; d < CPL; d <<= 1) delta += __shfl_xor(delta, d, 64);
+    }
+    const uint16_t* kbase = kv + (b * S) * ldkv + col;
+    uint16_t* dbase = dkv + (b * S) * lddkv + col;
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 4
+    for (int j0 = 0; j0 < S; j0 += KPI) {
+        const int key = j0 + g;
+        const bool valid = key < S;
+        const u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(valid ? key : S - 1) * ldkv);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += qf[2 * i] * pv_unpack_lo(kk[i]) + qf[2 * i + 1] * pv_unpack_hi(kk[i]);
+#pragma unroll
+        for (int d = 1; d < CPL; d <<= 1) s += __shfl_xor(s, d, 64);
+        if (valid) {
+            const float mn = fmaxf(m, s);
+            l = l * __expf(m - mn) + __expf(s - mn);
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int d = CPL; d < 64; d <<= 1) {
+        const float m2 = __shfl_xor(m, d, 64), l2 = __shfl_xor(l, d, 64);
+        const float mn = fmaxf(m, m2);
+        l = l * (m == -INFINITY ? 0.f : __expf(m - mn)) + l2 * (m2 == -INFINITY ? 0.f : __expf(m2 - mn));
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    float dqa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dqa[i] = 0.f;
+#pragma unroll 4
+    for (int j0 = 0; j0 < S; j0 += KPI) {
+        const int key = j0 + g;
+        const bool valid = key < S;
+        const int64_t off = (int64_t)(valid ? key : S - 1) * ldkv;
+        const u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + off);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(kbase + off + vcol);
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s += qf[2 * i] * pv_unpack_lo(kk[i]) + qf[2 * i + 1] * pv_unpack_hi(kk[i]);
+            dp += df[2 * i] * pv_unpack_lo(vv[i]) + df[2 * i + 1] * pv_unpack_hi(vv[i]);
+        }
+#pragma unroll
+        for (int d = 1; d < CPL; d <<= 1) {
+            s += __shfl_xor(s, d, 64);
+            dp += __shfl_xor(dp, d, 64);
+        }
+        const float pr = __expf(s - m) * inv;
+        const float ds = pr * (dp - delta);
+        if (valid && act) {
+            u32x4 rk, rv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rk[i] = pv_pack_bf16x2(ds * qf[2 * i], ds * qf[2 * i + 1]);
+                rv[i] = pv_pack_bf16x2(pr * df[2 * i], pr * df[2 * i + 1]);
+            }
+            *reinterpret_cast<u32x4*>(dbase + (int64_t)key * lddkv) = rk;
+            *reinterpret_cast<u32x4*>(dbase + (int64_t)key * lddkv + vcol) = rv;
+        }
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dqa[2 * i] += ds * pv_unpack_lo(kk[i]);
+                dqa[2 * i + 1] += ds * pv_unpack_hi(kk[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = CPL; d < 64; d <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dqa[i] += __shfl_xor(dqa[i], d, 64);
+    }
+    if (g == 0 && act) {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = pv_pack_bf16x2(dqa[2 * i] * qscale, dqa[2 * i + 1] * qscale);
+        *reinterpret_cast<u32x4*>(dq + b * lddq + col) = r;
+    }
+}
+
+template <int DH>
+static int pv_launch_attn_rows_bwd(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, const uint16_t* out, int64_t ldo, const uint16_t* dout,
+                                   int64_t lddo, uint16_t* dq, int64_t lddq, uint16_t* dkv, int64_t lddkv, int64_t B, int S, int H, float qscale,
+                                   hipStream_t stream) {
+    const int64_t total = B * H;
+    PV_LAUNCH(pv_attn_rows_bwd_kernel<DH>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, q, ldq, kv, ldkv, out, ldo, dout, lddo, dq, lddq, dkv,
+              lddkv, S, H, qscale, total);
+    return pv_check_launch();
+}
+
+extern "C" int pv_attention_rows_bwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, const uint16_t* out, int64_t ldo,
+                                          const uint16_t* dout, int64_t lddo, uint16_t* dq, int64_t lddq, uint16_t* dkv, int64_t lddkv, int64_t B,
+                                          int64_t S, int64_t nq, int64_t H, int64_t dh, float qscale, void* stream) {
+    if (!q || !kv || !out || !dout || !dq || !dkv || B <= 0 || S <= 0 || nq <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)q | (uintptr_t)kv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dkv) & 15) return PV_ERR_INVALID_ARG;
+    if ((ldq | ldkv | ldo | lddo | lddq | lddkv) & 7) return PV_ERR_INVALID_ARG;
+    if (ldq < H * dh || ldo < H * dh || lddo < H * dh || lddq < H * dh || ldkv < 2 * H * dh || lddkv < 2 * H * dh) return PV_ERR_INVALID_ARG;
+    if (nq != 1 || B * H > 0x7fffffffLL * 4 || S > 0x3fffffff) return PV_ERR_UNSUPPORTED;      // one query row per image (the class token)
+    hipStream_t s = (hipStream_t)stream;
+#define PV_ROWS_BWD(N) case N: return pv_launch_attn_rows_bwd<N>(q, ldq, kv, ldkv, out, ldo, dout, lddo, dq, lddq, dkv, lddkv, B, (int)S, (int)H, qscale, s);
+    switch (dh) {
+        PV_ROWS_BWD(32) PV_ROWS_BWD(48) PV_ROWS_BWD(64) PV_ROWS_BWD(80) PV_ROWS_BWD(96) PV_ROWS_BWD(128)
+        default: return PV_ERR_UNSUPPORTED;
+    }
+#undef PV_ROWS_BWD
+}
+
 extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return PV_ERR_INVALID_ARG;

@@ -51,11 +51,13 @@ class RankViTBlock(ViTBlock):
 
     def _pv_forward_rows(self, input: torch.Tensor, nq: int):
         """Last block of a model forward: rank / drop as forward() does, then only the class-token row of the block's output."""
-        if type(self) is not RankViTBlock or nq != 1 or not self._pv_rows_ok(input):
+        if type(self) is not RankViTBlock or nq != 1 or input.dim() != 3 or not engine.rows_only_ok(self):
+            return None
+        if not (train_engine.train_eligible(input, self, self._p_drop) or engine.backend_for(input, self, self._p_drop) == "hip"):
             return None
         if self.current_budget != 1:
             input = self.sort_and_drop(input)
-        return engine.run_guarded(self, input, lambda: engine.block_forward_rows(self, input, self.ln_1.eps, nq))
+        return self._pv_rows(input, nq)
 
     def set_budget(self, budget: float):
         self.current_budget = budget
@@ -113,7 +115,7 @@ class RankVisionTransformer(_ViTBase):
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
             with engine.on_device(x):
-                tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True)
+                tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x), _pos_added=True,

@@ -44,12 +44,20 @@ class ViTBlock(nn.Module):
 
     def _pv_forward_rows(self, input: torch.Tensor, nq: int):
         """engine.run_layers, last block of a model forward: the output rows [0, nq) of every image only, or None (= run forward())."""
-        if type(self) is not ViTBlock or not self._pv_rows_ok(input):
+        if type(self) is not ViTBlock:
+            return None
+        return self._pv_rows(input, nq)
+
+    def _pv_rows(self, input: torch.Tensor, nq: int):
+        if input.dim() != 3 or not engine.rows_only_ok(self):
+            return None
+        if train_engine.train_eligible(input, self, self._p_drop):
+            if nq == 1 and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]):
+                return train_engine.block_forward_rows_train(self, input)
+            return None
+        if engine.backend_for(input, self, self._p_drop) != "hip":
             return None
         return engine.run_guarded(self, input, lambda: engine.block_forward_rows(self, input, self.ln_1.eps, nq))
-
-    def _pv_rows_ok(self, input: torch.Tensor) -> bool:
-        return input.dim() == 3 and engine.rows_only_ok(self) and engine.backend_for(input, self, self._p_drop) == "hip"
 
     def _composite(self, tokens: torch.Tensor) -> torch.Tensor:
         attn = self.dropout(self.self_attention(self.ln_1(tokens)))
@@ -194,7 +202,7 @@ class VisionTransformer(_ViTBase):
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
             with engine.on_device(x):
                 tokens = train_engine.embed_tokens_train(self, x)  # same kernels, recorded for loss.backward()
-                tokens = self.encoder(tokens, _pos_added=True)
+                tokens = self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             return engine.run_guarded(self, x, lambda: engine.forward_split(x, self._hip_forward))

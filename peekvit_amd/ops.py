@@ -249,6 +249,21 @@ def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int,
     return out
 
 
+def attention_rows_bwd(q, kv, out, dout, dq, dkv, B: int, S: int, H: int, dh: int, qscale: float):
+    """Backward of attention_rows for one query row per image: q, out, dout, dq 16-bit [B, H*dh]; kv, dkv 16-bit [B*S, >= 2*H*dh]."""
+    for t, name in ((q, "q"), (kv, "kv"), (out, "out"), (dout, "dout"), (dq, "dq"), (dkv, "dkv")):
+        if not (t.is_cuda and t.dtype == _lib.operand_dtype() and t.dim() == 2 and t.stride(1) == 1):
+            raise _lib.PeekvitHipError(f"attention_rows_bwd: {name} must be a 2-D GPU tensor of the operand type with unit column stride")
+    if any(t.shape[0] != B for t in (q, out, dout, dq)) or kv.shape[0] != B * S or dkv.shape[0] != B * S:
+        raise _lib.PeekvitHipError("attention_rows_bwd: shape mismatch")
+    with _timed("pv_attention_rows_bwd_bf16", q.device, 10.0 * B * H * S * dh, 2.0 * 3 * 2 * B * S * H * dh):
+        check(_lib.load().pv_attention_rows_bwd_bf16(_ptr(q), q.stride(0), _ptr(kv), kv.stride(0), _ptr(out), out.stride(0), _ptr(dout), dout.stride(0),
+                                                     _ptr(dq), dq.stride(0), _ptr(dkv), dkv.stride(0), B, S, 1, H, dh, float(qscale), _stream(q)),
+              "pv_attention_rows_bwd_bf16")
+    _count()
+    return dq, dkv
+
+
 def cls_pool(x: torch.Tensor, gamma, beta, eps: float, num_cls: int) -> torch.Tensor:
     B, S, D = x.shape
     pooled = torch.empty((B, D), dtype=torch.float32, device=x.device)

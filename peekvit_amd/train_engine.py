@@ -320,6 +320,108 @@ def block_forward_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
                          blk.mlp.fc2.weight, blk.mlp.fc2.bias)
 
 
+class RowsBlockFn(torch.autograd.Function):
+    """The LAST encoder block of a model forward in training, class-token row only: [B,S,D] -> [B,1,D] (engine.block_forward_rows is the
+    inference counterpart).  The head reads that row alone (models/vit.py:242-246), so the gradient of every other output row is zero and
+    the reference's backward through them multiplies zeros.  All-token work left: LN1, the k|v two thirds of the in-projection and their
+    backward; everything else runs on B rows.
+      forward   h1 = LN1(x) | kv = h1.Wkv^T+b | q = h1[cls].Wq^T+b (scaled) | att = attention_rows(q, kv) | x1 = x[cls] + att.Wo^T+b
+                h2 = LN2(x1) | [gl | pre] = fc1 pair | out = x1 + gl.W2^T+b                  saved: x, h1, kv, q, att, x1, h2, [gl | pre]
+      backward  as BlockFn on B rows down to datt; (dq, dkv) = attention_rows'(q, kv, att, datt); dWin = [dq^T.h1[cls] ; dkv^T.h1];
+                dh1 = dkv.Wkv (+ dq.Wq on the class rows); dx = LN1'(dh1) (+ dx1 on the class rows)."""
+
+    @staticmethod
+    def forward(ctx, blk, x, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+        x = x.float() if x.dtype != torch.float32 else x
+        x = x if x.is_contiguous() else x.contiguous()
+        B, S, D = x.shape
+        mha = blk.self_attention.self_attention
+        H = mha.num_heads
+        dh = D // H
+        Mh = blk.mlp.fc1.out_features
+        R, dev, eps, bf = B * S, x.device, blk.ln_1.eps, torch.bfloat16
+        qscale = float(dh) ** -0.5
+        h1 = torch.empty((R, D), dtype=bf, device=dev)
+        kv = torch.empty((R, 2 * D), dtype=bf, device=dev)
+        q = torch.empty((B, D), dtype=bf, device=dev)
+        att = torch.empty((B, D), dtype=bf, device=dev)
+        x1 = torch.empty((B, D), dtype=torch.float32, device=dev)
+        h2 = torch.empty((B, D), dtype=bf, device=dev)
+        pair = torch.empty((B, 2 * Mh), dtype=bf, device=dev)
+        gl = pair[:, :Mh]
+        out = torch.empty((B, 1, D), dtype=torch.float32, device=dev)
+        w_in = bf16_weight(mha.in_proj_weight)
+        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1)
+        ops.gemm(h1, w_in[D:], _f32(inb)[D:], kv, PV_EPI_BIAS_BF16, M=R)
+        ops.gemm(h1.view(B, S, D)[:, 0], w_in[:D], _f32(inb)[:D], q, PV_EPI_BIAS_BF16, M=B, qcols=D, qscale=qscale)
+        ops.attention_rows(q, kv, att, B, S, 1, H, dh)
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), x1, PV_EPI_BIAS_RES_F32, M=B, res=x[:, 0])
+        ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2)
+        ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=B)
+        ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(B, D), PV_EPI_BIAS_RES_F32, M=B, res=x1)
+        ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.save_for_backward(x, h1, kv, q, att, x1, h2, pair)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        x, h1, kv, q, att, x1, h2, pair = ctx.saved_tensors
+        B, S, D, H, dh, Mh, qscale = ctx.dims
+        gl, pre = pair[:, :Mh], pair[:, Mh:]
+        mha = blk.self_attention.self_attention
+        R, dev, bf, f32 = B * S, x.device, torch.bfloat16, torch.float32
+        ws = workspace
+        dout = (dout.float() if dout.dtype != f32 else dout).contiguous().view(B, D)
+        # ---- MLP branch, class rows ---------------------------------------------------------------------------
+        d2 = ops.cast_bf16(dout, torch.empty((B, D), dtype=bf, device=dev))
+        dw2, db2 = _wgrad(d2, gl, "fc2")
+        dpre = torch.empty((B, Mh), dtype=bf, device=dev)
+        db1 = torch.empty((Mh,), dtype=f32, device=dev)
+        ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=B, res=pre, tag="[dgrad]", colsum_out=db1)
+        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
+        dhq = torch.empty((B, D), dtype=bf, device=dev)
+        ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhq, PV_EPI_BIAS_BF16, M=B, tag="[dgrad]")
+        dx1 = torch.empty((B, D), dtype=f32, device=dev)
+        dgb2 = torch.empty((3, D), dtype=f32, device=dev)
+        d1 = torch.empty((B, D), dtype=bf, device=dev)
+        ops.layernorm_bwd(x1, dhq, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
+        # ---- attention branch ---------------------------------------------------------------------------------
+        dwo, _ = _wgrad(d1, att, "proj", bias_grad=False)
+        datt = torch.empty((B, D), dtype=bf, device=dev)
+        ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=B, tag="[dgrad]")
+        dq = torch.empty((B, D), dtype=bf, device=dev)
+        dkv = ws.get("bw_dqkv", (R, 2 * D), bf, dev)
+        ops.attention_rows_bwd(q, kv, att, datt, dq, dkv, B, S, H, dh, qscale)
+        dbin = torch.empty((3 * D,), dtype=f32, device=dev)
+        ops.colsum(dq, dbin[:D])
+        ops.colsum(dkv, dbin[D:])
+        h1c = h1.view(B, S, D)[:, 0]                                           # LN1 output of the class rows (row-strided view)
+        dwin = torch.cat([_wgrad(dq, h1c, "q", bias_grad=False)[0], _wgrad(dkv, h1, "qkv", bias_grad=False)[0]], dim=0)
+        wt = bf16_weight_t(mha.in_proj_weight)                                 # [D, 3D]
+        dhid = ws.get("bw_dh", (R, D), bf, dev)
+        ops.gemm(dkv, wt[:, D:], None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
+        dhc = torch.empty((B, D), dtype=bf, device=dev)
+        ops.gemm(dq, wt[:, :D], None, dhc, PV_EPI_BIAS_BF16, M=B, tag="[dgrad]")
+        dhid.view(B, S, D)[:, 0] += dhc
+        dx = torch.empty((B, S, D), dtype=f32, device=dev)
+        dgb1 = torch.empty((3, D), dtype=f32, device=dev)
+        dxb = torch.empty((B, S, D), dtype=bf, device=dev)
+        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), None, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        dx[:, 0] += dx1                                                        # the residual path exists for the class rows only
+        dxb[:, 0] = dx[:, 0]
+        dgb1[2] += dx1.sum(0)
+        dx._pv_bf16 = (dxb, dx._version, dgb1[2])
+        return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+
+
+def block_forward_rows_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    mha = blk.self_attention.self_attention
+    return RowsBlockFn.apply(blk, x, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                             mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+
+
 class EmbedFn(torch.autograd.Function):
     """Patch embedding + class/register tokens + positional embedding (reference models/vit.py:203-236, :92) with backward:
     dW_conv = dpatch^T . im2col(img), db_conv = colsum(dpatch), dpos = sum_b dtok[b], dcls = dpos[:n_cls]."""

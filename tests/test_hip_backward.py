@@ -97,6 +97,34 @@ def test_attention_backward(ops, B, S, H, dh):
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
 
 
+@pytest.mark.parametrize("B,S,H,dh", [(3, 197, 12, 64), (2, 26, 12, 64), (2, 1, 2, 64), (2, 5, 2, 32), (2, 401, 8, 32), (3, 99, 8, 48), (1, 50, 3, 96),
+                                      (2, 130, 2, 128)])
+def test_attention_rows_backward(ops, B, S, H, dh):
+    """Backward of the class-token-row attention (last encoder block): dq (gradient of the unscaled q), dk | dv of every token, against fp32
+    autograd on the same 16-bit values."""
+    D = H * dh
+    qscale = dh ** -0.5
+    q = (_bf(B, D, seed=S).float() * qscale).to(torch.bfloat16)
+    kv = _bf(B * S, 2 * D, seed=S + 1)
+    dout = _bf(B, D, seed=S + 2, scale=0.1)
+    out = torch.empty((B, D), device="cuda", dtype=torch.bfloat16)
+    ops.attention_rows(q, kv, out, B, S, 1, H, dh)
+    dq = torch.full((B, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    wide = torch.full((B * S, 2 * D + 8), float("nan"), device="cuda", dtype=torch.bfloat16)       # row stride wider than 2D
+    dkv = wide[:, :2 * D]
+    ops.attention_rows_bwd(q, kv, out, dout, dq, dkv, B, S, H, dh, qscale)
+    qf = q.float().view(B, H, 1, dh).requires_grad_(True)
+    kf = kv[:, :D].float().view(B, S, H, dh).transpose(1, 2).contiguous().requires_grad_(True)
+    vf = kv[:, D:].float().view(B, S, H, dh).transpose(1, 2).contiguous().requires_grad_(True)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2), -1) @ vf).transpose(1, 2).reshape(B, D)
+    assert rel_l2(out.float(), ref) < 3e-3
+    (ref * dout.float()).sum().backward()
+    assert torch.isfinite(dq.float()).all() and torch.isfinite(dkv.float()).all()
+    assert rel_l2(dq.float(), qf.grad.reshape(B, D) * qscale) < 6e-3
+    assert rel_l2(dkv[:, :D].float(), kf.grad.transpose(1, 2).reshape(B * S, D)) < 6e-3
+    assert rel_l2(dkv[:, D:].float(), vf.grad.transpose(1, 2).reshape(B * S, D)) < 6e-3
+
+
 def test_transpose_padded(ops):
     x = _bf(197, 72, seed=5)
     y = ops.transpose(x, pad_to=64)
@@ -189,6 +217,34 @@ def test_training_step_gradients(monkeypatch, name, B):
         worst = max(worst, err)
         assert err < 3e-2, (n, err)
     print("worst parameter-gradient rel-L2:", worst)
+
+
+@pytest.mark.parametrize("name,B", [("vit_micro", 6), ("vit_tiny", 5), ("vit_b_16", 3)])
+def test_last_block_class_row_backward_matches_all_rows(monkeypatch, name, B):
+    """Training: the last block computes (and differentiates) the class-token row only (train_engine.RowsBlockFn).  Every parameter
+    gradient and the loss against the SAME HIP path with the all-rows last block: the two differ by 16-bit rounding of a few
+    intermediates only (the reference's backward through the other rows multiplies zeros)."""
+    from peekvit_amd import engine, ops
+    cfg, (m_rows, m_all), x, y = _train_pair(name, B)
+    with ops.KernelTimer() as kt:
+        loss_r = torch.nn.functional.cross_entropy(m_rows(x), y)
+        loss_r.backward()
+    monkeypatch.setattr(engine, "_LAST_BLOCK_ROWS", False)
+    with ops.KernelTimer() as kt0:
+        loss_a = torch.nn.functional.cross_entropy(m_all(x), y)
+        loss_a.backward()
+    torch.cuda.synchronize()
+    ks, ks0 = kt.summary(), kt0.summary()
+    assert ks["pv_attention_rows_bwd_bf16"]["launches"] == 1 and ks["pv_attention_bwd_bf16"]["launches"] == cfg["num_layers"] - 1
+    assert "pv_attention_rows_bwd_bf16" not in ks0 and ks0["pv_attention_bwd_bf16"]["launches"] == cfg["num_layers"]
+    assert abs(loss_r.item() - loss_a.item()) < 2e-3 * abs(loss_a.item())
+    worst = 0.0
+    for (n, pr), (_, pa) in zip(m_rows.named_parameters(), m_all.named_parameters()):
+        assert pr.grad is not None and pr.grad.shape == pa.grad.shape and torch.isfinite(pr.grad).all(), n
+        err = rel_l2(pr.grad, pa.grad)
+        worst = max(worst, err)
+        assert err < 1.5e-2, (n, err)
+    print("worst parameter-gradient rel-L2, class-row last block vs all rows:", worst)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048, 768, 256), (4096, 1536, 384), (2300, 128, 64)])
