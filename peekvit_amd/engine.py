@@ -485,14 +485,14 @@ def rows_only_ok(blk: nn.Module) -> bool:
             and not _m._global_forward_hooks and not _m._global_forward_pre_hooks)
 
 
-def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int) -> torch.Tensor:
+def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The block's output for the FIRST `nq` ROWS of every image only: [B,S,D] -> [B,nq,D].
 
     For the last encoder block of a model forward, whose consumer (pool_and_head) reads the class-token rows alone
     (models/vit.py:242-246; the reference computes all S rows and drops S - nq of them).  Rows of a block are independent except
     through attention, which needs k and v of every token but q of the wanted rows only - so the all-token work left is LN1 and the
     k|v two thirds of the in-projection; out-proj, LN2 and the MLP run on B*nq rows.  Same arithmetic per surviving row as block_forward
-    (fp32 softmax weights instead of 16-bit ones in the attention)."""
+    (fp32 softmax weights instead of 16-bit ones in the attention).  row_scale [B,S] as in block_forward (ResidualViT)."""
     if x.dtype != torch.float32:
         x = x.float()
     fold_in, handoff = getattr(x, "_pv_fold", None), getattr(x, "_pv_ln", None)
@@ -500,6 +500,8 @@ def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int) -> 
         fold_in = None
     if not x.is_contiguous():
         x, fold_in, handoff = x.contiguous(), None, None
+    if row_scale is not None:
+        fold_in, handoff = None, None
     B, S, D = x.shape
     mha = blk.self_attention.self_attention
     H = mha.num_heads
@@ -521,22 +523,26 @@ def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int) -> 
             h = handoff[0]
         else:
             h = workspace.get("h", (R, D), od, dev)
-            ops.layernorm_bf16(x, g1, b1, eps, h, None)
+            ops.layernorm_bf16(x, g1, b1, eps, h, row_scale)
         ops.gemm(h, bf16_weight(mha.in_proj_weight)[D:], _f32(mha.in_proj_bias)[D:], kv, PV_EPI_BIAS_BF16, M=R)
 
     # q of the wanted rows, then everything else on B*nq rows
     xq = workspace.get("rows_x", (B, nq, D), torch.float32, dev)
     xq.copy_(x[:, :nq])
     xq = xq.view(Rq, D)
+    rsq = None
+    if row_scale is not None:
+        rsq = workspace.get("rows_rs", (B, nq), torch.float32, dev)
+        rsq.copy_(row_scale.view(B, S)[:, :nq])
     hq = workspace.get("rows_h", (Rq, D), od, dev)
-    ops.layernorm_bf16(xq, g1, b1, eps, hq, None)
+    ops.layernorm_bf16(xq, g1, b1, eps, hq, rsq)
     qb = workspace.get("rows_q", (Rq, D), od, dev)
     ops.gemm(hq, bf16_weight(mha.in_proj_weight)[:D], _f32(mha.in_proj_bias)[:D], qb, PV_EPI_BIAS_BF16, M=Rq, qcols=D, qscale=float(dh) ** -0.5)
     att = workspace.get("rows_att", (Rq, D), od, dev)
     ops.attention_rows(qb, kv, att, B, S, nq, H, dh)
     x1 = workspace.get("rows_x1", (Rq, D), torch.float32, dev)
-    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, PV_EPI_BIAS_RES_F32, M=Rq, res=xq)
-    ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, hq, None)
+    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, PV_EPI_BIAS_RES_F32, M=Rq, res=xq, row_scale=rsq)
+    ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, hq, rsq)
     g = workspace.get("rows_g", (Rq, M), od, dev)
     ops.gemm(hq, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=Rq)
     out = torch.empty((B, nq, D), dtype=torch.float32, device=dev)

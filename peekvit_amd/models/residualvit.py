@@ -141,14 +141,27 @@ class ResidualViTBlock(ResidualModule):
             y = y + torch.cat([torch.zeros_like(special), img * (1 - self.mask)], dim=1)
         return y
 
-    def _hip_gated_block(self, input: torch.Tensor):
+    def _hip_gated_block(self, input: torch.Tensor, rows: int = 0):
         x = input if input.is_contiguous() else input.contiguous()
         gate, bgate = self.residual_gate.projection, self.budget_token_gate
         masked = torch.empty_like(x)
         self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
                                                  bgate.weight.detach(), bgate.bias.detach(),
                                                  self.residual_gate.temp, self.residual_gate.sigmoid_bias)
+        if rows:
+            return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale)
         return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale)
+
+    def _pv_forward_rows(self, input: torch.Tensor, nq: int):
+        """engine.run_layers, last block of a model forward (inference): the gate still sees every token and `self.mask` is the full mask,
+        the block's output is computed for the class-token rows only."""
+        if type(self) is not ResidualViTBlock or input.dim() != 3 or not engine.rows_only_ok(self) or nq > self.num_special_tokens:
+            return None
+        if self.skip == 'attention+mlp' and self._hip_gated(input):
+            return engine.run_guarded(self, input, lambda: self._hip_gated_block(input, rows=nq))
+        if self.skip not in ('attention', 'mlp', 'attention+mlp') and engine.backend_for(input, self, self._p_drop) == "hip":
+            return engine.run_guarded(self, input, lambda: engine.block_forward_rows(self, input, self.ln_1.eps, nq))
+        return None
 
     def plain_forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None):
         """Masked pre-LN block: the mask multiplies LN1's output, the attention branch and LN2's output
@@ -202,10 +215,10 @@ class ResidualViTEncoder(nn.Module):
                                        gate_threshold=gate_threshold, budget_token=budget_token), num_layers)
         self.ln = nn.LayerNorm(hidden_dim)
 
-    def forward(self, input: torch.Tensor, _pos_added: bool = False):
+    def forward(self, input: torch.Tensor, _pos_added: bool = False, _rows: int = 0):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
         if _pos_added:
-            return engine.run_layers(self.layers, input)      # gated blocks publish no _pv_plain_ln1: they normalise themselves
+            return engine.run_layers(self.layers, input, last_rows=_rows)      # gated blocks publish no _pv_plain_ln1: they normalise themselves
         if self.budget_token:
             body, btok = input[:, :-self.num_budget_tokens], input[:, -self.num_budget_tokens:]
             input = torch.cat([body + self.pos_embedding, btok], dim=1)
@@ -293,7 +306,8 @@ class ResidualVisionTransformer(_ViTBase):
             if self.add_budget_token == 'learnable':
                 assert self.current_budget is not None, 'Budget token not set. Call set_budget() before forward() to evaluate the model on a chosen budget.'
                 btok, budget = self.learnable_budget_token_1.detach().view(-1), float(self.current_budget)
-            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True)))
+            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True,
+                                                                                                   _rows=self.num_class_tokens)))
         if (self.training and train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout))
                 and train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length + (1 if self.add_budget_token else 0))):
             # training on the MI355X kernels end to end: patch embedding (+ class tokens, + pos_embedding) and its backward are the

@@ -330,19 +330,22 @@ def test_layernorm_folding_on_off(monkeypatch):
 
 @pytest.mark.parametrize("kind,name,batch,extra", [("vit", "vit_b_16", 56, {}), ("vit", "vit_tiny", 5, {}), ("vit", "vit_micro", 3, {"num_class_tokens": 2}),
                                                    ("rank", "vit_b_16", 56, {"rankvit_layers": [3, 6, 9]}),
-                                                   ("rank", "vit_tiny", 4, {"rankvit_layers": [1, 3]})])
+                                                   ("rank", "vit_tiny", 4, {"rankvit_layers": [1, 3]}),
+                                                   ("res", "vit_b_16", 9, dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable",
+                                                                               gate_threshold=0.5))])
 def test_last_block_computes_class_token_rows_only(monkeypatch, kind, name, batch, extra):
     """A model forward reads only the class-token rows of the last block's output (models/vit.py:242-246), so that block computes k | v for
     every token but q, out-proj and the MLP for the class-token rows alone (engine.block_forward_rows).  Same logits as the all-rows
     block to the operand-rounding noise; a forward hook on the block (someone looks at its output) switches the shortcut off."""
     from peekvit_amd import engine, ops
     cfg, m = _model(kind, name, **extra)
-    if kind == "rank":
+    if kind == "rank" or extra.get("add_budget_token"):
         m.set_budget(0.5)
     x = _x(cfg, batch).to(DEV)
     with torch.no_grad():
         with ops.KernelTimer() as kt:
             got = m(x)
+        masks = [blk.mask.clone() for blk in m.encoder.layers if getattr(blk, "mask", None) is not None]
         seen = []
         h = m.encoder.layers[-1].register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
         with ops.KernelTimer() as kth:
@@ -357,6 +360,8 @@ def test_last_block_computes_class_token_rows_only(monkeypatch, kind, name, batc
     assert "pv_attention_rows_bf16" not in kth.summary() and len(seen) == 1 and seen[0][0] == batch and seen[0][1] > extra.get("num_class_tokens", 1)
     assert torch.equal(hooked, ref)
     assert rel_l2(got.cpu(), ref.cpu()) < 5e-4
+    masks0 = [blk.mask for blk in m.encoder.layers if getattr(blk, "mask", None) is not None]
+    assert len(masks) == len(masks0) and all(torch.equal(a, b) for a, b in zip(masks, masks0))      # ResidualViT: the full masks either way
 
 
 def test_rank_norms_come_from_the_fc2_epilogue(monkeypatch):
