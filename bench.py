@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE.json configs[2]/[4]: a step = forward + cross-entropy + backward (HIP backward kernels); with N > 1 "
                          "ranks the parameter gradients are all-reduced over RCCL (data-parallel training path)")
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="--train: stop the step after loss.backward() (+ all-reduce).  Default: the reference's whole step (train/train.py:112-121) "
+                         "- zero_grad, forward, cross-entropy, backward, [all-reduce], clip_grad_norm_(1.0), Adam(1e-3).step()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64, help="images of the CPU-oracle sample (64: large enough that the GPU path scored "
                                                                 "against it takes the same kernels / LayerNorm folding as the timed batch)")
@@ -172,7 +175,8 @@ def main():
     infer_model = model
     flops_img = synth.fwd_flops_per_image(cfg, seqs) * (3 if args.train else 1)      # backward = dgrad + wgrad = 2x forward
     if args.train:
-        workload = workload.replace("forward", "fwd+bwd (cross-entropy, parameter gradients" + (f", gradient all-reduce over {args.dist_backend})" if world > 1 else ")"))
+        workload = workload.replace("forward", "train step (fwd, cross-entropy, bwd" + (f", gradient all-reduce over {args.dist_backend}" if world > 1 else "")
+                                    + (")" if args.no_optimizer else ", clip 1.0, Adam)"))
 
     # random (never zero-filled) device-resident input, bf16-representable like the parity fixtures
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -192,14 +196,22 @@ def main():
         n_buckets = 0
         reducer = pvdist.OverlappedGradReducer(infer.parameters(), bucket_bytes=args.bucket_kib << 10) if dist else None      # ~25 MB buckets leave during backward
 
+        # the reference's optimizer (configs/optimizer/adam.yaml: torch.optim.Adam, lr 1e-3) and clip (train/train.py:120); stock
+        # multi-tensor PyTorch kernels over the 86.6 M fp32 parameters - plumbing around the path, ~1 % of the step
+        params = [p for p in infer.parameters() if p.requires_grad]
+        opt = None if args.no_optimizer else torch.optim.Adam(params, lr=1e-3, fused=True)
+
         def train_step(inp):
             nonlocal n_buckets
-            for p in infer.parameters():
+            for p in params:
                 p.grad = None
             logits = infer(inp)
             torch.nn.functional.cross_entropy(logits, y).backward()
             if dist:
                 n_buckets = reducer.finish()
+            if opt is not None:
+                torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
+                opt.step()
             return logits.detach()
 
         model = train_step

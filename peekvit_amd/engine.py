@@ -178,7 +178,7 @@ def _check_ln_range(ln: nn.LayerNorm):
     """fp16 operands only: |LayerNorm(x)| <= max|gamma| * sqrt(D) + max|beta| must fit fp16 (checked once per parameter version)."""
     if _lib.OPERAND != "f16":
         return
-    key, ver = id(ln), (ln.weight._version, ln.bias._version, ln.weight.data_ptr())
+    key, ver = id(ln), (pver(ln.weight), pver(ln.bias), ln.weight.data_ptr())
     ent = _lnok.get(key)
     if ent is None or ent[0] != ver:
         D = ln.normalized_shape[0]
@@ -247,13 +247,36 @@ def use_workspace(ws: "_Workspace"):
 # ------------------------------------------------------------------------------------------------
 _wcache: Dict[tuple, tuple] = {}      # (id(param), operand) -> (weakref, version, data_ptr, cast tensor, (stream, event) | None)
 
+# Cached derivatives of a parameter (16-bit copies, transposes, folded weights, LayerNorm bounds) are keyed by the tensor's autograd version
+# counter - which fused optimizers do NOT advance: torch.optim.Adam(fused=True).step() rewrites the parameters with `_version` unchanged
+# (measured, torch 2.10).  Every optimizer step of any torch optimizer therefore also advances `_opt_generation`, which is part of the
+# key of every tensor that requires grad.
+_opt_generation = 0
+
+
+def _on_optimizer_step(*_args, **_kwargs):
+    global _opt_generation
+    _opt_generation += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_on_optimizer_step)
+except ImportError:                    # pragma: no cover - torch < 2.0
+    pass
+
+
+def pver(p: torch.Tensor) -> tuple:
+    """What a cached derivative of `p` is valid for: (autograd version, optimizer generation if p is trainable)."""
+    return (p._version, _opt_generation if p.requires_grad else 0)
+
 
 def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes.  The cast is a launch on the
     current stream: a hit from ANOTHER stream (forward_split) first waits for the event recorded behind that cast."""
     key = (id(p), _lib.OPERAND)
     ent = _wcache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+    if ent is not None and ent[0]() is p and ent[1] == pver(p) and ent[2] == p.data_ptr():
         if ent[4] is not None:
             cur = torch.cuda.current_stream(p.device)
             if ent[4][1].query():
@@ -271,7 +294,7 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     if _STREAMS > 1 and not torch.cuda.is_current_stream_capturing():
         ev = (torch.cuda.current_stream(p.device).cuda_stream, torch.cuda.Event())
         ev[1].record()
-    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), p._version, p.data_ptr(), w, ev)
+    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), pver(p), p.data_ptr(), w, ev)
     return w
 
 
@@ -286,12 +309,12 @@ def bf16x3_weight(p: torch.Tensor) -> torch.Tensor:
     """[w_hi | w_hi | w_lo] along K (bf16 [N, 3K]) of an fp32 parameter, refreshed when it changes."""
     key = id(p)
     ent = _w3cache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+    if ent is not None and ent[0]() is p and ent[1] == pver(p) and ent[2] == p.data_ptr():
         return ent[3]
     src = p.detach()
     src = (src if src.is_contiguous() else src.contiguous()).view(src.shape[0], -1)
     w = ops.split3(src, 1)
-    _w3cache[key] = (weakref.ref(p, lambda _r, k=key: _w3cache.pop(k, None)), p._version, p.data_ptr(), w)
+    _w3cache[key] = (weakref.ref(p, lambda _r, k=key: _w3cache.pop(k, None)), pver(p), p.data_ptr(), w)
     return w
 
 
@@ -326,7 +349,7 @@ def _ln_fusable(D: int, K: int) -> bool:
 
 
 def _ln_key(ln: nn.LayerNorm):
-    return (id(ln.weight), ln.weight._version, ln.bias._version, float(ln.eps))
+    return (id(ln.weight), pver(ln.weight), pver(ln.bias), float(ln.eps))
 
 
 # LayerNorm FOLDING (default since round 2 where every token GEMM of a block runs on the 256-row tile kernel, i.e. large batches;
@@ -348,7 +371,7 @@ _foldcache: Dict[Tuple[int, int, str], tuple] = {}
 def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
     """(W' = operand(gamma (.) W) [N,D], c1 = sum_k W'[n,k], c2 = W beta + b) cached per (weight, LayerNorm, operand type) version."""
     key = (id(w), id(ln.weight), _lib.OPERAND)
-    ver = (w._version, b._version if b is not None else -1, ln.weight._version, ln.bias._version, w.data_ptr())
+    ver = (pver(w), pver(b) if b is not None else -1, pver(ln.weight), pver(ln.bias), w.data_ptr())
     ent = _foldcache.get(key)
     if ent is not None and ent[0] == ver:
         return ent[1]

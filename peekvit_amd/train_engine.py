@@ -31,7 +31,7 @@ from torch import nn
 
 from . import ops
 from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_GELU_GRAD_BF16)
-from .engine import _f32, bf16_weight, workspace
+from .engine import _f32, bf16_weight, pver, workspace
 
 _wtcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
 
@@ -40,10 +40,10 @@ def bf16_weight_t(p: torch.Tensor) -> torch.Tensor:
     """bf16 TRANSPOSE [K, N] of an fp32 [N, K] parameter (the 'weight' of the data-gradient GEMM), cached per version."""
     key = id(p)
     ent = _wtcache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2] == p.data_ptr():
+    if ent is not None and ent[0]() is p and ent[1] == pver(p) and ent[2] == p.data_ptr():
         return ent[3]
     wt = ops.transpose(bf16_weight(p))
-    _wtcache[key] = (weakref.ref(p, lambda _r, k=key: _wtcache.pop(k, None)), p._version, p.data_ptr(), wt)
+    _wtcache[key] = (weakref.ref(p, lambda _r, k=key: _wtcache.pop(k, None)), pver(p), p.data_ptr(), wt)
     return wt
 
 

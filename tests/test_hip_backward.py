@@ -219,6 +219,44 @@ def test_training_step_gradients(monkeypatch, name, B):
     print("worst parameter-gradient rel-L2:", worst)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_weight_caches_follow_optimizer_steps(fused):
+    """torch.optim.Adam(fused=True).step() rewrites the parameters WITHOUT advancing their autograd version counter (torch 2.10), so the
+    16-bit weight copies / transposes must not be keyed by that counter alone: after every step the HIP forward has to see the new weights."""
+    from peekvit_amd import engine
+    cfg, (m, _), x, y = _train_pair("vit_tiny", 4)
+    params = list(m.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2, fused=fused)
+    w = m.encoder.layers[0].mlp.fc1.weight
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        before = w.detach().clone()
+        opt.step()
+        assert not torch.equal(before, w.detach())
+        assert torch.equal(engine.bf16_weight(w).float(), w.detach().to(torch.bfloat16).float())          # the cache was refreshed
+        with torch.no_grad(), engine.precision("bf16"):
+            hip = m.eval()(x)
+            m.train()
+        ref = _composite_logits(m, x)
+        assert rel_l2(hip, ref) < 2e-2                                                                    # bf16 operands vs the fp32 composite
+
+
+def _composite_logits(m, x):
+    import os
+    old = os.environ.get("PEEKVIT_AMD_BACKEND")
+    os.environ["PEEKVIT_AMD_BACKEND"] = "torch"
+    try:
+        with torch.no_grad():
+            return m.eval()(x)
+    finally:
+        m.train()
+        if old is None:
+            del os.environ["PEEKVIT_AMD_BACKEND"]
+        else:
+            os.environ["PEEKVIT_AMD_BACKEND"] = old
+
+
 @pytest.mark.parametrize("name,B", [("vit_micro", 6), ("vit_tiny", 5), ("vit_b_16", 3)])
 def test_last_block_class_row_backward_matches_all_rows(monkeypatch, name, B):
     """Training: the last block computes (and differentiates) the class-token row only (train_engine.RowsBlockFn).  Every parameter
