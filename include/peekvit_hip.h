@@ -201,7 +201,7 @@ int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_
 /* bf16 [R,C] (row stride lds >= C) -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be
  * a multiple of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
 /* colsum_out (fp32 [C], optional): also the column sums of src (the bias gradient when src = dY), from the same pass;
- * colsum_ws: fp32 scratch [ceil(ldd/1024)*C], required with colsum_out. */
+ * colsum_ws: fp32 scratch [ceil(ldd/q)*C] with q = 64 for ldd <= 65536, else 1024; required with colsum_out. */
 int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R, int64_t C, int64_t ldd, float* colsum_out,
                       float* colsum_ws, void* stream);
 /* LayerNorm backward (models/blocks.py:60,77): x fp32 [rows,D] (the saved LN input), dy bf16 [rows,D], gamma fp32 [D];
@@ -225,7 +225,7 @@ int pv_masked_residual(const float* x, const uint16_t* u, const float* row_scale
 int pv_gelu_bf16(const uint16_t* pre, uint16_t* out, int64_t n, void* stream);
 int pv_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dg, uint16_t* dpre, int64_t n, void* stream);
 /* Column sums of a bf16 (C % 8 == 0) or fp32 (C % 4 == 0) [R,C] matrix into fp32 [C] (bias gradients: db = sum_m dY[m,:]);
- * ws: fp32 scratch [ceil(R/1024)*C]. */
+ * ws: fp32 scratch [ceil(R/q)*C] with q = 64 for R <= 65536, else 1024 (short matrices are cut finer so that they fill the chip). */
 int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float* ws, int64_t R, int64_t C, int accumulate, void* stream);
 
 /* Backward of pv_gather_tokens (models/rankvit.py:55-77 under loss.backward()): dy fp32 [B,1+k,D], keep int32 [B,k] ->

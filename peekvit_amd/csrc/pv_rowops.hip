@@ -193,11 +193,11 @@ extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_el
 // to ws[chunk][C] (bias gradient = column sums of the dY being transposed for the weight gradient; pv_colsum stage 2 ends it).
 template <bool VEC, bool CSUM>
 __global__ __launch_bounds__(256) void pv_transpose_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int64_t C,
-                                                           int64_t lds, int64_t ldd, float* __restrict__ ws) {
+                                                           int64_t lds, int64_t ldd, float* __restrict__ ws, int crows) {
     __shared__ uint16_t tile[64][72];          // 144-byte rows: 16-byte aligned chunks, 36-bank pitch
     __shared__ float red[32][65];
     const int64_t c0 = (int64_t)blockIdx.x * 64;
-    const int64_t rbeg = (int64_t)blockIdx.y * 1024, rend = rbeg + 1024 < ldd ? rbeg + 1024 : ldd;
+    const int64_t rbeg = (int64_t)blockIdx.y * crows, rend = rbeg + crows < ldd ? rbeg + crows : ldd;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int rr = threadIdx.x >> 3, ch = threadIdx.x & 7;
     for (int64_t r0 = rbeg; r0 < rend; r0 += 64) {
@@ -263,33 +263,36 @@ extern "C" int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst
                                  float* colsum_ws, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || ldd < R || lds < C) return PV_ERR_INVALID_ARG;
     if (colsum_out && !colsum_ws) return PV_ERR_INVALID_ARG;
-    const int64_t chunks = (ldd + 1023) / 1024;
+    const int crows = ldd <= 65536 ? 64 : 1024;          // source rows per workgroup: a weight matrix (<= 4096 rows) would otherwise be 12-48 workgroups
+    const int64_t chunks = (ldd + crows - 1) / crows;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)chunks);
     if (chunks > 65535 || C > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     const bool vec = C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
     hipStream_t s = (hipStream_t)stream;
     if (colsum_out) {
-        if (vec) PV_LAUNCH((pv_transpose_kernel<true, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws);
-        else PV_LAUNCH((pv_transpose_kernel<false, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws);
+        if (vec) PV_LAUNCH((pv_transpose_kernel<true, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws, crows);
+        else PV_LAUNCH((pv_transpose_kernel<false, true>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, colsum_ws, crows);
         if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
         PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, (const float*)colsum_ws, colsum_out, chunks, (int)C, 0);
     } else {
-        if (vec) PV_LAUNCH((pv_transpose_kernel<true, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr);
-        else PV_LAUNCH((pv_transpose_kernel<false, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr);
+        if (vec) PV_LAUNCH((pv_transpose_kernel<true, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr, crows);
+        else PV_LAUNCH((pv_transpose_kernel<false, false>), grid, dim3(256), 0, s, src, dst, R, C, lds, ldd, (float*)nullptr, crows);
     }
     return pv_check_launch();
 }
 
-// Column sums, stage 1: a workgroup owns a 1024-row chunk x 512-column (bf16: 8 per lane) / 256-column (fp32: 4 per lane)
-// strip; its 4 waves interleave the rows with 16-byte loads and combine through LDS into ws[chunk][C].  Stage 2 sums the
-// chunks: a workgroup per 64 columns, 4 waves striding the chunk list.
+// Column sums, stage 1: a workgroup owns a chunk of `crows` rows (1024; 64 for short matrices, which would otherwise fill a tenth of the
+// chip) x 512-column (bf16: 8 per lane) / 256-column (fp32: 4 per lane) strip; its 4 waves interleave the rows with 16-byte loads and
+// combine through LDS into ws[chunk][C].  Stage 2 sums the chunks: a workgroup per 64 columns, 4 waves striding the chunk list.
+static inline int64_t pv_colsum_chunk_rows(int64_t R) { return R <= 65536 ? 64 : 1024; }
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void pv_colsum_kernel(const void* __restrict__ src, float* __restrict__ ws, int64_t R, int C) {
+__global__ __launch_bounds__(256) void pv_colsum_kernel(const void* __restrict__ src, float* __restrict__ ws, int64_t R, int C, int crows) {
     constexpr int VW = BF16 ? 8 : 4;
     __shared__ float red[4][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * VW;
-    const int64_t r0 = (int64_t)blockIdx.y * 1024, r1 = r0 + 1024 < R ? r0 + 1024 : R;
+    const int64_t r0 = (int64_t)blockIdx.y * crows, r1 = r0 + crows < R ? r0 + crows : R;
     float acc[VW];
 #pragma unroll
     for (int k = 0; k < VW; ++k) acc[k] = 0.f;
@@ -323,8 +326,18 @@ __global__ __launch_bounds__(256) void pv_colsum_stage2_kernel(const float* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < C)
-        for (int64_t t = wave; t < chunks; t += 4) s += ws[t * C + c];
+    if (c < C) {
+        // eight independent loads in flight per lane: the chunk list is up to ~400 long and a dependent chain of L2 round trips paced this
+        // kernel (43 us for 19 MB at r2's first profile)
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int64_t t = wave;
+        for (; t + 28 < chunks; t += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ws[(t + 4 * u) * C + c];
+        }
+        for (; t < chunks; t += 4) a[0] += ws[t * C + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && c < C) {
@@ -337,11 +350,12 @@ extern "C" int pv_colsum_f32(const void* src, int src_is_bf16, float* out, float
     if (!src || !out || !ws || R <= 0 || C <= 0) return PV_ERR_INVALID_ARG;
     const int vw = src_is_bf16 ? 8 : 4;
     if (C % vw || ((uintptr_t)src & 15) || C > 0x7fffffff) return PV_ERR_UNSUPPORTED;
-    const int64_t chunks = (R + 1023) / 1024;
+    const int64_t crows = pv_colsum_chunk_rows(R);
+    const int64_t chunks = (R + crows - 1) / crows;
     if (chunks > 65535) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((C / vw + 63) / 64), (unsigned)chunks);
-    if (src_is_bf16) PV_LAUNCH(pv_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
-    else PV_LAUNCH(pv_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C);
+    if (src_is_bf16) PV_LAUNCH(pv_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C, (int)crows);
+    else PV_LAUNCH(pv_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ws, R, (int)C, (int)crows);
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
     PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, out, chunks, (int)C, accumulate);
     return pv_check_launch();

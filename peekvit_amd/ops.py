@@ -304,7 +304,8 @@ def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int
     if out is None:
         out = torch.empty((Cc, ldd), dtype=_lib.operand_dtype(), device=src.device)
     assert out.shape == (Cc, ldd) and out.is_contiguous()
-    ws = torch.empty(((ldd + 1023) // 1024, Cc), dtype=torch.float32, device=src.device) if colsum_out is not None else None
+    q = 64 if ldd <= 65536 else 1024                     # source rows per workgroup (include/peekvit_hip.h)
+    ws = torch.empty(((ldd + q - 1) // q, Cc), dtype=torch.float32, device=src.device) if colsum_out is not None else None
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
         check(_lib.load().pv_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), R, Cc, ldd, _ptr(colsum_out), _ptr(ws), _stream(src)),
               "pv_transpose_bf16")
@@ -317,7 +318,8 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
     assert src.dtype in (_lib.operand_dtype(), torch.float32) and src.is_contiguous()
     _chk(out, torch.float32, "out")
     R, Cc = src.shape
-    ws = torch.empty(((R + 1023) // 1024, Cc), dtype=torch.float32, device=src.device)
+    q = 64 if R <= 65536 else 1024                       # chunk height of stage 1 (include/peekvit_hip.h)
+    ws = torch.empty(((R + q - 1) // q, Cc), dtype=torch.float32, device=src.device)
     with _timed("pv_colsum_f32", src.device, 0.0, float(src.element_size() * src.numel())):
         check(_lib.load().pv_colsum_f32(_ptr(src), int(src.dtype == _lib.operand_dtype()), _ptr(out), _ptr(ws), R, Cc, int(accumulate),
                                         _stream(src)), "pv_colsum_f32")
