@@ -536,9 +536,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     char* const Ks = smem + IMG;
     char* const Vs = smem + 2 * IMG;
     char* const Os = smem + 3 * IMG;
-    float* const st_m = reinterpret_cast<float*>(smem + 4 * IMG);     // row max (of the raw scores), 1/l, D per query
-    float* const st_i = st_m + SP;
-    float* const st_d = st_i + SP;
+    float* const st_m = reinterpret_cast<float*>(smem + 4 * IMG);     // per query: log2(1/l) - m log2(e), and D
+    float* const st_d = st_m + SP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
@@ -550,21 +549,23 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     uint16_t* gb = dqkv + (int64_t)b * S * ld + h * DH;
 
     // ---- stage the four images; rows >= S are zero: zero Q / dO rows make every padded-query contribution vanish ------
-    for (int e = tid; e < SP * CPR; e += NW * 64) {
-        const int row = e / CPR, c = e - row * CPR;
-        u32x4 q = {0u, 0u, 0u, 0u}, k = q, v = q, o = q;
-        if (row < S && c * 8 < DH) {
-            const uint16_t* rp = qb + (int64_t)row * ld + c * 8;
-            q = *reinterpret_cast<const u32x4*>(rp);
-            k = *reinterpret_cast<const u32x4*>(rp + D);
-            v = *reinterpret_cast<const u32x4*>(rp + 2 * D);
-            o = *reinterpret_cast<const u32x4*>(ob + (int64_t)row * D + c * 8);
+    {
+        for (int e = tid; e < SP * CPR; e += NW * 64) {
+            const int row = e / CPR, c = e - row * CPR;
+            u32x4 q = {0u, 0u, 0u, 0u}, k = q, v = q, o = q;
+            if (row < S && c * 8 < DH) {
+                const uint16_t* rp = qb + (int64_t)row * ld + c * 8;
+                q = *reinterpret_cast<const u32x4*>(rp);
+                k = *reinterpret_cast<const u32x4*>(rp + D);
+                v = *reinterpret_cast<const u32x4*>(rp + 2 * D);
+                o = *reinterpret_cast<const u32x4*>(ob + (int64_t)row * D + c * 8);
+            }
+            const int off = pv_swz<CPR>(row, c);
+            *reinterpret_cast<u32x4*>(Qs + off) = q;
+            *reinterpret_cast<u32x4*>(Ks + off) = k;
+            *reinterpret_cast<u32x4*>(Vs + off) = v;
+            *reinterpret_cast<u32x4*>(Os + off) = o;
         }
-        const int off = pv_swz<CPR>(row, c);
-        *reinterpret_cast<u32x4*>(Qs + off) = q;
-        *reinterpret_cast<u32x4*>(Ks + off) = k;
-        *reinterpret_cast<u32x4*>(Vs + off) = v;
-        *reinterpret_cast<u32x4*>(Os + off) = o;
     }
     __syncthreads();
 
@@ -590,9 +591,6 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { cq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ck[dt] = cq[dt]; cv[dt] = cq[dt]; }
 
-#if defined(PV_ATTN_BWD_STOP) && PV_ATTN_BWD_STOP == 1
-    if (S > 0) return;                       // diagnostic build: staging only
-#endif
     // =============================== pass 1: per 16-query tile ===============================
     for (int qt = wid; qt < nqt; qt += NW) {
         const int q0 = qt << 4;
@@ -641,7 +639,8 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             }
         dd += __shfl_xor(dd, 16, 64);
         dd += __shfl_xor(dd, 32, 64);
-        if (g == 0) { st_m[q0 + i16] = m; st_i[q0 + i16] = inv; st_d[q0 + i16] = dd; }
+        // one statistic per query for pass 2, log2(1/l) - m log2(e): p = exp2(s log2(e) + that), no second LDS read and no multiply per element
+        if (g == 0) { st_m[q0 + i16] = nm + __builtin_amdgcn_logf(inv); st_d[q0 + i16] = dd; }
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -678,9 +677,6 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     }
     __syncthreads();
 
-#if defined(PV_ATTN_BWD_STOP) && PV_ATTN_BWD_STOP == 2
-    if (S > 0) return;                       // diagnostic build: staging + pass 1
-#endif
     // =============================== pass 2: per 16-key tile ===============================
     for (int kt = wid; kt < nqt; kt += NW) {
         const int k0 = kt << 4;
@@ -700,20 +696,24 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
                 c = PV_MFMA_16x16x32(frag(Os, qt, ks), vf[ks], c, 0, 0, 0);
             }
             const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
-            const float4 i4 = *reinterpret_cast<const float4*>(st_i + qt * 16 + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * g);
-            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
             float p[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = key_ok ? __builtin_amdgcn_exp2f((s[r] - mm[r]) * LOG2E) * ii[r] : 0.f;
+                p[r] = key_ok ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, mm[r])) : 0.f;
                 ds[r] = p[r] * (c[r] - dd[r]);
             }
             pw = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
             dw = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
         };
         // q tiles in pairs on the K = 32 MFMA (same slot order on both operands as in pass 1), an odd last tile on the K = 16 form
-#pragma unroll 1
+        // three pairs per iteration at S = 193..208 (two iterations): the LDS reads of the next pair are issued under the MFMAs of this one
+        // (2.28 -> 2.13 ms at ViT-B/16, batch 2048); shorter sequences spill with it (NKT = 7: 0.93 -> 2.07 ms) and keep the rolled loop
+#ifndef PV_ABW_P2_UNROLL
+#define PV_ABW_P2_UNROLL (NKT == 13 ? 3 : 1)
+#endif
+#pragma unroll PV_ABW_P2_UNROLL
         for (int tt = 0; tt < NKT / 2; ++tt) {
             u32x2 p0, d0, p1, d1;
             pds(2 * tt, p0, d0);
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 template <int DH, int NKT>
 static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
-    constexpr int lds = 4 * NKT * 16 * DHP * 2 + 3 * NKT * 16 * 4;
+    constexpr int lds = 4 * NKT * 16 * DHP * 2 + 2 * NKT * 16 * 4;
     constexpr int NW = NKT <= 13 ? 8 : 4;
     static_assert(lds <= 160 * 1024, "Q, K, V, dO of one head must fit the LDS");
     static PvPerDevice attr_set;
