@@ -447,3 +447,31 @@ def test_two_stream_forward_is_bit_identical(monkeypatch):
         with torch.no_grad():
             m.encoder.layers[0].mlp.fc1.weight.mul_(1.0)          # new parameter version: the cast happens on one stream, both use it
         assert torch.equal(m(x), one)
+
+
+def test_device_prefetcher_feeds_the_same_batches():
+    """harness.pipeline.DevicePrefetcher: host batches copied one ahead on a side stream through a reused ring - every batch arrives intact
+    and in order (fp32 NCHW and uint8 NHWC, pinned and pageable, a ragged last batch), and the evaluation loop built on it reports the
+    reference loop's accuracy."""
+    from peekvit_amd.harness.pipeline import DevicePrefetcher
+    from peekvit_amd.harness import test as htest
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(5 if i < 6 else 3, 3, 32, 32, generator=g), torch.randint(0, 10, (5 if i < 6 else 3,), generator=g)) for i in range(7)]
+    for depth in (1, 2):
+        for pin in (False, True):
+            src = [(x.pin_memory(), y.pin_memory()) if pin else (x, y) for x, y in batches]
+            got = []
+            for x, y in DevicePrefetcher(src, DEV, depth=depth):
+                assert x.is_cuda and y.is_cuda
+                got.append((x.square().sum(), y.sum()))            # work on the compute stream that reads the slot
+            assert len(got) == len(batches)
+            for (sx, sy), (x, y) in zip(got, batches):
+                assert abs(float(sx) - float(x.double().square().sum())) < 1e-2 and int(sy) == int(y.sum())
+    u8 = [(torch.randint(0, 256, (4, 32, 32, 3), generator=g, dtype=torch.uint8), torch.zeros(4, dtype=torch.int64)) for _ in range(3)]
+    for (x, _), (xr, _) in zip(DevicePrefetcher(u8, DEV), u8):
+        assert torch.equal(x.cpu(), xr)
+    cfg, m = _model("vit", "vit_micro")
+    data = [(torch.from_numpy(synth.synth_images(4, cfg["image_size"], seed=s)), torch.randint(0, cfg["num_classes"], (4,), generator=g)) for s in range(5)]
+    a = htest.evaluate(m, data, torch.device(DEV), [None], 20, prefetch=True)[0]
+    b = htest.evaluate(m, data, torch.device(DEV), [None], 20, prefetch=False)[0]
+    assert a["accuracy"] == b["accuracy"] and a["device_images_per_second"] > 0
