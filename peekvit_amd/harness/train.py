@@ -28,6 +28,10 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
     loss_fn = torch.nn.CrossEntropyLoss()
     last = float("nan")
     reducer = pdist.OverlappedGradReducer(model.parameters()) if distributed else None   # buckets leave while backward still runs
+    device = torch.device(device)
+    if device.type == "cuda":                              # host -> HBM copy of the next batch under this step (harness.pipeline)
+        from .pipeline import DevicePrefetcher
+        loader = DevicePrefetcher(loader, device)
     for batch, labels in loader:
         batch, labels = batch.to(device), labels.to(device)
         if distributed:                                   # rank r trains on samples r::world of the global batch
@@ -40,7 +44,8 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
         if clip:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         optimizer.step()
-        last = float(loss.item())
+        last = loss.detach()
+    last = float(last) if torch.is_tensor(last) else last   # one read-back per epoch, not one per step
     if reducer is not None:
         reducer.remove()
     return last
