@@ -502,10 +502,13 @@ _LAST_BLOCK_ROWS = os.environ.get("PEEKVIT_AMD_LAST_BLOCK_ROWS", "1") != "0"
 
 def rows_only_ok(blk: nn.Module) -> bool:
     """May the LAST block of a model forward compute only the rows its consumer reads (block_forward_rows)?  Not in mode "bf16x3", and not
-    when someone observes the block's output through a forward hook (they would see [B,nq,D] instead of [B,S,D])."""
+    when someone observes the block's output (or its gradient) through a module hook (they would see [B,nq,D] instead of [B,S,D])."""
     import torch.nn.modules.module as _m
-    return (_LAST_BLOCK_ROWS and _PRECISION != "bf16x3" and not blk._forward_hooks and not blk._forward_pre_hooks
-            and not _m._global_forward_hooks and not _m._global_forward_pre_hooks)
+    if not _LAST_BLOCK_ROWS or _PRECISION == "bf16x3":
+        return False
+    own = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
+    glob = ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks")
+    return not any(getattr(blk, n, None) for n in own) and not any(getattr(_m, n, None) for n in glob)
 
 
 def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
