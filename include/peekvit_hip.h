@@ -277,10 +277,17 @@ int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B,
  *   x_out[b]  = [x[b,0] | mask[b,i] * x[b,1+i] | x[b,S-1]]                  (:220-227, masked_input)
  * x_in: fp32 [B,S,D] (layout [cls | N | budget], one special token); x_out: same shape, may alias x_in;
  * mask_out: fp32 [B,S-2] (block.mask); row_scale: fp32 [B,S] = [1, mask, 1] (:230-235 fwd_mask) for the
- * LN / out-proj epilogues. */
+ * LN / out-proj epilogues.
+ * thr_out: fp32 [B] or NULL - the per-image threshold (what the reference leaves in residual_gate.threshold, :66). */
 int pv_residual_gate(const float* x_in, float* x_out, const float* wg, const float* bg, const float* wb,
-                     const float* bb, float temp, float sigmoid_bias, float* mask_out, float* row_scale,
+                     const float* bb, float temp, float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out,
                      int64_t B, int64_t S, int64_t D, void* stream);
+/* Its backward (training: loss.backward() through the gate).  dx_out = dL/d(x_out) [B,S,D], drow = dL/d(row_scale) [B,S] (the mask
+ * gradient of the masked block plus that of any auxiliary loss on block.mask); dx_in [B,S,D]; parameter gradients as per-image partials
+ * dwg_part, dwb_part fp32 [B,D] and scal_part fp32 [B,4] = (dbg, dbb, 0, 0) - sum them over B (pv_colsum_f32). */
+int pv_residual_gate_bwd(const float* x_in, const float* dx_out, const float* drow, const float* wg, const float* bg, const float* wb,
+                         const float* bb, float temp, float sigmoid_bias, float* dx_in, float* dwg_part, float* dwb_part,
+                         float* scal_part, int64_t B, int64_t S, int64_t D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -945,7 +945,8 @@ __device__ __forceinline__ float pv_sigmoid(float z) { return 1.0f / (1.0f + exp
 template <int NCH>
 __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, float* xo, const float* __restrict__ wg, const float* __restrict__ bg,
                                                                const float* __restrict__ wb, const float* __restrict__ bb, float temp, float sbias,
-                                                               float* __restrict__ mask_out, float* __restrict__ row_scale, int64_t S, int D) {
+                                                               float* __restrict__ mask_out, float* __restrict__ row_scale, float* __restrict__ thr_out,
+                                                               int64_t S, int D) {
     __shared__ float thr_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
     const int64_t b = blockIdx.x, N = S - 2;
@@ -961,6 +962,7 @@ __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, f
             thr_s = pv_sigmoid(s + bb[0]);
             row_scale[b * S] = 1.0f;
             row_scale[b * S + S - 1] = 1.0f;
+            if (thr_out) thr_out[b] = thr_s;
         }
     }
     if (xo != x && wave >= 2) {   // pass the class token and the budget token through unchanged
@@ -1000,12 +1002,131 @@ __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, f
 }
 
 extern "C" int pv_residual_gate(const float* x, float* xo, const float* wg, const float* bg, const float* wb, const float* bb, float temp,
-                                float sigmoid_bias, float* mask_out, float* row_scale, int64_t B, int64_t S, int64_t D, void* stream) {
+                                float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out, int64_t B, int64_t S, int64_t D, void* stream) {
     if (!x || !xo || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
     if (D % 4 || D > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)xo & 15) || ((uintptr_t)wg & 15) || ((uintptr_t)wb & 15)) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)B);
-#define RG_LAUNCH(N) PV_LAUNCH(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, S, (int)D)
+#define RG_LAUNCH(N) PV_LAUNCH(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, thr_out, S, (int)D)
     PV_DISPATCH_NCH(D, RG_LAUNCH);
 #undef RG_LAUNCH
+    return pv_check_launch();
+}
+
+// Backward of pv_residual_gate (loss.backward() through models/residualvit.py:197-235 in training).  G = dL/d(x_out) [B,S,D], dr = dL/d(row_scale)
+// [B,S] (the mask gradient of the masked block and of any auxiliary loss on block.mask; entries of the two special rows are ignored):
+//   patch row:  dm = dr + G . x;  active = sigmoid(..) > thr;  dz = active ? dm * sg (1 - sg) / temp : 0;  dthr -= active ? dm : 0
+//               dx = m G + dz wg;   dwg += dz x;   dbg += dz
+//   budget row: du = dthr * thr (1 - thr);  dx = G + du wb;  dwb = du x;  dbb = du        class row: dx = G
+// One workgroup per image; a wave keeps x and G of its row in registers, so each is read once.  Parameter gradients leave as per-image
+// partials (dwg_part, dwb_part [B,D]; scal_part [B,4] = dbg, dbb, 0, 0) for pv_colsum_f32.
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_residual_gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ G, const float* __restrict__ dr,
+                                                                   const float* __restrict__ wg, const float* __restrict__ bg, const float* __restrict__ wb,
+                                                                   const float* __restrict__ bb, float temp, float sbias, float* __restrict__ dx,
+                                                                   float* __restrict__ dwg_part, float* __restrict__ dwb_part, float* __restrict__ scal_part,
+                                                                   int64_t S, int D) {
+    __shared__ float thr_s, red_s[4][2];
+    __shared__ float4 red_w[3][NCH * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    const int64_t b = blockIdx.x, N = S - 2;
+    const float4* xb4 = reinterpret_cast<const float4*>(x + (b * S + S - 1) * (int64_t)D);
+    if (wave == 0) {
+        float s = 0.f;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float4 v = xb4[idx], w = reinterpret_cast<const float4*>(wb)[idx];
+            s += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+        }
+        s = pv_wave_sum(s);
+        if (lane == 0) thr_s = pv_sigmoid(s + bb[0]);
+    }
+    if (wave == 1) {      // class row: passes through
+        const float4* s4 = reinterpret_cast<const float4*>(G + (b * S) * (int64_t)D);
+        float4* d4 = reinterpret_cast<float4*>(dx + (b * S) * (int64_t)D);
+        for (int idx = lane; idx < nvec; idx += 64) d4[idx] = s4[idx];
+    }
+    __syncthreads();
+    const float thr = thr_s;
+    float4 wv[NCH], acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int idx = lane + 64 * j;
+        wv[j] = idx < nvec ? reinterpret_cast<const float4*>(wg)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float dbg = 0.f, dthr = 0.f;
+    for (int64_t i = wave; i < N; i += 4) {
+        const int64_t row = b * S + 1 + i;
+        RowRegs<NCH> r, g;
+        pv_load_row<NCH>(r, x + row * (int64_t)D, nvec, lane);
+        pv_load_row<NCH>(g, G + row * (int64_t)D, nvec, lane);
+        float s = 0.f, a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            s += (r.v[j].x * wv[j].x + r.v[j].y * wv[j].y) + (r.v[j].z * wv[j].z + r.v[j].w * wv[j].w);
+            a += (r.v[j].x * g.v[j].x + r.v[j].y * g.v[j].y) + (r.v[j].z * g.v[j].z + r.v[j].w * g.v[j].w);
+        }
+        s = pv_wave_sum(s) + bg[0];
+        a = pv_wave_sum(a);
+        const float t = s / temp + sbias;
+        const float sg = pv_sigmoid(t);
+        const float m = fmaxf(sg - thr, 0.f);
+        const float dm = a + dr[row];
+        const bool active = sg - thr > 0.f;
+        // sigmoid'(t) = sigmoid(t) sigmoid(-t): with the reference's sigmoid bias of 10 the gate sits at 1 - 5e-5 and "1 - sg" in fp32
+        // would carry three digits
+        const float dz = active ? dm * sg * pv_sigmoid(-t) / temp : 0.f;
+        if (active) dthr -= dm;
+        dbg += dz;
+        float* dxr = dx + row * (int64_t)D;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                reinterpret_cast<float4*>(dxr)[idx] = make_float4(m * g.v[j].x + dz * wv[j].x, m * g.v[j].y + dz * wv[j].y,
+                                                                  m * g.v[j].z + dz * wv[j].z, m * g.v[j].w + dz * wv[j].w);
+                acc[j].x += dz * r.v[j].x; acc[j].y += dz * r.v[j].y; acc[j].z += dz * r.v[j].z; acc[j].w += dz * r.v[j].w;
+            }
+        }
+    }
+    // combine the four waves: dwg partial of the image, dbg, dthr
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) red_w[wave - 1][lane + 64 * j] = acc[j];
+    }
+    if (lane == 0) { red_s[wave][0] = dbg; red_s[wave][1] = dthr; }      // every lane of a wave holds the same dbg / dthr
+    __syncthreads();
+    if (wave == 0) {
+        const float dbg_t = (red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0]);
+        const float dthr_t = (red_s[0][1] + red_s[1][1]) + (red_s[2][1] + red_s[3][1]);
+        const float du = dthr_t * thr * (1.0f - thr);      // the threshold is a mid-range sigmoid (budget ~ 0.1 .. 0.9): no cancellation here
+        const float4* g4 = reinterpret_cast<const float4*>(G + (b * S + S - 1) * (int64_t)D);
+        float4* d4 = reinterpret_cast<float4*>(dx + (b * S + S - 1) * (int64_t)D);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                const float4 t0 = red_w[0][idx], t1 = red_w[1][idx], t2 = red_w[2][idx];
+                reinterpret_cast<float4*>(dwg_part + b * (int64_t)D)[idx] =
+                    make_float4(acc[j].x + t0.x + t1.x + t2.x, acc[j].y + t0.y + t1.y + t2.y, acc[j].z + t0.z + t1.z + t2.z, acc[j].w + t0.w + t1.w + t2.w);
+                const float4 xv = xb4[idx], gv = g4[idx], w = reinterpret_cast<const float4*>(wb)[idx];
+                d4[idx] = make_float4(gv.x + du * w.x, gv.y + du * w.y, gv.z + du * w.z, gv.w + du * w.w);
+                reinterpret_cast<float4*>(dwb_part + b * (int64_t)D)[idx] = make_float4(du * xv.x, du * xv.y, du * xv.z, du * xv.w);
+            }
+        }
+        if (lane == 0) { scal_part[b * 4] = dbg_t; scal_part[b * 4 + 1] = du; scal_part[b * 4 + 2] = 0.f; scal_part[b * 4 + 3] = 0.f; }
+    }
+}
+
+extern "C" int pv_residual_gate_bwd(const float* x, const float* dxo, const float* drow, const float* wg, const float* bg, const float* wb, const float* bb,
+                                    float temp, float sigmoid_bias, float* dx, float* dwg_part, float* dwb_part, float* scal_part, int64_t B, int64_t S,
+                                    int64_t D, void* stream) {
+    if (!x || !dxo || !drow || !wg || !bg || !wb || !bb || !dx || !dwg_part || !dwb_part || !scal_part || B <= 0 || S < 3 || D <= 0 || temp == 0.f)
+        return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)dxo | (uintptr_t)dx | (uintptr_t)wg | (uintptr_t)wb | (uintptr_t)dwg_part | (uintptr_t)dwb_part) & 15) return PV_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)B);
+#define RGB_LAUNCH(N) PV_LAUNCH(pv_residual_gate_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, dxo, drow, wg, bg, wb, bb, temp, sigmoid_bias, dx, dwg_part, dwb_part, scal_part, S, (int)D)
+    PV_DISPATCH_NCH(D, RGB_LAUNCH);
+#undef RGB_LAUNCH
     return pv_check_launch();
 }

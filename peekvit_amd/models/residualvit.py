@@ -124,9 +124,21 @@ class ResidualViTBlock(ResidualModule):
             y = y + torch.cat([torch.zeros_like(special), img * (1 - self.mask)], dim=1)
         return y
 
+    def _hip_gated_train(self, input: torch.Tensor) -> bool:
+        return (self.gate_type == 'sigmoid' and self.budget_token == 'learnable' and not self.add_input and self.num_special_tokens == 1
+                and input.shape[1] >= 3 and train_engine.train_eligible(input, self, self._p_drop)
+                and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1]))
+
     def forward_skip_attention_mlp(self, input: torch.Tensor):
         if self._hip_gated(input):
             return engine.run_guarded(self, input, lambda: self._hip_gated_block(input))
+        if self._hip_gated_train(input):
+            # training on the MI355X kernels: gate + masking (GateFn) and the masked block (MaskedBlockFn), both with hand-written backward;
+            # block.mask is a view of the gate's output and stays differentiable for the auxiliary mask losses (utils/losses.py)
+            masked, row_scale, thr = train_engine.gate_forward_train(self, input)
+            self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
+            self.residual_gate.threshold = thr.view(-1, 1, 1)                 # what ResidualGate.forward leaves behind (residualvit.py:66)
+            return train_engine.masked_block_forward_train(self, masked, row_scale)
         special, img, btok = self._split(input)
         budget, threshold = None, None
         if self.budget_token:

@@ -510,14 +510,33 @@ def scatter_tokens(dy: torch.Tensor, keep: torch.Tensor, S_in: int) -> torch.Ten
     return dx
 
 
-def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float):
-    """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]."""
+def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float, thr_out: Optional[torch.Tensor] = None):
+    """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]; thr_out (fp32 [B], optional): the thresholds."""
     B, S, D = x.shape
     mask = torch.empty((B, S - 2, 1), dtype=torch.float32, device=x.device)
     row_scale = torch.empty((B, S), dtype=torch.float32, device=x.device)
     with _timed("pv_residual_gate", x.device, 0.0, 8.0 * x.numel()):
         check(_lib.load().pv_residual_gate(_ptr(x), _ptr(x_out), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp),
-                                           float(sigmoid_bias), _ptr(mask), _ptr(row_scale), B, S, D, _stream(x)),
+                                           float(sigmoid_bias), _ptr(mask), _ptr(row_scale), _ptr(thr_out), B, S, D, _stream(x)),
               "pv_residual_gate")
     _count()
     return mask, row_scale
+
+
+def residual_gate_bwd(x: torch.Tensor, dxo: torch.Tensor, drow: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float):
+    """Backward of residual_gate: returns (dx [B,S,D], dwg [D], dbg [1], dwb [D], dbb [1]) for x, dxo fp32 [B,S,D], drow fp32 [B,S]."""
+    _chk(x, torch.float32, "x"); _chk(dxo, torch.float32, "dxo"); _chk(drow, torch.float32, "drow")
+    B, S, D = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    dwg_p = torch.empty((B, D), dtype=torch.float32, device=dev)
+    dwb_p = torch.empty((B, D), dtype=torch.float32, device=dev)
+    scal_p = torch.empty((B, 4), dtype=torch.float32, device=dev)          # (dbg, dbb, 0, 0): four columns for pv_colsum_f32's 16-byte loads
+    with _timed("pv_residual_gate_bwd", dev, 0.0, 12.0 * x.numel()):
+        check(_lib.load().pv_residual_gate_bwd(_ptr(x), _ptr(dxo), _ptr(drow), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp), float(sigmoid_bias),
+                                               _ptr(dx), _ptr(dwg_p), _ptr(dwb_p), _ptr(scal_p), B, S, D, _stream(x)), "pv_residual_gate_bwd")
+    _count()
+    dwg = colsum(dwg_p, torch.empty((D,), dtype=torch.float32, device=dev))
+    dwb = colsum(dwb_p, torch.empty((D,), dtype=torch.float32, device=dev))
+    scal = colsum(scal_p, torch.empty((4,), dtype=torch.float32, device=dev))
+    return dx, dwg, scal[0:1], dwb, scal[1:2]

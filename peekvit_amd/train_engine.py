@@ -304,6 +304,40 @@ class MaskedBlockFn(torch.autograd.Function):
         return (None, dx, dm.view(B, S), dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
 
+class GateFn(torch.autograd.Function):
+    """ResidualViT's sigmoid gate with the learnable budget threshold + the token masking it drives (models/residualvit.py:197-235,
+    :47-74, models/blocks.py:62-69), forward and backward on one kernel each: tokens [B,S,D] -> (masked tokens [B,S,D], row_scale [B,S] =
+    [1 | mask | 1], thresholds [B]).  row_scale carries the autograd graph of the mask: the masked block (MaskedBlockFn) and any auxiliary
+    loss on `block.mask` (a view of it) send their gradients back through it."""
+
+    @staticmethod
+    def forward(ctx, x, wg, bg, wb, bb, temp, sbias):
+        x = x.float() if x.dtype != torch.float32 else x
+        x = x if x.is_contiguous() else x.contiguous()
+        masked = torch.empty_like(x)
+        thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        _mask, rs = ops.residual_gate(x, masked, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), temp, sbias, thr_out=thr)
+        ctx.save_for_backward(x, wg, bg, wb, bb)
+        ctx.cfg = (float(temp), float(sbias))
+        ctx.mark_non_differentiable(thr)
+        return masked, rs, thr
+
+    @staticmethod
+    def backward(ctx, dmasked, drs, _dthr):
+        x, wg, bg, wb, bb = ctx.saved_tensors
+        B, S, D = x.shape
+        dmasked = torch.zeros_like(x) if dmasked is None else (dmasked.float() if dmasked.dtype != torch.float32 else dmasked).contiguous()
+        drs = torch.zeros((B, S), dtype=torch.float32, device=x.device) if drs is None else drs.float().contiguous()
+        dx, dwg, dbg, dwb, dbb = ops.residual_gate_bwd(x, dmasked, drs, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), *ctx.cfg)
+        return dx, dwg.view_as(wg), dbg.view_as(bg), dwb.view_as(wb), dbb.view_as(bb), None, None
+
+
+def gate_forward_train(blk: nn.Module, x: torch.Tensor):
+    """(masked tokens, row_scale [B,S], thresholds [B]) of a ResidualViT block with a sigmoid gate and the learnable budget token."""
+    g, bgate = blk.residual_gate, blk.budget_token_gate
+    return GateFn.apply(x, g.projection.weight, g.projection.bias, bgate.weight, bgate.bias, g.temp, g.sigmoid_bias)
+
+
 def masked_block_forward_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """mask: [B,S,1] or [B,S] (carries the gate's autograd graph)."""
     mha = blk.self_attention.self_attention

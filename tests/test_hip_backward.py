@@ -422,6 +422,39 @@ def test_training_step_vs_reference_golden(golden, name, batch):
             assert rel_l2(named[key.split("/grad/")[1]].grad, g[key]) < 3e-2, key
 
 
+@pytest.mark.parametrize("B,S,D,temp,sbias", [(3, 18, 128, 1.0, 10.0), (5, 198, 768, 1.0, 0.0), (2, 7, 384, 2.0, 1.0), (4, 51, 1024, 0.5, -1.0)])
+def test_residual_gate_backward(ops, B, S, D, temp, sbias):
+    """GateFn (ResidualViT's sigmoid gate + learnable budget threshold + token masking, models/residualvit.py:197-235) against torch autograd
+    over the stock-op formula: the gradient of the masked tokens AND of the mask (row_scale) flow back to the tokens, the gate projection and
+    the budget-token gate."""
+    from peekvit_amd import train_engine
+    g = torch.Generator(device="cuda").manual_seed(B * S)
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g, device="cuda") * scale
+    x = rnd(B, S, D)
+    wg, bg, wb, bb = rnd(1, D, scale=D ** -0.5), rnd(1, scale=0.1), rnd(1, D, scale=D ** -0.5), rnd(1, scale=0.1)
+    G, dmask = rnd(B, S, D, scale=0.1), rnd(B, S, scale=0.3)
+
+    def ref(x, wg, bg, wb, bb):
+        cls, img, bud = x[:, :1], x[:, 1:-1], x[:, -1:]
+        thr = torch.sigmoid(torch.nn.functional.linear(bud, wb, bb))                                   # [B,1,1]
+        mask = torch.relu(torch.sigmoid(torch.nn.functional.linear(img, wg, bg) / temp + sbias) - thr)  # [B,N,1]
+        ones = torch.ones((x.shape[0], 1), device=x.device)
+        return torch.cat([cls, mask * img, bud], dim=1), torch.cat([ones, mask.squeeze(-1), ones], dim=1), thr.view(-1)
+
+    leaves_r = [t.clone().double().requires_grad_(True) for t in (x, wg, bg, wb, bb)]
+    mr, rr, tr = ref(*leaves_r)
+    ((mr * G.double()).sum() + (rr * dmask.double()).sum()).backward()
+    leaves_h = [t.clone().requires_grad_(True) for t in (x, wg, bg, wb, bb)]
+    mh, rh, th = train_engine.GateFn.apply(*leaves_h, temp, sbias)
+    assert rel_l2(mh, mr) < 1e-6 and rel_l2(rh, rr) < 1e-6 and rel_l2(th, tr) < 1e-6
+    assert float((rh[:, 1:-1] > 0).float().mean()) > 0.05, "the case must have active gates"
+    ((mh * G).sum() + (rh * dmask).sum()).backward()
+    for name, a, b in zip(("x", "gate weight", "gate bias", "budget-gate weight", "budget-gate bias"), leaves_h, leaves_r):
+        assert a.grad is not None and a.grad.shape == b.grad.shape, name
+        assert rel_l2(a.grad, b.grad) < 2e-5, (name, rel_l2(a.grad, b.grad))
+
+
 @pytest.mark.parametrize("rows,D", [(50, 128), (3940, 768)])
 def test_layernorm_backward_masked(ops, rows, D):
     """y = m * LayerNorm(x) (+ x1 = x + m * u elsewhere): dx, dgamma/dbeta, the mask gradient incl. the rowdot(dx_out, u) term,
