@@ -157,9 +157,11 @@ class ResidualViTBlock(ResidualModule):
         x = input if input.is_contiguous() else input.contiguous()
         gate, bgate = self.residual_gate.projection, self.budget_token_gate
         masked = torch.empty_like(x)
+        thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
         self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
                                                  bgate.weight.detach(), bgate.bias.detach(),
-                                                 self.residual_gate.temp, self.residual_gate.sigmoid_bias)
+                                                 self.residual_gate.temp, self.residual_gate.sigmoid_bias, thr_out=thr)
+        self.residual_gate.threshold = thr.view(-1, 1, 1)           # what ResidualGate.forward leaves behind (residualvit.py:66; utils.py:131)
         if rows:
             return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale)
         return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale)

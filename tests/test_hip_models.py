@@ -141,10 +141,14 @@ def test_residualvit_parity(golden, tag, name, gb):
         with torch.no_grad():
             logits = m(x.to(DEV)).cpu().numpy()
         masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
+        thr = torch.stack([blk.residual_gate.threshold.cpu() for blk in m.encoder.layers])      # left behind like ResidualGate.forward does (utils.py:131)
+        assert thr.shape == (cfg["num_layers"], x.shape[0], 1, 1) and bool(((thr > 0) & (thr < 1)).all())
         tr = {}
         same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, _op(), trace=tr).numpy()
         assert rel_l2(logits, same) < TOL_SAME
         assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
+        if "thresholds" in tr:
+            assert np.abs(thr.view(cfg["num_layers"], -1).numpy() - torch.stack(tr["thresholds"]).view(cfg["num_layers"], -1).numpy()).max() < 5e-3
         assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
         assert np.abs(masks - g[f"{tag}_b{b}_masks"]).max() < 2e-3            # every block's mask vs the REAL reference's
         if np.linalg.norm(g[f"{tag}_b{b}_logits"]) > 0:
