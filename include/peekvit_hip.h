@@ -278,9 +278,12 @@ int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B,
  * x_in: fp32 [B,S,D] (layout [cls | N | budget], one special token); x_out: same shape, may alias x_in;
  * mask_out: fp32 [B,S-2] (block.mask); row_scale: fp32 [B,S] = [1, mask, 1] (:230-235 fwd_mask) for the
  * LN / out-proj epilogues.
- * thr_out: fp32 [B] or NULL - the per-image threshold (what the reference leaves in residual_gate.threshold, :66). */
+ * thr_out: fp32 [B] or NULL - the per-image threshold (what the reference leaves in residual_gate.threshold, :66).
+ * ln_out: 16-bit [B,S,D] or NULL - also row_scale * LayerNorm(x_out; ln_gamma, ln_beta, ln_eps), the first thing the masked block does with
+ * these rows (:251), from the registers the row is in (bit-identical to pv_layernorm_bf16 with that row_scale). */
 int pv_residual_gate(const float* x_in, float* x_out, const float* wg, const float* bg, const float* wb,
                      const float* bb, float temp, float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out,
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, uint16_t* ln_out,
                      int64_t B, int64_t S, int64_t D, void* stream);
 /* Its backward (training: loss.backward() through the gate).  dx_out = dL/d(x_out) [B,S,D], drow = dL/d(row_scale) [B,S] (the mask
  * gradient of the masked block plus that of any auxiliary loss on block.mask); dx_in [B,S,D]; parameter gradients as per-image partials

@@ -942,14 +942,15 @@ extern "C" int pv_scatter_tokens(const float* dy, const int32_t* keep, float* dx
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pv_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-template <int NCH>
+template <int NCH, bool LN>
 __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, float* xo, const float* __restrict__ wg, const float* __restrict__ bg,
                                                                const float* __restrict__ wb, const float* __restrict__ bb, float temp, float sbias,
                                                                float* __restrict__ mask_out, float* __restrict__ row_scale, float* __restrict__ thr_out,
-                                                               int64_t S, int D) {
+                                                               const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
+                                                               uint16_t* __restrict__ ln_out, int64_t S, int D) {
     __shared__ float thr_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
-    const int64_t b = blockIdx.x, N = S - 2;
+    const int64_t b = blockIdx.x;
     if (wave == 0) {   // threshold from the budget token (last row), models/residualvit.py:212
         const float4* xr = reinterpret_cast<const float4*>(x + (b * S + S - 1) * (int64_t)D);
         float s = 0.f;
@@ -960,53 +961,67 @@ __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, f
         s = pv_wave_sum(s);
         if (lane == 0) {
             thr_s = pv_sigmoid(s + bb[0]);
-            row_scale[b * S] = 1.0f;
-            row_scale[b * S + S - 1] = 1.0f;
             if (thr_out) thr_out[b] = thr_s;
         }
     }
-    if (xo != x && wave >= 2) {   // pass the class token and the budget token through unchanged
-        const int64_t r = wave == 2 ? 0 : S - 1;
-        const float4* s4 = reinterpret_cast<const float4*>(x + (b * S + r) * (int64_t)D);
-        float4* d4 = reinterpret_cast<float4*>(xo + (b * S + r) * (int64_t)D);
-        for (int idx = lane; idx < nvec; idx += 64) d4[idx] = s4[idx];
-    }
     __syncthreads();
     const float thr = thr_s;
-    for (int64_t i = wave; i < N; i += 4) {
-        const float* xr = x + (b * S + 1 + i) * (int64_t)D;
-        float* xw = xo + (b * S + 1 + i) * (int64_t)D;
+    float4 gm[LN ? NCH : 1], bt[LN ? NCH : 1];
+    if constexpr (LN) pv_ln_load_affine<NCH>(gm, bt, ln_gamma, ln_beta, nvec, lane);
+    for (int64_t i = wave; i < S; i += 4) {
+        const bool special = i == 0 || i == S - 1;          // class token, budget token: pass through, scale 1
+        const float* xr = x + (b * S + i) * (int64_t)D;
+        float* xw = xo + (b * S + i) * (int64_t)D;
         RowRegs<NCH> r;
         pv_load_row<NCH>(r, xr, nvec, lane);
-        float s = 0.f;
+        float m = 1.0f;
+        if (!special) {
+            float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int idx = lane + 64 * j;
-            if (idx < nvec) {
-                float4 w = reinterpret_cast<const float4*>(wg)[idx];
-                s += (r.v[j].x * w.x + r.v[j].y * w.y) + (r.v[j].z * w.z + r.v[j].w * w.w);
+            for (int j = 0; j < NCH; ++j) {
+                int idx = lane + 64 * j;
+                if (idx < nvec) {
+                    float4 w = reinterpret_cast<const float4*>(wg)[idx];
+                    s += (r.v[j].x * w.x + r.v[j].y * w.y) + (r.v[j].z * w.z + r.v[j].w * w.w);
+                }
+            }
+            s = pv_wave_sum(s) + bg[0];
+            m = fmaxf(pv_sigmoid(s / temp + sbias) - thr, 0.f);   // blocks.py:69, residualvit.py:66
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) { r.v[j].x *= m; r.v[j].y *= m; r.v[j].z *= m; r.v[j].w *= m; }
+        }
+        if (!special || xo != x) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                int idx = lane + 64 * j;
+                if (idx < nvec) reinterpret_cast<float4*>(xw)[idx] = r.v[j];
             }
         }
-        s = pv_wave_sum(s) + bg[0];
-        const float m = fmaxf(pv_sigmoid(s / temp + sbias) - thr, 0.f);   // blocks.py:69, residualvit.py:66
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int idx = lane + 64 * j;
-            if (idx < nvec) reinterpret_cast<float4*>(xw)[idx] = make_float4(r.v[j].x * m, r.v[j].y * m, r.v[j].z * m, r.v[j].w * m);
-        }
         if (lane == 0) {
-            mask_out[b * N + i] = m;
-            row_scale[b * S + 1 + i] = m;
+            if (!special) mask_out[b * (S - 2) + i - 1] = m;
+            row_scale[b * S + i] = m;
+        }
+        if constexpr (LN) {      // the block's first LayerNorm on the row just written, times its scale: m * LN1(masked row) (residualvit.py:251)
+            pv_ln_row_regs<NCH>(r, gm, bt, D, nvec, lane, ln_eps);
+            u32x2* o = reinterpret_cast<u32x2*>(ln_out + (b * S + i) * (int64_t)D);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                int idx = lane + 64 * j;
+                if (idx < nvec) o[idx] = (u32x2){pv_pack_bf16x2(r.v[j].x * m, r.v[j].y * m), pv_pack_bf16x2(r.v[j].z * m, r.v[j].w * m)};
+            }
         }
     }
 }
 
 extern "C" int pv_residual_gate(const float* x, float* xo, const float* wg, const float* bg, const float* wb, const float* bb, float temp,
-                                float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out, int64_t B, int64_t S, int64_t D, void* stream) {
+                                float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out, const float* ln_gamma, const float* ln_beta,
+                                float ln_eps, uint16_t* ln_out, int64_t B, int64_t S, int64_t D, void* stream) {
     if (!x || !xo || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
     if (D % 4 || D > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)xo & 15) || ((uintptr_t)wg & 15) || ((uintptr_t)wb & 15)) return PV_ERR_UNSUPPORTED;
+    if (ln_out && (!ln_gamma || !ln_beta || ((uintptr_t)ln_gamma & 15) || ((uintptr_t)ln_beta & 15) || ((uintptr_t)ln_out & 7))) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)B);
-#define RG_LAUNCH(N) PV_LAUNCH(pv_residual_gate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, thr_out, S, (int)D)
+#define RG_LAUNCH(N) do { if (ln_out) PV_LAUNCH((pv_residual_gate_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, thr_out, ln_gamma, ln_beta, ln_eps, ln_out, S, (int)D); \
+                          else PV_LAUNCH((pv_residual_gate_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, x, xo, wg, bg, wb, bb, temp, sigmoid_bias, mask_out, row_scale, thr_out, ln_gamma, ln_beta, ln_eps, ln_out, S, (int)D); } while (0)
     PV_DISPATCH_NCH(D, RG_LAUNCH);
 #undef RG_LAUNCH
     return pv_check_launch();

@@ -397,7 +397,7 @@ def _fold_ok(R: int, D: int, M: int) -> bool:
 
 
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
-                  next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False) -> torch.Tensor:
+                  next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
 
     Launches: [LN1] -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual, fused LN2)
@@ -408,6 +408,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     row_scale [B,S] (ResidualViT fwd_mask) multiplies LN1 out, the attention branch and LN2 out.
     next_ranks: the consumer of the output is a RankViT block with an active budget (encoder hint): the fc2 epilogue then also leaves the
     per-column-tile sums of squares of every output row (`out._pv_rowsq`), from which sort_and_drop ranks without a pass over the tokens.
+    h1: row_scale * LN1(x) as 16-bit [B*S, D], already computed by the caller (ResidualViT: the gate kernel has the rows in registers).
     """
     if _PRECISION == "bf16x3":
         return _block_forward_x3(blk, x, eps, row_scale)
@@ -467,7 +468,9 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
             out._pv_rowsq = (rowsq, out._version)
         return out
 
-    if handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
+    if h1 is not None and h1.shape == (R, D):
+        h = h1
+    elif handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
         h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue
     else:
         h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
@@ -498,6 +501,8 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
 
 
 _LAST_BLOCK_ROWS = os.environ.get("PEEKVIT_AMD_LAST_BLOCK_ROWS", "1") != "0"
+# ResidualViT: the gate kernel also emits row_scale * LN1(masked row) (it holds the row in registers); PEEKVIT_AMD_GATE_LN1=0 leaves LN1 to its own launch
+_GATE_LN1 = os.environ.get("PEEKVIT_AMD_GATE_LN1", "1") != "0"
 
 
 def rows_only_ok(blk: nn.Module) -> bool:
@@ -511,7 +516,8 @@ def rows_only_ok(blk: nn.Module) -> bool:
     return not any(getattr(blk, n, None) for n in own) and not any(getattr(_m, n, None) for n in glob)
 
 
-def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row_scale: Optional[torch.Tensor] = None,
+                       h1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The block's output for the FIRST `nq` ROWS of every image only: [B,S,D] -> [B,nq,D].
 
     For the last encoder block of a model forward, whose consumer (pool_and_head) reads the class-token rows alone
@@ -545,7 +551,9 @@ def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row
         stat = ops.rowstat_finalize(fold_in[1], D, blk.ln_1.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
         ops.gemm(fold_in[0], wg[D:], None, kv, PV_EPI_BIAS_BF16, M=R, fold=(stat, c1[D:], c2[D:]))
     else:
-        if handoff is not None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
+        if h1 is not None and h1.shape == (R, D):
+            h = h1                                       # row_scale * LN1(x) from the caller (ResidualViT's gate kernel)
+        elif handoff is not None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
             h = handoff[0]
         else:
             h = workspace.get("h", (R, D), od, dev)

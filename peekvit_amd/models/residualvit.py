@@ -158,13 +158,19 @@ class ResidualViTBlock(ResidualModule):
         gate, bgate = self.residual_gate.projection, self.budget_token_gate
         masked = torch.empty_like(x)
         thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        # the gate kernel holds every row in registers: it also emits row_scale * LN1(masked row), the block's first step (residualvit.py:251)
+        h1 = None
+        if engine._PRECISION != "bf16x3" and engine._GATE_LN1:
+            engine._check_ln_range(self.ln_1)
+            h1 = engine.workspace.get("h", (x.shape[0] * x.shape[1], x.shape[2]), engine._lib.operand_dtype(), x.device)
         self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
                                                  bgate.weight.detach(), bgate.bias.detach(),
-                                                 self.residual_gate.temp, self.residual_gate.sigmoid_bias, thr_out=thr)
+                                                 self.residual_gate.temp, self.residual_gate.sigmoid_bias, thr_out=thr,
+                                                 ln=None if h1 is None else (self.ln_1.weight.detach(), self.ln_1.bias.detach(), self.ln_1.eps, h1))
         self.residual_gate.threshold = thr.view(-1, 1, 1)           # what ResidualGate.forward leaves behind (residualvit.py:66; utils.py:131)
         if rows:
-            return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale)
-        return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale)
+            return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale, h1=h1)
+        return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale, h1=h1)
 
     def _pv_forward_rows(self, input: torch.Tensor, nq: int):
         """engine.run_layers, last block of a model forward (inference): the gate still sees every token and `self.mask` is the full mask,

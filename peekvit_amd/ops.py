@@ -510,14 +510,21 @@ def scatter_tokens(dy: torch.Tensor, keep: torch.Tensor, S_in: int) -> torch.Ten
     return dx
 
 
-def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float, thr_out: Optional[torch.Tensor] = None):
-    """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]; thr_out (fp32 [B], optional): the thresholds."""
+def residual_gate(x: torch.Tensor, x_out: torch.Tensor, wg, bg, wb, bb, temp: float, sigmoid_bias: float, thr_out: Optional[torch.Tensor] = None,
+                  ln=None):
+    """Returns (mask [B,N,1], row_scale [B,S]); x_out receives [cls | mask*img | budget]; thr_out (fp32 [B], optional): the thresholds;
+    ln = (gamma, beta, eps, out 16-bit [B*S, D]): also row_scale * LayerNorm(x_out) from the same pass."""
     B, S, D = x.shape
     mask = torch.empty((B, S - 2, 1), dtype=torch.float32, device=x.device)
     row_scale = torch.empty((B, S), dtype=torch.float32, device=x.device)
-    with _timed("pv_residual_gate", x.device, 0.0, 8.0 * x.numel()):
+    if ln is not None:
+        _chk(ln[3], _lib.operand_dtype(), "ln out")
+    with _timed("pv_residual_gate", x.device, 0.0, (8.0 + (2.0 if ln is not None else 0.0)) * x.numel()):
         check(_lib.load().pv_residual_gate(_ptr(x), _ptr(x_out), _ptr(wg), _ptr(bg), _ptr(wb), _ptr(bb), float(temp),
-                                           float(sigmoid_bias), _ptr(mask), _ptr(row_scale), _ptr(thr_out), B, S, D, _stream(x)),
+                                           float(sigmoid_bias), _ptr(mask), _ptr(row_scale), _ptr(thr_out),
+                                           _ptr(ln[0]) if ln is not None else C.c_void_p(0), _ptr(ln[1]) if ln is not None else C.c_void_p(0),
+                                           float(ln[2]) if ln is not None else 0.0, _ptr(ln[3]) if ln is not None else C.c_void_p(0),
+                                           B, S, D, _stream(x)),
               "pv_residual_gate")
     _count()
     return mask, row_scale

@@ -332,6 +332,29 @@ def test_layernorm_folding_on_off(monkeypatch):
     assert rel_l2(got.cpu(), ref.cpu()) < 2e-3
 
 
+def test_residual_gate_emits_the_first_layernorm(monkeypatch):
+    """ResidualViT: the gate kernel holds every token row in registers and also emits row_scale * LN1(masked row), the first step of the
+    masked block - bit-identical to the separate LayerNorm launch it replaces (same row arithmetic), one pass over the tokens less per block."""
+    from peekvit_amd import engine, ops
+    extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5)
+    for name, batch in (("vit_b_16", 9), ("vit_micro", 5)):
+        cfg, m = _model("res", name, **extra)
+        m.set_budget(0.5)
+        x = _x(cfg, batch).to(DEV)
+        with torch.no_grad():
+            with ops.KernelTimer() as kt:
+                got = m(x)
+            monkeypatch.setattr(engine, "_GATE_LN1", False)
+            with ops.KernelTimer() as kt0:
+                ref = m(x)
+            monkeypatch.setattr(engine, "_GATE_LN1", True)
+        torch.cuda.synchronize()
+        L = cfg["num_layers"]
+        # all-token LayerNorm launches: LN2 of the L - 1 full blocks (+ the last block's two class-row launches) vs LN1 and LN2 of every block
+        assert kt.summary()["pv_layernorm_bf16"]["launches"] == (L - 1) + 2 and kt0.summary()["pv_layernorm_bf16"]["launches"] == (2 * L - 1) + 2
+        assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("kind,name,batch,extra", [("vit", "vit_b_16", 56, {}), ("vit", "vit_tiny", 5, {}), ("vit", "vit_micro", 3, {"num_class_tokens": 2}),
                                                    ("rank", "vit_b_16", 56, {"rankvit_layers": [3, 6, 9]}),
                                                    ("rank", "vit_tiny", 4, {"rankvit_layers": [1, 3]}),
