@@ -285,6 +285,19 @@ def main():
         except (OSError, KeyError, ValueError, StopIteration):
             pass
         flops_exec = sum(v["flops"] for v in ks.values()) / (args.steps * args.batch)
+        # the EMPIRICAL roofline (scripts/power_roofline.hip, profiles/r02_power_roofline.json): what a dependency-free loop with a 256^2 GEMM tile's
+        # LDS / L2 operand traffic sustains on this part at the dominant kernel's HBM bytes per FLOP - `peak` above stays the nominal 2.5 PFLOP/s
+        try:
+            if roof["bound"] == "mfma" and d["bytes"] > 0:
+                pr_ = json.load(open(os.path.join(ROOT, "profiles", "r02_power_roofline.json")))
+                pts = sorted((r["bytes_per_kflop_hbm"], r["tflops"]) for r in pr_["synthetic"] if r["lds_per_16mfma"] == 6 and r["l2_per_16mfma"] == 2)
+                bpk = d["bytes"] / d["flops"] * 1e3
+                lo = max((q for q in pts if q[0] <= bpk), default=pts[0]); hi = min((q for q in pts if q[0] >= bpk), default=pts[-1])
+                emp = lo[1] if hi[0] == lo[0] else lo[1] + (hi[1] - lo[1]) * (bpk - lo[0]) / (hi[0] - lo[0])
+                roof["empirical"] = {"algorithmic_hbm_bytes_per_kflop": round(bpk, 3), "sustained_by_dependency_free_mix_tflops": round(emp, 1),
+                                     "frac": round(roof["achieved"] / emp, 4), "source": "profiles/r02_power_roofline.json"}
+        except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
+            pass
         kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                        "algo_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
