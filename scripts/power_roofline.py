@@ -16,6 +16,10 @@ if not sm.cards:
     sm = PowerSampler(None)
 sm.start()
 exe = os.path.join(ROOT, "scripts", "bin", "power_roofline")
+src = os.path.join(ROOT, "scripts", "power_roofline.hip")
+if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-w", src, "-o", exe], check=True)
 mixes = [(0, 0, 0), (6, 0, 0), (6, 2, 0), (6, 2, 2), (6, 2, 4), (6, 2, 6), (6, 2, 8), (6, 2, 10), (6, 2, 12), (6, 2, 16), (6, 1, 4), (6, 1, 8), (0, 0, 8), (0, 0, 16), (6, 0, 8), (3, 1, 8)]
 out = {"synthetic": [], "note": "per wave and trip: 16 MFMA 16x16x32 bf16 + l x ds_read_b128 + c x 1 KiB L2-window loads; m x 1 KiB HBM-stream loads per 8 trips; "
                                 "one 8-wave workgroup per CU; loads consumed one period after issue"}
