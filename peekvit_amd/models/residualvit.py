@@ -177,6 +177,12 @@ class ResidualViTBlock(ResidualModule):
         the block's output is computed for the class-token rows only."""
         if type(self) is not ResidualViTBlock or input.dim() != 3 or not engine.rows_only_ok(self) or nq > self.num_special_tokens:
             return None
+        if self.skip == 'attention+mlp' and nq == 1 and self._hip_gated_train(input):
+            # training: gate over every token (block.mask stays the full, differentiable mask), masked block on the class-token row
+            masked, row_scale, thr = train_engine.gate_forward_train(self, input)
+            self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
+            self.residual_gate.threshold = thr.view(-1, 1, 1)
+            return train_engine.block_forward_rows_train(self, masked, mask=row_scale)
         if self.skip == 'attention+mlp' and self._hip_gated(input):
             return engine.run_guarded(self, input, lambda: self._hip_gated_block(input, rows=nq))
         if self.skip not in ('attention', 'mlp', 'attention+mlp') and engine.backend_for(input, self, self._p_drop) == "hip":
@@ -337,7 +343,7 @@ class ResidualVisionTransformer(_ViTBase):
                 tokens = train_engine.embed_tokens_train(self, x)
                 if self.add_budget_token:
                     tokens = self._add_budget_token(tokens)
-                return train_engine.pool_and_head_train(self, self.encoder(tokens, _pos_added=True))
+                return train_engine.pool_and_head_train(self, self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens))
         tokens = self._composite_tokens(x)
         if self.add_budget_token:
             tokens = self._add_budget_token(tokens)

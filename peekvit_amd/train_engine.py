@@ -365,7 +365,9 @@ class RowsBlockFn(torch.autograd.Function):
                 dh1 = dkv.Wkv (+ dq.Wq on the class rows); dx = LN1'(dh1) (+ dx1 on the class rows)."""
 
     @staticmethod
-    def forward(ctx, blk, x, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+        """m: None, or the ResidualViT row scale [B,S] of a masked block (h1 = m * LN1(x); the class-token rows carry scale 1, so everything
+        behind the attention is the unmasked arithmetic)."""
         x = x.float() if x.dtype != torch.float32 else x
         x = x if x.is_contiguous() else x.contiguous()
         B, S, D = x.shape
@@ -375,6 +377,7 @@ class RowsBlockFn(torch.autograd.Function):
         Mh = blk.mlp.fc1.out_features
         R, dev, eps, bf = B * S, x.device, blk.ln_1.eps, torch.bfloat16
         qscale = float(dh) ** -0.5
+        mrow = None if m is None else (m.float() if m.dtype != torch.float32 else m).contiguous().view(R)
         h1 = torch.empty((R, D), dtype=bf, device=dev)
         kv = torch.empty((R, 2 * D), dtype=bf, device=dev)
         q = torch.empty((B, D), dtype=bf, device=dev)
@@ -385,7 +388,7 @@ class RowsBlockFn(torch.autograd.Function):
         gl = pair[:, :Mh]
         out = torch.empty((B, 1, D), dtype=torch.float32, device=dev)
         w_in = bf16_weight(mha.in_proj_weight)
-        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1)
+        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1, mrow)
         ops.gemm(h1, w_in[D:], _f32(inb)[D:], kv, PV_EPI_BIAS_BF16, M=R)
         ops.gemm(h1.view(B, S, D)[:, 0], w_in[:D], _f32(inb)[:D], q, PV_EPI_BIAS_BF16, M=B, qcols=D, qscale=qscale)
         ops.attention_rows(q, kv, att, B, S, 1, H, dh)
@@ -394,13 +397,15 @@ class RowsBlockFn(torch.autograd.Function):
         ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=B)
         ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(B, D), PV_EPI_BIAS_RES_F32, M=B, res=x1)
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
-        ctx.save_for_backward(x, h1, kv, q, att, x1, h2, pair)
+        ctx.masked = mrow is not None
+        ctx.save_for_backward(x, h1, kv, q, att, x1, h2, pair, *([mrow] if mrow is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         blk = ctx.blk
-        x, h1, kv, q, att, x1, h2, pair = ctx.saved_tensors
+        x, h1, kv, q, att, x1, h2, pair = ctx.saved_tensors[:8]
+        mrow = ctx.saved_tensors[8] if ctx.masked else None
         B, S, D, H, dh, Mh, qscale = ctx.dims
         gl, pre = pair[:, :Mh], pair[:, Mh:]
         mha = blk.self_attention.self_attention
@@ -441,17 +446,24 @@ class RowsBlockFn(torch.autograd.Function):
         dx = torch.empty((B, S, D), dtype=f32, device=dev)
         dgb1 = torch.empty((3, D), dtype=f32, device=dev)
         dxb = torch.empty((B, S, D), dtype=bf, device=dev)
-        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), None, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        dm = None
+        if mrow is None:
+            ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), None, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        else:                                                                  # h1 = m * LN1(x): the mask gradient falls out of the same pass
+            dm = torch.empty((R,), dtype=f32, device=dev)
+            ops.layernorm_bwd_masked(x.view(R, D), dhid, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), mrow, None, None, dx.view(R, D), dxb, False,
+                                     dgb1, dm, False, blk.ln_1.eps)
+            dm = dm.view(B, S)
         dx[:, 0] += dx1                                                        # the residual path exists for the class rows only
         dxb[:, 0] = dx[:, 0]
         dgb1[2] += dx1.sum(0)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])
-        return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+        return (None, dx, dm, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
 
-def block_forward_rows_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
+def block_forward_rows_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     mha = blk.self_attention.self_attention
-    return RowsBlockFn.apply(blk, x, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+    return RowsBlockFn.apply(blk, x, mask, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                              mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                              blk.mlp.fc2.weight, blk.mlp.fc2.bias)
 

@@ -285,6 +285,45 @@ def test_last_block_class_row_backward_matches_all_rows(monkeypatch, name, B):
     print("worst parameter-gradient rel-L2, class-row last block vs all rows:", worst)
 
 
+@pytest.mark.parametrize("name,B", [("vit_micro", 6), ("vit_tiny", 4)])
+def test_residualvit_last_block_class_row_backward_matches_all_rows(monkeypatch, name, B):
+    """ResidualViT training: the gate of the last block still sees every token (block.mask is the full, differentiable mask, an auxiliary loss on
+    it is part of this test's loss), the masked block behind it is computed and differentiated for the class-token row only.  Every parameter
+    gradient - gate projections and budget-token gates included - against the same path with the all-rows last block."""
+    from peekvit_amd import engine, ops, synth
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    cfg = synth.MODEL_CONFIGS[name]
+    extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=2, add_budget_token="learnable", gate_threshold=0.5)
+    models = []
+    for _ in range(2):
+        m = ResidualVisionTransformer(**cfg, **extra)
+        synth.load_synth_weights(m, dict(cfg, **extra), "residualvit", seed=0)
+        models.append(m.cuda().train())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=g, device="cuda").to(torch.bfloat16).float()
+    y = torch.randint(0, cfg["num_classes"], (B,), generator=g, device="cuda")
+
+    def loss_of(m):
+        torch.manual_seed(7)                                     # the per-image training budgets are sampled: same ones for both models
+        logits = m(x)
+        aux = sum(blk.mask.mean() for blk in m.encoder.layers)   # a mask loss in the style of utils/losses.py:34-60
+        return torch.nn.functional.cross_entropy(logits, y) + 0.1 * aux
+
+    with ops.KernelTimer() as kt:
+        lr = loss_of(models[0]); lr.backward()
+    monkeypatch.setattr(engine, "_LAST_BLOCK_ROWS", False)
+    with ops.KernelTimer() as kt0:
+        la = loss_of(models[1]); la.backward()
+    torch.cuda.synchronize()
+    assert kt.summary()["pv_attention_rows_bwd_bf16"]["launches"] == 1 and "pv_attention_rows_bwd_bf16" not in kt0.summary()
+    assert kt.summary()["pv_residual_gate_bwd"]["launches"] == cfg["num_layers"] == kt0.summary()["pv_residual_gate_bwd"]["launches"]
+    assert abs(lr.item() - la.item()) < 2e-3 * abs(la.item())
+    for (n, pr), (_, pa) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert pr.grad is not None and torch.isfinite(pr.grad).all(), n
+        # single-number gradients (gate biases) are sums with cancellation over every token: bf16 noise of the two paths shows at the percent level
+        assert rel_l2(pr.grad, pa.grad) < (6e-2 if pr.numel() == 1 else 2e-2), (n, rel_l2(pr.grad, pa.grad))
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048, 768, 256), (4096, 1536, 384), (2300, 128, 64)])
 def test_gemm_training_epilogues(ops, M, N, K):
     """PV_EPI_BIAS_GELU_PAIR_BF16 ([gelu | pre] in one pass) and PV_EPI_GELU_GRAD_BF16 (product * gelu'(pre)), both tile kernels."""
