@@ -135,10 +135,10 @@ class ResidualViTBlock(ResidualModule):
         if self._hip_gated_train(input):
             # training on the MI355X kernels: gate + masking (GateFn) and the masked block (MaskedBlockFn), both with hand-written backward;
             # block.mask is a view of the gate's output and stays differentiable for the auxiliary mask losses (utils/losses.py)
-            masked, row_scale, thr = train_engine.gate_forward_train(self, input)
+            masked, row_scale, thr, h1 = train_engine.gate_forward_train(self, input)
             self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
             self.residual_gate.threshold = thr.view(-1, 1, 1)                 # what ResidualGate.forward leaves behind (residualvit.py:66)
-            return train_engine.masked_block_forward_train(self, masked, row_scale)
+            return train_engine.masked_block_forward_train(self, masked, row_scale, h1=h1)
         special, img, btok = self._split(input)
         budget, threshold = None, None
         if self.budget_token:
@@ -179,10 +179,10 @@ class ResidualViTBlock(ResidualModule):
             return None
         if self.skip == 'attention+mlp' and nq == 1 and self._hip_gated_train(input):
             # training: gate over every token (block.mask stays the full, differentiable mask), masked block on the class-token row
-            masked, row_scale, thr = train_engine.gate_forward_train(self, input)
+            masked, row_scale, thr, h1 = train_engine.gate_forward_train(self, input)
             self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
             self.residual_gate.threshold = thr.view(-1, 1, 1)
-            return train_engine.block_forward_rows_train(self, masked, mask=row_scale)
+            return train_engine.block_forward_rows_train(self, masked, mask=row_scale, h1=h1)
         if self.skip == 'attention+mlp' and self._hip_gated(input):
             return engine.run_guarded(self, input, lambda: self._hip_gated_block(input, rows=nq))
         if self.skip not in ('attention', 'mlp', 'attention+mlp') and engine.backend_for(input, self, self._p_drop) == "hip":

@@ -226,7 +226,7 @@ class MaskedBlockFn(torch.autograd.Function):
     pv_layernorm_bwd_masked adds  dm = rowdot(dh1, LN1(x)) + rowdot(dh2, LN2(x1)) + rowdot(dx1, u)."""
 
     @staticmethod
-    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2, h1_given=None):
         x = x.float() if x.dtype != torch.float32 else x
         x = x if x.is_contiguous() else x.contiguous()
         m = m.float().contiguous()
@@ -246,7 +246,10 @@ class MaskedBlockFn(torch.autograd.Function):
         out = torch.empty_like(x)
         qscale = float(dh) ** -0.5
         mrow = m.view(R)
-        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), blk.ln_1.eps, h1, mrow)
+        if h1_given is not None and h1_given.shape == (R, D):
+            h1 = h1_given                                    # m * LN1(x), emitted by the gate kernel
+        else:
+            ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), blk.ln_1.eps, h1, mrow)
         ops.gemm(h1, bf16_weight(mha.in_proj_weight), _f32(inb), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=qscale)
         ops.attention(qkv, att, B, S, H, dh)
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), u, PV_EPI_BIAS_BF16, M=R)
@@ -301,7 +304,7 @@ class MaskedBlockFn(torch.autograd.Function):
         ops.layernorm_bwd_masked(x.view(R, D), dhid, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), mrow, dx1, None, dx.view(R, D), dxb, False, dgb1,
                                  dm, True, blk.ln_1.eps)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])
-        return (None, dx, dm.view(B, S), dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+        return (None, dx, dm.view(B, S), dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2, None)
 
 
 class GateFn(torch.autograd.Function):
@@ -311,40 +314,48 @@ class GateFn(torch.autograd.Function):
     loss on `block.mask` (a view of it) send their gradients back through it."""
 
     @staticmethod
-    def forward(ctx, x, wg, bg, wb, bb, temp, sbias):
+    def forward(ctx, x, wg, bg, wb, bb, temp, sbias, ln=None):
+        """ln = (gamma, beta, eps) of the masked block's LN1 (detached): the kernel also emits h1 = row_scale * LN1(masked) from the registers
+        the rows are in (a constant of this function as far as autograd goes: the block differentiates LN1 from its own input)."""
         x = x.float() if x.dtype != torch.float32 else x
         x = x if x.is_contiguous() else x.contiguous()
         masked = torch.empty_like(x)
         thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
-        _mask, rs = ops.residual_gate(x, masked, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), temp, sbias, thr_out=thr)
+        h1 = torch.empty((x.shape[0] * x.shape[1], x.shape[2]), dtype=torch.bfloat16, device=x.device) if ln is not None else None
+        _mask, rs = ops.residual_gate(x, masked, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), temp, sbias, thr_out=thr,
+                                      ln=None if ln is None else (_f32(ln[0]), _f32(ln[1]), float(ln[2]), h1))
         ctx.save_for_backward(x, wg, bg, wb, bb)
         ctx.cfg = (float(temp), float(sbias))
-        ctx.mark_non_differentiable(thr)
-        return masked, rs, thr
+        if h1 is None:
+            h1 = torch.empty((0,), dtype=torch.bfloat16, device=x.device)
+        ctx.mark_non_differentiable(thr, h1)
+        return masked, rs, thr, h1
 
     @staticmethod
-    def backward(ctx, dmasked, drs, _dthr):
+    def backward(ctx, dmasked, drs, _dthr, _dh1):
         x, wg, bg, wb, bb = ctx.saved_tensors
         B, S, D = x.shape
         dmasked = torch.zeros_like(x) if dmasked is None else (dmasked.float() if dmasked.dtype != torch.float32 else dmasked).contiguous()
         drs = torch.zeros((B, S), dtype=torch.float32, device=x.device) if drs is None else drs.float().contiguous()
         dx, dwg, dbg, dwb, dbb = ops.residual_gate_bwd(x, dmasked, drs, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), *ctx.cfg)
-        return dx, dwg.view_as(wg), dbg.view_as(bg), dwb.view_as(wb), dbb.view_as(bb), None, None
+        return dx, dwg.view_as(wg), dbg.view_as(bg), dwb.view_as(wb), dbb.view_as(bb), None, None, None
 
 
 def gate_forward_train(blk: nn.Module, x: torch.Tensor):
-    """(masked tokens, row_scale [B,S], thresholds [B]) of a ResidualViT block with a sigmoid gate and the learnable budget token."""
+    """(masked tokens, row_scale [B,S], thresholds [B], h1 = row_scale * LN1(masked) as bf16 [B*S, D]) of a ResidualViT block with a sigmoid
+    gate and the learnable budget token."""
     g, bgate = blk.residual_gate, blk.budget_token_gate
-    return GateFn.apply(x, g.projection.weight, g.projection.bias, bgate.weight, bgate.bias, g.temp, g.sigmoid_bias)
+    return GateFn.apply(x, g.projection.weight, g.projection.bias, bgate.weight, bgate.bias, g.temp, g.sigmoid_bias,
+                        (blk.ln_1.weight.detach(), blk.ln_1.bias.detach(), blk.ln_1.eps))
 
 
-def masked_block_forward_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-    """mask: [B,S,1] or [B,S] (carries the gate's autograd graph)."""
+def masked_block_forward_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor, h1: torch.Tensor = None) -> torch.Tensor:
+    """mask: [B,S,1] or [B,S] (carries the gate's autograd graph); h1: mask * LN1(x) as bf16 [B*S, D] when the gate kernel produced it."""
     mha = blk.self_attention.self_attention
     m = mask.squeeze(-1) if mask.dim() == 3 else mask
     return MaskedBlockFn.apply(blk, x, m, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                                mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                               blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+                               blk.mlp.fc2.weight, blk.mlp.fc2.bias, h1)
 
 
 def block_forward_train(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -365,7 +376,7 @@ class RowsBlockFn(torch.autograd.Function):
                 dh1 = dkv.Wkv (+ dq.Wq on the class rows); dx = LN1'(dh1) (+ dx1 on the class rows)."""
 
     @staticmethod
-    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2):
+    def forward(ctx, blk, x, m, ln1w, ln1b, inw, inb, ow, ob, ln2w, ln2b, w1, b1, w2, b2, h1_given=None):
         """m: None, or the ResidualViT row scale [B,S] of a masked block (h1 = m * LN1(x); the class-token rows carry scale 1, so everything
         behind the attention is the unmasked arithmetic)."""
         x = x.float() if x.dtype != torch.float32 else x
@@ -388,7 +399,10 @@ class RowsBlockFn(torch.autograd.Function):
         gl = pair[:, :Mh]
         out = torch.empty((B, 1, D), dtype=torch.float32, device=dev)
         w_in = bf16_weight(mha.in_proj_weight)
-        ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1, mrow)
+        if h1_given is not None and h1_given.shape == (R, D):
+            h1 = h1_given
+        else:
+            ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1, mrow)
         ops.gemm(h1, w_in[D:], _f32(inb)[D:], kv, PV_EPI_BIAS_BF16, M=R)
         ops.gemm(h1.view(B, S, D)[:, 0], w_in[:D], _f32(inb)[:D], q, PV_EPI_BIAS_BF16, M=B, qcols=D, qscale=qscale)
         ops.attention_rows(q, kv, att, B, S, 1, H, dh)
@@ -458,14 +472,14 @@ class RowsBlockFn(torch.autograd.Function):
         dxb[:, 0] = dx[:, 0]
         dgb1[2] += dx1.sum(0)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])
-        return (None, dx, dm, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2)
+        return (None, dx, dm, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2, None)
 
 
-def block_forward_rows_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
+def block_forward_rows_train(blk: nn.Module, x: torch.Tensor, mask: torch.Tensor = None, h1: torch.Tensor = None) -> torch.Tensor:
     mha = blk.self_attention.self_attention
     return RowsBlockFn.apply(blk, x, mask, blk.ln_1.weight, blk.ln_1.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                              mha.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                             blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, h1)
 
 
 class EmbedFn(torch.autograd.Function):

@@ -485,7 +485,7 @@ def test_residual_gate_backward(ops, B, S, D, temp, sbias):
     mr, rr, tr = ref(*leaves_r)
     ((mr * G.double()).sum() + (rr * dmask.double()).sum()).backward()
     leaves_h = [t.clone().requires_grad_(True) for t in (x, wg, bg, wb, bb)]
-    mh, rh, th = train_engine.GateFn.apply(*leaves_h, temp, sbias)
+    mh, rh, th, _h1 = train_engine.GateFn.apply(*leaves_h, temp, sbias)
     assert rel_l2(mh, mr) < 1e-6 and rel_l2(rh, rr) < 1e-6 and rel_l2(th, tr) < 1e-6
     assert float((rh[:, 1:-1] > 0).float().mean()) > 0.05, "the case must have active gates"
     ((mh * G).sum() + (rh * dmask).sum()).backward()
