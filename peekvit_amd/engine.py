@@ -86,7 +86,8 @@ fallback_count = 0          # forwards repeated on bf16 operands because the fp1
 def range_flag_for(device) -> torch.Tensor:
     f = _flags.get(device)
     if f is None:
-        f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        with torch.inference_mode(False):        # a buffer that outlives the call: never an inference tensor (those refuse in-place updates later)
+            f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
     return f
 
 
@@ -221,7 +222,8 @@ class _Workspace:
         key = (name, device, torch.cuda.current_stream(device).cuda_stream)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            with torch.inference_mode(False):    # scratch outlives the call: a first use under torch.inference_mode() must not make it an inference tensor
+                buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf[:nbytes].view(dtype).view(*shape)
 
@@ -266,6 +268,21 @@ except ImportError:                    # pragma: no cover - torch < 2.0
     pass
 
 
+def _tver(t: torch.Tensor) -> int:
+    """Version counter of an ACTIVATION (the hand-offs between blocks are valid only while nobody has modified the tensor in place).
+    Tensors created under torch.inference_mode() have no counter: -1, and run_layers drops the hand-offs when a module hook could have
+    touched the tensor between two blocks."""
+    return -1 if t.is_inference() else t._version
+
+
+_HANDOFFS = ("_pv_fold", "_pv_ln", "_pv_rowsq")
+
+
+def _hooks_between(a: nn.Module, b: Optional[nn.Module]) -> bool:
+    import torch.nn.modules.module as _m
+    return bool(a._forward_hooks or (b is not None and b._forward_pre_hooks) or _m._global_forward_hooks or _m._global_forward_pre_hooks)
+
+
 def pver(p: torch.Tensor) -> tuple:
     """What a cached derivative of `p` is valid for: (autograd version, optimizer generation if p is trainable)."""
     return (p._version, _opt_generation if p.requires_grad else 0)
@@ -287,7 +304,8 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     src = p.detach()
     if not src.is_contiguous():
         src = src.contiguous()
-    w = ops.cast_bf16(src.view(src.shape[0], -1))
+    with torch.inference_mode(False):
+        w = ops.cast_bf16(src.view(src.shape[0], -1))
     if _lib.OPERAND == "f16" and not bool(torch.isfinite(w).all()):      # once per parameter version
         raise F16RangeError("a weight does not fit the fp16 operand range (|w| > 65504 or non-finite)")
     ev = None
@@ -313,7 +331,8 @@ def bf16x3_weight(p: torch.Tensor) -> torch.Tensor:
         return ent[3]
     src = p.detach()
     src = (src if src.is_contiguous() else src.contiguous()).view(src.shape[0], -1)
-    w = ops.split3(src, 1)
+    with torch.inference_mode(False):
+        w = ops.split3(src, 1)
     _w3cache[key] = (weakref.ref(p, lambda _r, k=key: _w3cache.pop(k, None)), pver(p), p.data_ptr(), w)
     return w
 
@@ -375,7 +394,7 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
     ent = _foldcache.get(key)
     if ent is not None and ent[0] == ver:
         return ent[1]
-    with torch.no_grad():
+    with torch.inference_mode(False), torch.no_grad():
         wf = w.detach().float()
         wg = ops.cast_bf16((wf * ln.weight.detach().float()).contiguous())
         c1 = wg.float().sum(1).contiguous()
@@ -438,7 +457,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
         # ---- LayerNorm folded into the GEMMs: no LayerNorm launch except for a block whose input has no producer hand-off ----
         nt = (D + 255) // 256
         fold_in = getattr(x, "_pv_fold", None)
-        if fold_in is not None and fold_in[3] != x._version:           # someone modified the tensor in place: the 16-bit copy is stale
+        if fold_in is not None and fold_in[3] != _tver(x):           # someone modified the tensor in place: the 16-bit copy is stale
             fold_in = None
         if fold_in is not None and fold_in[2] == _ln_key(blk.ln_1) and fold_in[0].shape == (R, D):
             wg, c1, c2 = _fold_weights(mha.in_proj_weight, mha.in_proj_bias, blk.ln_1)
@@ -463,9 +482,9 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
         ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D),
                  x16_out=o16, rowstat_out=opart, rowsq_out=rowsq)
         if emit:
-            out._pv_fold = (o16, opart, _ln_key(next_ln), out._version)
+            out._pv_fold = (o16, opart, _ln_key(next_ln), _tver(out))
         if rowsq is not None:
-            out._pv_rowsq = (rowsq, out._version)
+            out._pv_rowsq = (rowsq, _tver(out))
         return out
 
     if h1 is not None and h1.shape == (R, D):
@@ -496,7 +515,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     if fuse_next:
         out._pv_ln = (hn, _ln_key(next_ln))
     if rowsq is not None:
-        out._pv_rowsq = (rowsq, out._version)          # valid only while nobody has modified `out` in place
+        out._pv_rowsq = (rowsq, _tver(out))          # valid only while nobody has modified `out` in place
     return out
 
 
@@ -528,7 +547,7 @@ def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row
     if x.dtype != torch.float32:
         x = x.float()
     fold_in, handoff = getattr(x, "_pv_fold", None), getattr(x, "_pv_ln", None)
-    if fold_in is not None and fold_in[3] != x._version:
+    if fold_in is not None and fold_in[3] != _tver(x):
         fold_in = None
     if not x.is_contiguous():
         x, fold_in, handoff = x.contiguous(), None, None
@@ -637,6 +656,12 @@ def run_layers(layers: nn.Sequential, x: torch.Tensor, last_rows: int = 0) -> to
             object.__setattr__(layer, "_pv_next_ranks", bool(nxt is not None and getattr(nxt, "_pv_ranks_input", None) is not None
                                                              and nxt._pv_ranks_input()))
         x = layer(x)
+        if x.is_inference() and _hooks_between(layer, nxt):
+            # no version counter to tell whether a hook edited the block's output in place: the next block recomputes instead of trusting
+            # what the producer left behind
+            for name in _HANDOFFS:
+                if hasattr(x, name):
+                    delattr(x, name)
     return x
 
 
@@ -691,7 +716,7 @@ def pool_and_head(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
 def sort_and_drop(x: torch.Tensor, budget: float):
     """RankViT token ranking + compaction (models/rankvit.py:55-77).  Returns (tokens [B,1+k,D], keep int32 [B,k])."""
     hand = getattr(x, "_pv_rowsq", None)
-    if hand is not None and hand[1] != x._version:
+    if hand is not None and hand[1] != _tver(x):
         hand = None
     if not x.is_contiguous():
         x, hand = x.contiguous(), None

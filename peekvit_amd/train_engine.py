@@ -42,7 +42,8 @@ def bf16_weight_t(p: torch.Tensor) -> torch.Tensor:
     ent = _wtcache.get(key)
     if ent is not None and ent[0]() is p and ent[1] == pver(p) and ent[2] == p.data_ptr():
         return ent[3]
-    wt = ops.transpose(bf16_weight(p))
+    with torch.inference_mode(False):
+        wt = ops.transpose(bf16_weight(p))
     _wtcache[key] = (weakref.ref(p, lambda _r, k=key: _wtcache.pop(k, None)), pver(p), p.data_ptr(), wt)
     return wt
 

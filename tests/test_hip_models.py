@@ -502,3 +502,38 @@ def test_device_prefetcher_feeds_the_same_batches():
     a = htest.evaluate(m, data, torch.device(DEV), [None], 20, prefetch=True)[0]
     b = htest.evaluate(m, data, torch.device(DEV), [None], 20, prefetch=False)[0]
     assert a["accuracy"] == b["accuracy"] and a["device_images_per_second"] > 0
+
+
+def test_inference_mode_and_no_grad_agree_and_mix():
+    """torch.inference_mode() (tensors without a version counter, buffers that must not become inference tensors) gives the logits of
+    torch.no_grad() bit for bit - at a batch that takes the folded-LayerNorm hand-offs, first use of the model under inference_mode -
+    the same model then still runs under no_grad and trains, and a hook that edits a block's output in place is honoured in both modes."""
+    from peekvit_amd import engine
+    engine.workspace.clear()
+    cfg, m = _model("vit", "vit_b_16")
+    x = _x(cfg, 56).to(DEV)
+    with torch.inference_mode():
+        a = m(x).clone()
+    with torch.no_grad():
+        b = m(x)
+    assert torch.equal(a, b)
+    h = m.encoder.layers[3].register_forward_hook(lambda mod, inp, out: out.mul_(0.5))     # in-place edit between two blocks
+    try:
+        with torch.inference_mode():
+            c = m(x).clone()
+        with torch.no_grad():
+            d = m(x)
+    finally:
+        h.remove()
+    assert torch.equal(c, d) and not torch.equal(c, a)
+    rcfg, r = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    r.set_budget(0.5)
+    with torch.inference_mode():
+        e = r(x).clone()
+    with torch.no_grad():
+        f = r(x)
+    assert torch.equal(e, f)
+    m.train()
+    loss = torch.nn.functional.cross_entropy(m(x[:4]), torch.arange(4, device=DEV))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
