@@ -302,6 +302,8 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
                 cur.wait_event(ent[4][1])
         return ent[3]
     src = p.detach()
+    if src.dtype != torch.float32:
+        src = src.float()                      # a .half() / .bfloat16() model: the operand copy is made from the values it holds
     if not src.is_contiguous():
         src = src.contiguous()
     with torch.inference_mode(False):
@@ -338,9 +340,14 @@ def bf16x3_weight(p: torch.Tensor) -> torch.Tensor:
 
 
 def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The fp32, contiguous, detached view the kernels read small parameters through (biases, LayerNorm affine, tokens).  A model
+    converted with .half() / .bfloat16() is served from fp32 copies of these (the kernels' accumulation and residual stream are fp32
+    regardless) instead of handing 16-bit memory to a kernel that reads floats."""
     if p is None:
         return None
     d = p.detach()
+    if d.dtype != torch.float32:
+        d = d.float()
     return d if d.is_contiguous() else d.contiguous()
 
 

@@ -163,10 +163,10 @@ class ResidualViTBlock(ResidualModule):
         if engine._PRECISION != "bf16x3" and engine._GATE_LN1:
             engine._check_ln_range(self.ln_1)
             h1 = engine.workspace.get("h", (x.shape[0] * x.shape[1], x.shape[2]), engine._lib.operand_dtype(), x.device)
-        self.mask, row_scale = ops.residual_gate(x, masked, gate.weight.detach(), gate.bias.detach(),
-                                                 bgate.weight.detach(), bgate.bias.detach(),
+        f32 = engine._f32
+        self.mask, row_scale = ops.residual_gate(x, masked, f32(gate.weight), f32(gate.bias), f32(bgate.weight), f32(bgate.bias),
                                                  self.residual_gate.temp, self.residual_gate.sigmoid_bias, thr_out=thr,
-                                                 ln=None if h1 is None else (self.ln_1.weight.detach(), self.ln_1.bias.detach(), self.ln_1.eps, h1))
+                                                 ln=None if h1 is None else (f32(self.ln_1.weight), f32(self.ln_1.bias), self.ln_1.eps, h1))
         self.residual_gate.threshold = thr.view(-1, 1, 1)           # what ResidualGate.forward leaves behind (residualvit.py:66; utils.py:131)
         if rows:
             return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale, h1=h1)

@@ -537,3 +537,18 @@ def test_inference_mode_and_no_grad_agree_and_mix():
     loss = torch.nn.functional.cross_entropy(m(x[:4]), torch.arange(4, device=DEV))
     loss.backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_half_precision_model_is_served_from_fp32_copies():
+    """model.half() / model.bfloat16() (16-bit PARAMETERS and inputs): the kernels read biases / LayerNorm affine / tokens as fp32 and make
+    their operand copies of the weights from the stored values - the logits are those of the fp32 model holding the same (rounded) values."""
+    cfg, m = _model("vit", "vit_tiny")
+    x = _x(cfg, 3).to(DEV)
+    for conv in (lambda t: t.half(), lambda t: t.bfloat16()):
+        m16 = conv(_model("vit", "vit_tiny")[1])
+        ref = _model("vit", "vit_tiny")[1]
+        ref.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+        with torch.no_grad():
+            got = m16(conv(x))
+            want = ref(conv(x).float())
+        assert got.dtype == torch.float32 and torch.equal(got, want)
