@@ -194,7 +194,8 @@ def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> s
     modules train_engine does not cover yet: RankViT / ResidualViT blocks - while autograd is recording).
     PEEKVIT_AMD_BACKEND=hip makes every non-eligible call raise instead of taking the composite path."""
     forced = os.environ.get("PEEKVIT_AMD_BACKEND", "")
-    eligible = x.is_cuda and not torch.is_grad_enabled() and not (module.training and dropout_p > 0.0)
+    # an empty batch has nothing to launch: the stock composite returns the empty result the reference returns
+    eligible = x.is_cuda and x.numel() > 0 and not torch.is_grad_enabled() and not (module.training and dropout_p > 0.0)
     if forced == "torch":
         return "torch"
     if forced == "hip" and not eligible:

@@ -112,6 +112,8 @@ class RankVisionTransformer(_ViTBase):
 
     def forward(self, x: torch.Tensor):
         self._check_image(x)
+        if x.shape[0] == 0:                    # a batch of zero images (the reference's nn.MultiheadAttention raises on it): empty logits
+            return x.new_zeros((0, self.num_classes), dtype=torch.float32)
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
             with engine.on_device(x):

@@ -326,6 +326,8 @@ class ResidualVisionTransformer(_ViTBase):
 
     def forward(self, x: torch.Tensor):
         self._check_image(x)
+        if x.shape[0] == 0:                    # a batch of zero images (the reference's nn.MultiheadAttention raises on it): empty logits
+            return x.new_zeros((0, self.num_classes), dtype=torch.float32)
         hip = engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip"
         if hip and self.add_budget_token in (False, None, 'learnable') and not self.training:
             btok, budget = None, 0.0

@@ -566,5 +566,5 @@ def pool_and_head_train(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
 
 def train_eligible(x: torch.Tensor, module: nn.Module, dropout_p: float) -> bool:
     from . import engine
-    return (x.is_cuda and torch.is_grad_enabled() and not (module.training and dropout_p > 0.0) and engine._PRECISION in ("auto", "bf16")
+    return (x.is_cuda and x.numel() > 0 and torch.is_grad_enabled() and not (module.training and dropout_p > 0.0) and engine._PRECISION in ("auto", "bf16")
             and os.environ.get("PEEKVIT_AMD_BACKEND", "") != "torch" and os.environ.get("PEEKVIT_AMD_TRAIN", "hip") == "hip")

@@ -552,3 +552,13 @@ def test_half_precision_model_is_served_from_fp32_copies():
             got = m16(conv(x))
             want = ref(conv(x).float())
         assert got.dtype == torch.float32 and torch.equal(got, want)
+
+
+def test_empty_batch_returns_empty_logits():
+    """A batch of zero images (the tail of a sharded loader): [0, num_classes] like the reference, nothing is launched."""
+    from peekvit_amd import ops
+    cfg, m = _model("vit", "vit_tiny")
+    n0 = ops.launch_count
+    with torch.no_grad():
+        y = m(torch.empty(0, 3, cfg["image_size"], cfg["image_size"], device=DEV))
+    assert y.shape == (0, cfg["num_classes"]) and ops.launch_count == n0
