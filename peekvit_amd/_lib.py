@@ -83,13 +83,33 @@ _libs: dict = {}
 
 # 16-bit operand type of the MFMA products (engine.precision): "bf16" -> libpeekvit_hip.so, "f16" -> libpeekvit_hip_f16.so (the
 # same sources built with -DPV_OPERAND_F16).  ops.py / engine.py allocate operand tensors with operand_dtype().
-OPERAND = "bf16"
+# The selection is PER THREAD (engine.precision() switches it around a forward; another thread in the middle of its own forward must not see
+# the switch): `_lib.OPERAND` reads the calling thread's value (module __getattr__), set_operand() writes it.
+_OPERAND_DEFAULT = "bf16"
+_tls = threading.local()
 LIB_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpeekvit_hip_f16.so")
+
+
+def current_operand() -> str:
+    return getattr(_tls, "operand", _OPERAND_DEFAULT)
+
+
+def set_operand(op: str) -> str:
+    """Set the calling thread's operand type; returns the previous one."""
+    old = current_operand()
+    _tls.operand = op
+    return old
+
+
+def __getattr__(name):
+    if name == "OPERAND":
+        return current_operand()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def operand_dtype():
     import torch as _t
-    return _t.float16 if OPERAND == "f16" else _t.bfloat16
+    return _t.float16 if current_operand() == "f16" else _t.bfloat16
 
 
 class PeekvitHipError(RuntimeError):
@@ -102,7 +122,7 @@ def lib_path(operand: str = "bf16") -> str:
 
 def load(operand=None):
     """Load the shared library of the current (or given) operand type once and attach the declared signatures.  Raises if missing."""
-    op = OPERAND if operand is None else operand
+    op = current_operand() if operand is None else operand
     lib = _libs.get(op)
     if lib is not None:
         return lib

@@ -38,29 +38,44 @@ from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_
 #   "f16"    fp16 operands unconditionally (no guard, no fallback): for A/B measurements
 #   "bf16x3" every GEMM operand split v = hi + lo and concatenated along K ([a_hi|a_lo|a_hi] . [w_hi|w_hi|w_lo]^T on the same
 #            MFMA kernel), exact-fp32 attention: meets BASELINE's 1e-3 (measured ~1e-5) at ~3x the GEMM work
-_PRECISION = os.environ.get("PEEKVIT_AMD_PRECISION", "auto")
+_MODE_DEFAULT = os.environ.get("PEEKVIT_AMD_PRECISION", "auto")
 _MODES = ("auto", "bf16", "f16", "bf16x3")
-if _PRECISION not in _MODES:
-    raise ValueError(f"PEEKVIT_AMD_PRECISION={_PRECISION!r}: expected one of {_MODES}")
-_lib.OPERAND = "f16" if _PRECISION == "f16" else "bf16"
+if _MODE_DEFAULT not in _MODES:
+    raise ValueError(f"PEEKVIT_AMD_PRECISION={_MODE_DEFAULT!r}: expected one of {_MODES}")
+_lib._OPERAND_DEFAULT = "f16" if _MODE_DEFAULT == "f16" else "bf16"
+# The mode (and with it the operand library, the range flag, the scratch arena) is state of the CALLING THREAD: precision() switches it
+# around one forward - mode "auto" does so inside every guarded forward - and a second thread in the middle of its own forward (a
+# serving thread pool, nn.DataParallel's per-GPU threads) must not see the switch.  `engine._PRECISION` reads the calling thread's mode.
+_mode_tls = threading.local()
+
+
+def _mode() -> str:
+    return getattr(_mode_tls, "mode", _MODE_DEFAULT)
+
+
+def __getattr__(name):
+    if name == "_PRECISION":
+        return _mode()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 @contextlib.contextmanager
 def precision(mode: str):
-    global _PRECISION
     if mode not in _MODES:
         raise ValueError(f"unknown precision {mode!r}")
-    old, _PRECISION = _PRECISION, mode
-    old_op, _lib.OPERAND = _lib.OPERAND, ("f16" if mode == "f16" else "bf16")
+    old = _mode()
+    _mode_tls.mode = mode
+    old_op = _lib.set_operand("f16" if mode == "f16" else "bf16")
     try:
         yield
     finally:
-        _PRECISION, _lib.OPERAND = old, old_op
+        _mode_tls.mode = old
+        _lib.set_operand(old_op)
 
 
 def inference_operand() -> str:
     """The 16-bit operand type an INFERENCE forward uses in the current mode ("f16" for auto / f16, else "bf16")."""
-    return "f16" if _PRECISION in ("auto", "f16") else "bf16"
+    return "f16" if _mode() in ("auto", "f16") else "bf16"
 
 
 class F16RangeError(PeekvitHipError):
@@ -77,17 +92,18 @@ def on_device(t: torch.Tensor):
         yield
 
 
-_flags: Dict[torch.device, torch.Tensor] = {}
+_flags: Dict[tuple, torch.Tensor] = {}
 _region = threading.local()
 _warned = set()
 fallback_count = 0          # forwards repeated on bf16 operands because the fp16 range guard tripped (tests / bench read it)
 
 
 def range_flag_for(device) -> torch.Tensor:
-    f = _flags.get(device)
+    key = (device, threading.get_ident())            # one word per device AND thread: a thread zeroes / reads only its own
+    f = _flags.get(key)
     if f is None:
         with torch.inference_mode(False):        # a buffer that outlives the call: never an inference tensor (those refuse in-place updates later)
-            f = _flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+            f = _flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return f
 
 
@@ -142,14 +158,14 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn):
     stream once per guarded forward; under stream capture (peekvit_amd.graph) the check is left to the replayer."""
     global fallback_count
     with on_device(x):
-        if _PRECISION != "auto" or getattr(_region, "active", False):
+        if _mode() != "auto" or getattr(_region, "active", False):
             return fn()
         _region.active = True
         try:
             if not getattr(owner, "_pv_f16_unsafe", False):
                 flag = range_flag_for(x.device)
                 flag.zero_()
-                ops.range_flag = flag
+                ops.set_range_flag(flag)
                 out = None
                 try:
                     with precision("f16"):
@@ -159,7 +175,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn):
                     _warn_once(f"param:{id(owner)}", f"peekvit_amd: {e}; this module runs on bf16 operands from now on "
                                                      "(logits then carry ~4e-3 relative operand-rounding error)")
                 finally:
-                    ops.range_flag = None
+                    ops.set_range_flag(None)
                 if out is not None:
                     if torch.cuda.is_current_stream_capturing() or int(flag.item()) == 0:
                         return out
@@ -208,19 +224,19 @@ def backend_for(x: torch.Tensor, module: nn.Module, dropout_p: float = 0.0) -> s
 # workspace arena: named scratch buffers per device, grown on demand, reused across blocks/calls
 # ------------------------------------------------------------------------------------------------
 class _Workspace:
-    """Scratch buffers keyed by (name, device, STREAM): two streams (or threads on their own streams) never share scratch, and a
-    buffer is only ever touched by launches on the stream it was created for.  `use_workspace` swaps the arena the engine draws
+    """Scratch buffers keyed by (name, device, STREAM, THREAD): two streams never share scratch, nor do two threads that enqueue on the same
+    (default) stream - their launches interleave on it - and a buffer is only ever touched by launches on the stream it was created for.  `use_workspace` swaps the arena the engine draws
     from, so a captured hipGraph owns the buffers its nodes point at (peekvit_amd.graph)."""
 
     def __init__(self):
-        self._bufs: Dict[Tuple[str, torch.device, int], torch.Tensor] = {}
+        self._bufs: Dict[tuple, torch.Tensor] = {}
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
         n = 1
         for s in shape:
             n *= int(s)
         nbytes = n * torch.empty((), dtype=dtype).element_size()
-        key = (name, device, torch.cuda.current_stream(device).cuda_stream)
+        key = (name, device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             with torch.inference_mode(False):    # scratch outlives the call: a first use under torch.inference_mode() must not make it an inference tensor
@@ -413,7 +429,7 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
 
 def _fold_ok(R: int, D: int, M: int) -> bool:
     """Folding needs the 256-row tile kernel for all four token GEMMs (include/peekvit_hip.h): enough rows, 128-multiples."""
-    if not (_FOLD_LN and _PRECISION in ("bf16", "f16") and D % 128 == 0 and M % 128 == 0) or _ln_fusable(D, D):
+    if not (_FOLD_LN and _mode() in ("bf16", "f16") and D % 128 == 0 and M % 128 == 0) or _ln_fusable(D, D):
         return False
     key = (R, D, M, _lib.OPERAND)
     ok = _foldok_cache.get(key)
@@ -437,7 +453,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     per-column-tile sums of squares of every output row (`out._pv_rowsq`), from which sort_and_drop ranks without a pass over the tokens.
     h1: row_scale * LN1(x) as 16-bit [B*S, D], already computed by the caller (ResidualViT: the gate kernel has the rows in registers).
     """
-    if _PRECISION == "bf16x3":
+    if _mode() == "bf16x3":
         return _block_forward_x3(blk, x, eps, row_scale)
     if x.dtype != torch.float32:
         x = x.float()
@@ -536,7 +552,7 @@ def rows_only_ok(blk: nn.Module) -> bool:
     """May the LAST block of a model forward compute only the rows its consumer reads (block_forward_rows)?  Not in mode "bf16x3", and not
     when someone observes the block's output (or its gradient) through a module hook (they would see [B,nq,D] instead of [B,S,D])."""
     import torch.nn.modules.module as _m
-    if not _LAST_BLOCK_ROWS or _PRECISION == "bf16x3":
+    if not _LAST_BLOCK_ROWS or _mode() == "bf16x3":
         return False
     own = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
     glob = ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks")
@@ -694,7 +710,7 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
     K = Cin * P * P
     dev = img.device
 
-    x3 = _PRECISION == "bf16x3" and not u8
+    x3 = _mode() == "bf16x3" and not u8
     cols = workspace.get("cols", (B * Np, 3 * K if x3 else K), _lib.operand_dtype(), dev)
     if x3:
         ops.im2col_split(img, P, cols)

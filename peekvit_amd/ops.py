@@ -81,10 +81,21 @@ def _stream(t: torch.Tensor):
 # Operand-range guard (fp16-operand library, include/peekvit_hip.h `range_flag`): while `range_flag` holds a 1-element int32 GPU
 # tensor the data-dependent operand producers (QKV / GELU GEMM epilogues, the fp32 patch gather) OR 1 into it when a value does
 # not fit fp16.  engine.forward_auto zeroes it before and reads it after a forward.
-range_flag: Optional[torch.Tensor] = None
+# Per THREAD: another thread's guarded forward has its own flag word.
+import threading as _threading
+_tls = _threading.local()
+
+
+def set_range_flag(flag: Optional[torch.Tensor]):
+    _tls.range_flag = flag
+
+
+def current_range_flag() -> Optional[torch.Tensor]:
+    return getattr(_tls, "range_flag", None)
 
 
 def _flag(dev):
+    range_flag = current_range_flag()
     return C.c_void_p(range_flag.data_ptr()) if range_flag is not None and range_flag.device == dev else C.c_void_p(0)
 
 
@@ -171,6 +182,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
     if M is None:
         M = a.numel() // K
     N = w.shape[0]
+    range_flag = current_range_flag()
     args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr() if bias is not None else 0,
                     out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
                     row_scale=row_scale.data_ptr() if row_scale is not None else 0,

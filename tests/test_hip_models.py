@@ -562,3 +562,40 @@ def test_empty_batch_returns_empty_logits():
     with torch.no_grad():
         y = m(torch.empty(0, 3, cfg["image_size"], cfg["image_size"], device=DEV))
     assert y.shape == (0, cfg["num_classes"]) and ops.launch_count == n0
+
+
+def test_two_threads_forward_concurrently():
+    """Two Python threads run guarded forwards at the same time on the same GPU and (default) stream - one of them keeps tripping the fp16 range
+    guard and repeating on bf16 operands, i.e. switching the operand library around its forwards.  Mode, operand library, range flag and
+    scratch arena are per thread: each thread's logits are the ones it gets alone."""
+    import threading
+    import warnings
+    cfg, m_ok = _model("vit", "vit_small")
+    _, m_ovf = _model("vit", "vit_small")
+    with torch.no_grad():
+        m_ovf.encoder.layers[1].mlp.fc1.bias.add_(1e5)           # GELU outputs beyond fp16: every forward of this model falls back to bf16
+    xa, xb = _x(cfg, 24).to(DEV), _x(cfg, 17).to(DEV)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_a, ref_b = m_ok(xa).clone(), m_ovf(xb).clone()
+    out, err = {}, []
+
+    def work(name, model, x, ref):
+        try:
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(12):
+                    y = model(x)
+                    if not torch.equal(y, ref):
+                        err.append(name)
+                        return
+            out[name] = True
+        except Exception as e:                                    # noqa: BLE001 - reported below
+            err.append(f"{name}: {type(e).__name__}: {e}")
+
+    ts = [threading.Thread(target=work, args=("fp16 thread", m_ok, xa, ref_a)), threading.Thread(target=work, args=("fallback thread", m_ovf, xb, ref_b))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err and len(out) == 2, err

@@ -202,7 +202,7 @@ def test_range_flag_is_raised_by_the_fp16_kernels_only():
             with engine.precision(lib):
                 a16, w16 = ops.cast_bf16(a.to(DEV)), ops.cast_bf16(w.to(DEV))
                 out = torch.empty((M, N), dtype=a16.dtype, device=DEV)
-                ops.range_flag = flag
+                ops.set_range_flag(flag)
                 try:
                     for epi in (PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16):
                         flag.zero_()
@@ -213,17 +213,17 @@ def test_range_flag_is_raised_by_the_fp16_kernels_only():
                         if lib == "bf16":
                             assert torch.isfinite(out.float()).all()
                 finally:
-                    ops.range_flag = None
+                    ops.set_range_flag(None)
     img = torch.zeros(2, 3, 32, 32)
     cols = torch.empty((2 * 16, 3 * 64), dtype=torch.float16, device=DEV)
     with engine.precision("f16"):
-        ops.range_flag = flag
+        ops.set_range_flag(flag)
         try:
             flag.zero_(); ops.im2col(img.to(DEV), 8, cols); assert int(flag.item()) == 0
             img[1, 2, 17, 5] = -1.0e5
             ops.im2col(img.to(DEV), 8, cols); assert int(flag.item()) == 1
         finally:
-            ops.range_flag = None
+            ops.set_range_flag(None)
 
 
 def test_auto_mode_falls_back_to_bf16_when_an_activation_overflows_fp16():
