@@ -188,13 +188,20 @@ class BlockFn(torch.autograd.Function):
         # ---- MLP branch ------------------------------------------------------------------------------------
         dout3 = dout
         dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
+        # frozen parameters (the reference's finetuning trains gates / class tokens / head only, train/train.py:100): their weight-gradient
+        # GEMMs - a fifth of the step - and bias sums are not computed.  needs_input_grad follows forward's argument order.
+        need = dict(zip(("ln1w", "ln1b", "inw", "inb", "ow", "ob", "ln2w", "ln2b", "w1", "b1", "w2", "b2"), ctx.needs_input_grad[2:14]))
         d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
-        dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
-        db2 = db2c if db2 is None else db2
+        dw2 = None
+        if need["w2"]:
+            dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
+            db2 = db2c if db2 is None else db2
+        elif need["b2"] and db2 is None:
+            db2 = ops.colsum(d2, torch.empty((D,), dtype=torch.float32, device=dev))
         dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
-        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev)
+        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev) if need["b1"] else None
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]", colsum_out=db1)
-        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
+        dw1 = _wgrad(dpre, h2, "fc1", bias_grad=False)[0] if need["w1"] else None
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
@@ -202,15 +209,15 @@ class BlockFn(torch.autograd.Function):
         d1 = ws.get("bw_d1", (R, D), bf, dev)
         ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
         # ---- attention branch ------------------------------------------------------------------------------
-        dwo, _ = _wgrad(d1, att, "proj", bias_grad=False)
+        dwo = _wgrad(d1, att, "proj", bias_grad=False)[0] if need["ow"] else None
         dbo = dgb2[2]                                                           # column sums of d1, from the LN2 backward pass
         datt = ws.get("bw_datt", (R, D), bf, dev)
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
-        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev)
+        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev) if need["inb"] else None
         ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
-        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev))        # sum of the per-image column sums
-        dwin, _ = _wgrad(dqkv, h1, "qkv", bias_grad=False)
+        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev)) if need["inb"] else None    # sum of the per-image column sums
+        dwin = _wgrad(dqkv, h1, "qkv", bias_grad=False)[0] if need["inw"] else None
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
@@ -274,13 +281,19 @@ class MaskedBlockFn(torch.autograd.Function):
         ws = workspace
         dout3 = dout
         dout = (dout if dout.is_contiguous() else dout.contiguous()).view(R, D)
+        # frozen block weights (the reference finetunes ResidualViT's gates / class tokens / head only, train/train.py:100): no weight-gradient GEMMs
+        need = dict(zip(("ln1w", "ln1b", "inw", "inb", "ow", "ob", "ln2w", "ln2b", "w1", "b1", "w2", "b2"), ctx.needs_input_grad[3:15]))
         d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
-        dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
-        db2 = db2c if db2 is None else db2
+        dw2 = None
+        if need["w2"]:
+            dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
+            db2 = db2c if db2 is None else db2
+        elif need["b2"] and db2 is None:
+            db2 = ops.colsum(d2, torch.empty((D,), dtype=torch.float32, device=dev))
         dpre = ws.get("bw_dgl", (R, Mh), bf, dev)
-        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev)
+        db1 = torch.empty((Mh,), dtype=torch.float32, device=dev) if need["b1"] else None
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]", colsum_out=db1)
-        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
+        dw1 = _wgrad(dpre, h2, "fc1", bias_grad=False)[0] if need["w1"] else None
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
@@ -289,15 +302,15 @@ class MaskedBlockFn(torch.autograd.Function):
         dm = torch.empty((R,), dtype=torch.float32, device=dev)
         ops.layernorm_bwd_masked(x1.view(R, D), dhid, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), mrow, dout, u, dx1, du, True, dgb2, dm, False,
                                  blk.ln_2.eps)
-        dwo, _ = _wgrad(du, att, "proj", bias_grad=False)
+        dwo = _wgrad(du, att, "proj", bias_grad=False)[0] if need["ow"] else None
         dbo = dgb2[2]
         datt = ws.get("bw_datt", (R, D), bf, dev)
         ops.gemm(du, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
-        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev)
+        dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev) if need["inb"] else None
         ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
-        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev))
-        dwin, _ = _wgrad(dqkv, h1, "qkv", bias_grad=False)
+        dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev)) if need["inb"] else None
+        dwin = _wgrad(dqkv, h1, "qkv", bias_grad=False)[0] if need["inw"] else None
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dxb = torch.empty((B, S, D), dtype=bf, device=dev)
@@ -428,12 +441,17 @@ class RowsBlockFn(torch.autograd.Function):
         ws = workspace
         dout = (dout.float() if dout.dtype != f32 else dout).contiguous().view(B, D)
         # ---- MLP branch, class rows ---------------------------------------------------------------------------
+        need = dict(zip(("ln1w", "ln1b", "inw", "inb", "ow", "ob", "ln2w", "ln2b", "w1", "b1", "w2", "b2"), ctx.needs_input_grad[3:15]))   # frozen: skipped
         d2 = ops.cast_bf16(dout, torch.empty((B, D), dtype=bf, device=dev))
-        dw2, db2 = _wgrad(d2, gl, "fc2")
+        dw2, db2 = None, None
+        if need["w2"]:
+            dw2, db2 = _wgrad(d2, gl, "fc2")
+        elif need["b2"]:
+            db2 = dout.sum(0)
         dpre = torch.empty((B, Mh), dtype=bf, device=dev)
-        db1 = torch.empty((Mh,), dtype=f32, device=dev)
+        db1 = torch.empty((Mh,), dtype=f32, device=dev) if need["b1"] else None
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=B, res=pre, tag="[dgrad]", colsum_out=db1)
-        dw1, _ = _wgrad(dpre, h2, "fc1", bias_grad=False)
+        dw1 = _wgrad(dpre, h2, "fc1", bias_grad=False)[0] if need["w1"] else None
         dhq = torch.empty((B, D), dtype=bf, device=dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhq, PV_EPI_BIAS_BF16, M=B, tag="[dgrad]")
         dx1 = torch.empty((B, D), dtype=f32, device=dev)
@@ -441,17 +459,21 @@ class RowsBlockFn(torch.autograd.Function):
         d1 = torch.empty((B, D), dtype=bf, device=dev)
         ops.layernorm_bwd(x1, dhq, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
         # ---- attention branch ---------------------------------------------------------------------------------
-        dwo, _ = _wgrad(d1, att, "proj", bias_grad=False)
+        dwo = _wgrad(d1, att, "proj", bias_grad=False)[0] if need["ow"] else None
         datt = torch.empty((B, D), dtype=bf, device=dev)
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=B, tag="[dgrad]")
         dq = torch.empty((B, D), dtype=bf, device=dev)
         dkv = ws.get("bw_dqkv", (R, 2 * D), bf, dev)
         ops.attention_rows_bwd(q, kv, att, datt, dq, dkv, B, S, H, dh, qscale)
-        dbin = torch.empty((3 * D,), dtype=f32, device=dev)
-        ops.colsum(dq, dbin[:D])
-        ops.colsum(dkv, dbin[D:])
+        dbin = None
+        if need["inb"]:
+            dbin = torch.empty((3 * D,), dtype=f32, device=dev)
+            ops.colsum(dq, dbin[:D])
+            ops.colsum(dkv, dbin[D:])
         h1c = h1.view(B, S, D)[:, 0]                                           # LN1 output of the class rows (row-strided view)
-        dwin = torch.cat([_wgrad(dq, h1c, "q", bias_grad=False)[0], _wgrad(dkv, h1, "qkv", bias_grad=False)[0]], dim=0)
+        dwin = None
+        if need["inw"]:                                                        # frozen in the reference's gates-only finetuning
+            dwin = torch.cat([_wgrad(dq, h1c, "q", bias_grad=False)[0], _wgrad(dkv, h1, "qkv", bias_grad=False)[0]], dim=0)
         wt = bf16_weight_t(mha.in_proj_weight)                                 # [D, 3D]
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dkv, wt[:, D:], None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
@@ -511,16 +533,21 @@ class EmbedFn(torch.autograd.Function):
         u8 = img.dtype == torch.uint8
         Cin = img.shape[3] if u8 else img.shape[1]
         K = Cin * P * P
-        cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
-        if u8:
-            from .engine import IMAGENET_MEAN, IMAGENET_STD
-            ops.im2col_u8(img, P, cols, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
-        else:
-            ops.im2col(img if img.dtype == torch.float32 else img.float(), P, cols)
-        dpatch32 = dtok[:, nsp:, :].contiguous().view(B * Np, D)
-        dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), torch.bfloat16, dev))
-        dwc, dbc = _wgrad(dpatch, cols, "conv")
-        dwc = dwc.view(model.conv_proj.weight.shape)
+        dwc, dbc = None, None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:          # a frozen stem (gates / class tokens / head finetuning) costs nothing here
+            dpatch32 = dtok[:, nsp:, :].contiguous().view(B * Np, D)
+            dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), torch.bfloat16, dev))
+            if ctx.needs_input_grad[2]:
+                cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
+                if u8:
+                    from .engine import IMAGENET_MEAN, IMAGENET_STD
+                    ops.im2col_u8(img, P, cols, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
+                else:
+                    ops.im2col(img if img.dtype == torch.float32 else img.float(), P, cols)
+                dwc, dbc = _wgrad(dpatch, cols, "conv")
+                dwc = dwc.view(model.conv_proj.weight.shape)
+            else:
+                dbc = ops.colsum(dpatch, torch.empty((D,), dtype=torch.float32, device=dev))
         dpos = ops.colsum(dtok.view(B, S * D), torch.empty((S * D,), dtype=torch.float32, device=dev)).view(1, S, D)
         dcls = dpos[:, :ncls].clone()
         dreg = dpos[:, ncls:nsp].clone() if ctx.has_reg else None
@@ -528,6 +555,10 @@ class EmbedFn(torch.autograd.Function):
 
 
 def embed_tokens_train(model: nn.Module, img: torch.Tensor) -> torch.Tensor:
+    if img.requires_grad:
+        # someone differentiates with respect to the IMAGE (saliency maps, adversarial examples): EmbedFn has no col2im, so the stem runs on
+        # the stock convolution (0.7 % of the FLOPs) and autograd delivers dL/d(image); the blocks behind it stay on the HIP functions
+        return model._composite_tokens(img.float() if img.dtype != torch.float32 else img) + model.encoder.pos_embedding
     reg = model.register_tokens if model.num_registers > 0 else None
     return EmbedFn.apply(model, img, model.conv_proj.weight, model.conv_proj.bias, model.encoder.pos_embedding, model.class_tokens, reg)
 

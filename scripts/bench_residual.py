@@ -40,4 +40,21 @@ for B in (512, 1024):
     pv = sum(v["ms"] for v in kt.summary().values())
     out[f"train step B={B}"] = {"img_per_s": round(B / dt, 1), "ms": round(dt * 1e3, 2), "ms_in_pv_kernels": round(pv, 2),
                                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(kt.summary().items(), key=lambda kv: -kv[1]["ms"])}}
+# the reference's finetuning (train/train.py:100): only parameters named gate / class / head / threshold / budget are trained
+for n, p in m.named_parameters():
+    p.requires_grad_(any(k in n for k in ("gate", "class", "head", "threshold", "budget")))
+B = 1024
+xb, y = x[:B], torch.randint(0, 1000, (B,), device="cuda")
+def step():
+    for p in m.parameters(): p.grad = None
+    torch.nn.functional.cross_entropy(m(xb), y).backward()
+for _ in range(2): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+with ops.KernelTimer() as kt:
+    step()
+torch.cuda.synchronize()
+out[f"finetune step (gates / class tokens / head only) B={B}"] = {"img_per_s": round(B / dt, 1), "ms": round(dt * 1e3, 2),
+    "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(kt.summary().items(), key=lambda kv: -kv[1]["ms"])}}
 print(json.dumps(out, indent=1))

@@ -324,6 +324,46 @@ def test_residualvit_last_block_class_row_backward_matches_all_rows(monkeypatch,
         assert rel_l2(pr.grad, pa.grad) < (6e-2 if pr.numel() == 1 else 2e-2), (n, rel_l2(pr.grad, pa.grad))
 
 
+def test_frozen_weights_skip_their_weight_gradient_gemms(monkeypatch):
+    """The reference's finetuning trains only parameters whose names contain gate / class / head / threshold / budget (train/train.py:100):
+    frozen block weights get no weight-gradient GEMM (a fifth of the step), the remaining gradients equal the stock-op composite's."""
+    from peekvit_amd import ops
+    cfg, (m_hip, m_ref), x, y = _train_pair("vit_tiny", 4)
+    for m in (m_hip, m_ref):
+        for n, p in m.named_parameters():
+            p.requires_grad_(any(k in n for k in ("gate", "class", "head", "threshold", "budget")) or n.endswith("ln_2.weight"))
+    with ops.KernelTimer() as kt:
+        torch.nn.functional.cross_entropy(m_hip(x), y).backward()
+    torch.cuda.synchronize()
+    ks = kt.summary()
+    assert "pv_gemm_tn_bf16[wgrad]" not in ks and "pv_gemm_bf16[wgrad]" not in ks, sorted(ks)
+    assert ks["pv_gemm_bf16[dgrad]"]["launches"] >= 4 * (cfg["num_layers"] - 1)              # the data gradients still flow to the class token / stem
+    monkeypatch.setenv("PEEKVIT_AMD_TRAIN", "torch")
+    torch.nn.functional.cross_entropy(m_ref(x), y).backward()
+    trained = 0
+    for (n, ph), (_, pr) in zip(m_hip.named_parameters(), m_ref.named_parameters()):
+        assert (ph.grad is None) == (pr.grad is None), n
+        if pr.grad is not None:
+            trained += 1
+            assert rel_l2(ph.grad, pr.grad) < 3e-2, (n, rel_l2(ph.grad, pr.grad))
+    assert trained >= 3 + cfg["num_layers"]
+
+
+def test_gradient_with_respect_to_the_image(monkeypatch):
+    """Saliency maps / adversarial examples differentiate with respect to the IMAGE: the stem then runs on the stock convolution (the HIP stem
+    has no col2im) while the blocks stay on the HIP functions, and dL/d(image) matches the stock-op composite."""
+    from peekvit_amd import ops
+    cfg, (m_hip, m_ref), x, y = _train_pair("vit_tiny", 3)
+    xh, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    n0 = ops.launch_count
+    torch.nn.functional.cross_entropy(m_hip(xh), y).backward()
+    assert ops.launch_count - n0 > 20 * cfg["num_layers"], "the blocks did not run on the HIP training path"
+    monkeypatch.setenv("PEEKVIT_AMD_TRAIN", "torch")
+    torch.nn.functional.cross_entropy(m_ref(xr), y).backward()
+    assert xh.grad is not None and xh.grad.shape == x.shape and rel_l2(xh.grad, xr.grad) < 3e-2
+    assert rel_l2(m_hip.conv_proj.weight.grad, m_ref.conv_proj.weight.grad) < 3e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048, 768, 256), (4096, 1536, 384), (2300, 128, 64)])
 def test_gemm_training_epilogues(ops, M, N, K):
     """PV_EPI_BIAS_GELU_PAIR_BF16 ([gelu | pre] in one pass) and PV_EPI_GELU_GRAD_BF16 (product * gelu'(pre)), both tile kernels."""
