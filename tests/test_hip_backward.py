@@ -594,3 +594,36 @@ def test_residualvit_training_step_vs_reference_golden(golden):
         if key.startswith(f"{name}/grad/"):
             clip = min(1.0, 1.0 / (total_ref + 1e-6))          # the stored gradients are post-clip (max_norm 1.0)
             assert rel_l2(named[key.split("/grad/")[1]].grad * clip, g[key]) < 3e-2, key
+
+
+def test_training_curve_tracks_the_fp32_composite(monkeypatch):
+    """End to end, many steps: vit_tiny on a learnable synthetic task, Adam(1e-3) + clip 1.0 as in train/train.py:112-121 - the loss of the HIP
+    training path (forward with saved activations, hand-written backward, weight caches refreshed after every optimizer step) follows the
+    stock-op fp32 composite's step for step and the task is learned.  (scripts/train_curve.py: 60 steps, max |difference| 1.1e-3.)"""
+    from peekvit_amd import synth
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_tiny"]
+    g = torch.Generator().manual_seed(0)
+    N, B, steps = 256, 32, 30
+    x = torch.randn(N, 3, cfg["image_size"], cfg["image_size"], generator=g) + 2.0 * torch.randn(N, 3, 1, 1, generator=g)
+    y = (x.mean(dim=(2, 3)) @ torch.randn(3, cfg["num_classes"], generator=g)).argmax(1)
+    curves = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("PEEKVIT_AMD_TRAIN", mode)
+        m = VisionTransformer(**cfg)
+        synth.load_synth_weights(m, cfg)
+        m = m.cuda().train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        losses = []
+        for s in range(steps):
+            idx = torch.arange(s * B, (s + 1) * B) % N
+            opt.zero_grad()
+            loss = torch.nn.functional.cross_entropy(m(x[idx].cuda()), y[idx].cuda())
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves[mode] = losses
+    worst = max(abs(a - b) for a, b in zip(curves["hip"], curves["torch"]))
+    assert worst < 2e-2, (worst, curves)
+    assert sum(curves["hip"][-5:]) < 0.5 * sum(curves["hip"][:5]), curves["hip"]
