@@ -747,6 +747,8 @@ def sort_and_drop(x: torch.Tensor, budget: float):
     B, S = x.shape[0], x.shape[1]
     N = S - 1
     k = math.ceil(N * budget)
+    if k <= 0:                                   # budget 0: every patch token is dropped, the class token alone goes on (rankvit.py:74 keeps ceil(N*0) = 0)
+        return x[:, :1].contiguous(), torch.empty((B, 0), dtype=torch.int32, device=x.device)
     if hand is not None and hand[0].shape[1] == B * S and hand[0].device == x.device:
         keep = ops.rank_topk_partials(hand[0], B, S, k)          # norms left behind by the producer's fc2 epilogue
     else:

@@ -581,6 +581,10 @@ class SortDropFn(torch.autograd.Function):
     def backward(ctx, dout, _dkeep):
         (keep,) = ctx.saved_tensors
         dout = dout.float() if dout.dtype != torch.float32 else dout
+        if keep.shape[1] == 0:                     # budget 0: only the class token went on
+            dx = dout.new_zeros((dout.shape[0], ctx.s_in, dout.shape[2]))
+            dx[:, :1] = dout
+            return dx, None
         return ops.scatter_tokens(dout if dout.is_contiguous() else dout.contiguous(), keep, ctx.s_in), None
 
 

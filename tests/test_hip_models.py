@@ -599,3 +599,24 @@ def test_two_threads_forward_concurrently():
     for t in ts:
         t.join()
     assert not err and len(out) == 2, err
+
+
+def test_rankvit_budget_zero_keeps_the_class_token_only():
+    """models/rankvit.py:74 keeps ceil(N * budget) tokens: budget 0 drops every patch token, the class token alone goes on."""
+    import os
+    cfg, m = _model("rank", "vit_tiny", rankvit_layers=[1, 2])
+    m.set_budget(0.0)
+    x = _x(cfg, 3).to(DEV)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (3, cfg["num_classes"]) and torch.isfinite(y).all() and m.encoder.layers[1].last_keep.shape == (3, 0)
+    os.environ["PEEKVIT_AMD_BACKEND"] = "torch"
+    try:
+        with torch.no_grad():
+            ref = m(x)
+    finally:
+        del os.environ["PEEKVIT_AMD_BACKEND"]
+    assert rel_l2(y.cpu(), ref.cpu()) < 5e-3
+    m.train()
+    torch.nn.functional.cross_entropy(m(x), torch.arange(3, device=DEV)).backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
