@@ -333,7 +333,9 @@ class ResidualVisionTransformer(_ViTBase):
             btok, budget = None, 0.0
             if self.add_budget_token == 'learnable':
                 assert self.current_budget is not None, 'Budget token not set. Call set_budget() before forward() to evaluate the model on a chosen budget.'
-                btok, budget = self.learnable_budget_token_1.detach().view(-1), float(self.current_budget)
+                cached = getattr(self, "_pv_budget", None)      # set_budget's value as a host float: no device read (a sync; illegal under graph capture)
+                budget = cached[1] if cached is not None and cached[0] is self.current_budget else float(self.current_budget)
+                btok = self.learnable_budget_token_1.detach().view(-1)
             return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x, btok, budget), _pos_added=True,
                                                                                                    _rows=self.num_class_tokens)))
         if (self.training and train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout))
@@ -355,3 +357,4 @@ class ResidualVisionTransformer(_ViTBase):
         if self.training:
             raise ValueError('You cannot set the budget during training in this model. This model has a learnable budget so you have to set it at the beginning of the training and then sample it during training. Use the add_budget_token parameter to specify the budget sampling strategy.')
         self.current_budget = torch.tensor(budget, device=self.class_tokens.device)
+        object.__setattr__(self, "_pv_budget", (self.current_budget, float(budget)))

@@ -620,3 +620,18 @@ def test_rankvit_budget_zero_keeps_the_class_token_only():
     m.train()
     torch.nn.functional.cross_entropy(m(x), torch.arange(3, device=DEV)).backward()
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize("kind,extra,budget", [("rank", {"rankvit_layers": [1, 3]}, 0.5),
+                                               ("res", dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5), 0.5)])
+def test_hip_graph_replay_of_the_pruning_models(kind, extra, budget):
+    """RankViT (ranking + compaction) and ResidualViT (gate + masked blocks) forwards are capturable as one hipGraph: no host read of a device
+    value inside them (the budget is kept as a host float by set_budget); replay is bit-identical to eager, also after new input."""
+    from peekvit_amd.graph import GraphedForward
+    cfg, m = _model(kind, "vit_tiny", **extra)
+    m.set_budget(budget)
+    x0, x1 = _x(cfg, 6).to(DEV), torch.from_numpy(synth.synth_images(6, cfg["image_size"], seed=9)).to(DEV)
+    with torch.no_grad():
+        g = GraphedForward(m, x0)
+        for x in (x0, x1, x0):
+            assert torch.equal(g(x).clone(), m(x))
