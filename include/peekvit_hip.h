@@ -198,6 +198,10 @@ int pv_gemm_tn_bf16(const pv_gemm_args* args, void* stream);
 
 /* out[n] (+)= sum_t partials[t*n_elems + n]: reduces split-K slices (accumulate != 0 adds to the existing out). fp32. */
 int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream);
+/* out = base + sum over the slices (base may alias out): finishes a split-K pv_gemm_bf16 (PV_EPI_BIAS_F32, ksplit > 1, bias in slice 0) as
+ * bias + residual add - the small-batch form of PV_EPI_BIAS_RES_F32 (models/vit.py:51,55), where the token rows alone would occupy a
+ * dozen of the 256 CUs through a long K loop. */
+int pv_sum_slices_add_f32(const float* partials, const float* base, float* out, int64_t n_elems, int64_t slices, void* stream);
 /* bf16 [R,C] (row stride lds >= C) -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be
  * a multiple of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
 /* colsum_out (fp32 [C], optional): also the column sums of src (the bias gradient when src = dY), from the same pass;

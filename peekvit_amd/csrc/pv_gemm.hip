@@ -1383,7 +1383,8 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     const bool feat = a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out;
     const bool big = !((a->epilogue == PV_EPI_BIAS_BF16 || a->epilogue == PV_EPI_BIAS_F32) && p.qcols % 8) &&
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
-                                       ((tiles256 >= 128 && !ragged_short) || feat || (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256))));
+                                       ((tiles256 >= 128 && !ragged_short) || feat ||
+                                        (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256 && tiles256 * p.ksplit >= 64))));   // (a few-row split-K GEMM - small-batch residual GEMMs - fills more CUs with 128^2 tiles)
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
     if ((a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
     if (query_only) return big ? G2_BM : G1_BM;

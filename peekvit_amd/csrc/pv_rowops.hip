@@ -168,10 +168,10 @@ extern "C" int pv_im2col_u8_bf16(const uint8_t* x, uint16_t* cols, int64_t B, in
 // ------------------------------------------------------------------------------------------------
 // backward helpers: split-K slice reduction, bf16 transpose, column sums
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pv_sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int slices, int accumulate) {
+__global__ __launch_bounds__(256) void pv_sum_slices_kernel(const float* __restrict__ part, const float* base, float* out, int64_t n, int slices) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = base ? reinterpret_cast<const float4*>(base)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t = 0; t < slices; ++t) {
             const float4 v = reinterpret_cast<const float4*>(part + (int64_t)t * n)[i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -183,7 +183,17 @@ __global__ __launch_bounds__(256) void pv_sum_slices_kernel(const float* __restr
 extern "C" int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_t slices, int accumulate, void* stream) {
     if (!partials || !out || n_elems <= 0 || slices <= 0) return PV_ERR_INVALID_ARG;
     if (n_elems % 4 || ((uintptr_t)partials & 15) || ((uintptr_t)out & 15)) return PV_ERR_UNSUPPORTED;
-    PV_LAUNCH(pv_sum_slices_kernel, dim3(pv_stream_grid(n_elems / 4, 256)), dim3(256), 0, (hipStream_t)stream, partials, out, n_elems, (int)slices, accumulate);
+    PV_LAUNCH(pv_sum_slices_kernel, dim3(pv_stream_grid(n_elems / 4, 256)), dim3(256), 0, (hipStream_t)stream, partials, accumulate ? (const float*)out : (const float*)nullptr, out,
+              n_elems, (int)slices);
+    return pv_check_launch();
+}
+
+// out = base + sum of the slices (base may be out): the second half of a split-K GEMM with a residual - the small-batch form of
+// PV_EPI_BIAS_RES_F32 (slice 0 carries the bias), where M rows alone would put a dozen workgroups on 256 CUs.
+extern "C" int pv_sum_slices_add_f32(const float* partials, const float* base, float* out, int64_t n_elems, int64_t slices, void* stream) {
+    if (!partials || !base || !out || n_elems <= 0 || slices <= 0) return PV_ERR_INVALID_ARG;
+    if (n_elems % 4 || ((uintptr_t)partials & 15) || ((uintptr_t)out & 15) || ((uintptr_t)base & 15)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_sum_slices_kernel, dim3(pv_stream_grid(n_elems / 4, 256)), dim3(256), 0, (hipStream_t)stream, partials, base, out, n_elems, (int)slices);
     return pv_check_launch();
 }
 

@@ -439,6 +439,37 @@ def _fold_ok(R: int, D: int, M: int) -> bool:
     return ok
 
 
+# Small batches (serving): a residual GEMM over a few hundred token rows is a dozen 128^2 tiles on 256 CUs walking the whole K (fc2 at batch 1:
+# 12 workgroups x 48 K-steps = 45 us of a 1.3 ms forward).  It runs split-K instead - fp32 partial slices (bias in slice 0) over many more
+# workgroups, then one pass that adds the slices to the residual.  Summation order differs from the one-pass kernel: logits are bit-identical
+# across batch sizes only among batches that take the same form (like LayerNorm folding).  PEEKVIT_AMD_SPLITK=0 disables.
+_SMALL_M_SPLITK = os.environ.get("PEEKVIT_AMD_SPLITK", "1") != "0"
+
+
+def _splitk_slices(M: int, N: int, K: int) -> int:
+    if not _SMALL_M_SPLITK or K < 2048:          # fc2 (K = mlp_dim) is the 45 us kernel; splitting the K = hidden_dim GEMMs buys little and costs the
+        return 1                                 # eager (host-bound) small-batch path two more launches each
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 96:
+        return 1
+    best = 1
+    for s_ in (2, 3, 4, 6, 8, 12, 16):
+        if K % (s_ * 64) == 0 and K // s_ >= 256 and tiles * s_ <= 384:
+            best = s_
+    return best
+
+
+def _residual_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out2d: torch.Tensor, res2d: torch.Tensor, M: int, **kw):
+    """out = res + a . w^T + bias (PV_EPI_BIAS_RES_F32), split-K for few rows when nothing else rides on the epilogue."""
+    N, K = w.shape[0], a.shape[-1]
+    ks = _splitk_slices(M, N, K) if not kw and res2d.is_contiguous() and out2d.is_contiguous() else 1
+    if ks > 1:
+        part = workspace.get("splitk", (ks, M, N), torch.float32, a.device)
+        ops.gemm(a, w, bias, part, PV_EPI_BIAS_F32, M=M, ksplit=ks)
+        return ops.sum_slices(part, out2d, base=res2d)
+    return ops.gemm(a, w, bias, out2d, PV_EPI_BIAS_RES_F32, M=M, res=res2d, **kw)
+
+
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
                   next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
@@ -522,9 +553,12 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
              qcols=D, qscale=float(dh) ** -0.5)
     ops.attention(qkv, att, B, S, H, dh)
     fuse2 = _ln_fusable(D, D)
-    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-             res=x.view(R, D), row_scale=row_scale,
-             ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale) if fuse2 else None)
+    if fuse2 or row_scale is not None:
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
+                 res=x.view(R, D), row_scale=row_scale,
+                 ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale) if fuse2 else None)
+    else:
+        _residual_gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), x.view(R, D), R)
     if not fuse2:
         ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
     ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
@@ -533,9 +567,12 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     rowsq = None
     if next_ranks and not fuse_next and _FUSE_RANK_NORM and ops.gemm_tile_rows(R, D, M, PV_EPI_BIAS_RES_F32) == 256:
         rowsq = workspace.get("rowsq", ((D + 255) // 256, R), torch.float32, dev)
-    ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-             res=x1.view(R, D), rowsq_out=rowsq,
-             ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
+    if fuse_next or rowsq is not None:
+        ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
+                 res=x1.view(R, D), rowsq_out=rowsq,
+                 ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
+    else:
+        _residual_gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), x1.view(R, D), R)
     if fuse_next:
         out._pv_ln = (hn, _ln_key(next_ln))
     if rowsq is not None:
@@ -618,12 +655,15 @@ def block_forward_rows(blk: nn.Module, x: torch.Tensor, eps: float, nq: int, row
     att = workspace.get("rows_att", (Rq, D), od, dev)
     ops.attention_rows(qb, kv, att, B, S, nq, H, dh)
     x1 = workspace.get("rows_x1", (Rq, D), torch.float32, dev)
-    ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, PV_EPI_BIAS_RES_F32, M=Rq, res=xq, row_scale=rsq)
+    if rsq is None:
+        _residual_gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, xq, Rq)
+    else:
+        ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1, PV_EPI_BIAS_RES_F32, M=Rq, res=xq, row_scale=rsq)
     ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, hq, rsq)
     g = workspace.get("rows_g", (Rq, M), od, dev)
     ops.gemm(hq, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=Rq)
     out = torch.empty((B, nq, D), dtype=torch.float32, device=dev)
-    ops.gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(Rq, D), PV_EPI_BIAS_RES_F32, M=Rq, res=x1)
+    _residual_gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(Rq, D), x1, Rq)
     return out
 
 
