@@ -202,6 +202,10 @@ int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_
  * bias + residual add - the small-batch form of PV_EPI_BIAS_RES_F32 (models/vit.py:51,55), where the token rows alone would occupy a
  * dozen of the 256 CUs through a long K loop. */
 int pv_sum_slices_add_f32(const float* partials, const float* base, float* out, int64_t n_elems, int64_t slices, void* stream);
+/* The same finish over rows of length D that also writes ln_out = 16-bit LayerNorm(out row; gamma, beta, eps) - the LayerNorm the consumer of
+ * the finished rows applies first (models/vit.py:48,53), bit-identical to pv_layernorm_bf16 on `out`. */
+int pv_sum_slices_add_ln_f32(const float* partials, const float* base, float* out, int64_t rows, int64_t D, int64_t slices, const float* gamma,
+                             const float* beta, float eps, uint16_t* ln_out, void* stream);
 /* bf16 [R,C] (row stride lds >= C) -> bf16 [C,ldd] (ldd >= R; columns R..ldd-1 zero-filled so that the GEMM K = ldd can be
  * a multiple of 64): the K-contiguous operands of dW = (dY^T) . (X^T)^T. */
 /* colsum_out (fp32 [C], optional): also the column sums of src (the bias gradient when src = dY), from the same pass;

@@ -197,6 +197,35 @@ extern "C" int pv_sum_slices_add_f32(const float* partials, const float* base, f
     return pv_check_launch();
 }
 
+// Row-wise finish of a split-K residual GEMM that ALSO emits the LayerNorm the consumer applies to the finished rows (small batches, where a
+// LayerNorm launch is latency, not bandwidth): one wave per row keeps it in registers - out = base + sum of slices, ln_out = 16-bit LN(out).
+// Same row arithmetic as pv_layernorm_bf16 (pv_ln_row).
+template <int NCH>
+__global__ __launch_bounds__(256) void pv_sum_slices_ln_kernel(const float* __restrict__ part, const float* base, float* out, int64_t rows, int D, int slices,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               uint16_t* __restrict__ ln_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
+    const int64_t n = rows * D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        RowRegs<NCH> r;
+        pv_load_row<NCH>(r, base + row * D, nvec, lane);
+        for (int t = 0; t < slices; ++t) {
+            RowRegs<NCH> v;
+            pv_load_row<NCH>(v, part + (int64_t)t * n + row * D, nvec, lane);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) { r.v[j].x += v.v[j].x; r.v[j].y += v.v[j].y; r.v[j].z += v.v[j].z; r.v[j].w += v.v[j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (lane + 64 * j < nvec) reinterpret_cast<float4*>(out + row * D)[lane + 64 * j] = r.v[j];
+        pv_ln_row<NCH>(r, gamma, beta, D, nvec, lane, eps);
+        u32x2* o = reinterpret_cast<u32x2*>(ln_out + row * (int64_t)D);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (lane + 64 * j < nvec) o[lane + 64 * j] = (u32x2){pv_pack_bf16x2(r.v[j].x, r.v[j].y), pv_pack_bf16x2(r.v[j].z, r.v[j].w)};
+    }
+}
+
 // 64 x 64 tiles through LDS; a workgroup walks a 64-column strip over 1024 source rows (16 tiles).  Fast path (C, lds, ldd
 // multiples of 8, 16-byte aligned): 16-byte global loads and stores, the transposition happens in the LDS read (8 two-byte
 // reads down a tile column).  CSUM: the strip's column sums over those 1024 rows fall out of the loaded registers and go
@@ -467,6 +496,18 @@ extern "C" int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma
 #define LN_LAUNCH(N) PV_LAUNCH(pv_layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, row_scale, out, rows, (int)D, eps)
     PV_DISPATCH_NCH(D, LN_LAUNCH);
 #undef LN_LAUNCH
+    return pv_check_launch();
+}
+
+extern "C" int pv_sum_slices_add_ln_f32(const float* partials, const float* base, float* out, int64_t rows, int64_t D, int64_t slices, const float* gamma,
+                                        const float* beta, float eps, uint16_t* ln_out, void* stream) {
+    if (!partials || !base || !out || !gamma || !beta || !ln_out || rows <= 0 || D <= 0 || slices <= 0) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 4096) return PV_ERR_UNSUPPORTED;
+    if (((uintptr_t)partials | (uintptr_t)base | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15 || ((uintptr_t)ln_out & 7)) return PV_ERR_INVALID_ARG;
+    dim3 grid(pv_stream_grid(rows, 4));
+#define SSL_LAUNCH(N) PV_LAUNCH(pv_sum_slices_ln_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, partials, base, out, rows, (int)D, (int)slices, gamma, beta, eps, ln_out)
+    PV_DISPATCH_NCH(D, SSL_LAUNCH);
+#undef SSL_LAUNCH
     return pv_check_launch();
 }
 

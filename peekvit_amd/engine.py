@@ -446,9 +446,11 @@ def _fold_ok(R: int, D: int, M: int) -> bool:
 _SMALL_M_SPLITK = os.environ.get("PEEKVIT_AMD_SPLITK", "1") != "0"
 
 
-def _splitk_slices(M: int, N: int, K: int) -> int:
-    if not _SMALL_M_SPLITK or K < 2048:          # fc2 (K = mlp_dim) is the 45 us kernel; splitting the K = hidden_dim GEMMs buys little and costs the
-        return 1                                 # eager (host-bound) small-batch path two more launches each
+def _splitk_slices(M: int, N: int, K: int, min_k: int = 2048) -> int:
+    # fc2 (K = mlp_dim) is the 45 us kernel; splitting a K = hidden_dim GEMM buys little and costs a launch - unless the finish pass replaces a
+    # LayerNorm launch that would follow anyway (min_k = 512)
+    if not _SMALL_M_SPLITK or K < min_k:
+        return 1
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 96:
         return 1
@@ -459,15 +461,18 @@ def _splitk_slices(M: int, N: int, K: int) -> int:
     return best
 
 
-def _residual_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out2d: torch.Tensor, res2d: torch.Tensor, M: int, **kw):
-    """out = res + a . w^T + bias (PV_EPI_BIAS_RES_F32), split-K for few rows when nothing else rides on the epilogue."""
+def _residual_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out2d: torch.Tensor, res2d: torch.Tensor, M: int, ln=None) -> bool:
+    """out = res + a . w^T + bias (PV_EPI_BIAS_RES_F32); for few rows split-K + one finish pass.  ln = (gamma, beta, eps, out16): the LayerNorm
+    the consumer applies to the finished rows - the finish pass emits it when the split form runs (returns True), else the caller launches it."""
     N, K = w.shape[0], a.shape[-1]
-    ks = _splitk_slices(M, N, K) if not kw and res2d.is_contiguous() and out2d.is_contiguous() else 1
+    ks = _splitk_slices(M, N, K, 512 if ln is not None else 2048) if res2d.is_contiguous() and out2d.is_contiguous() else 1
     if ks > 1:
         part = workspace.get("splitk", (ks, M, N), torch.float32, a.device)
         ops.gemm(a, w, bias, part, PV_EPI_BIAS_F32, M=M, ksplit=ks)
-        return ops.sum_slices(part, out2d, base=res2d)
-    return ops.gemm(a, w, bias, out2d, PV_EPI_BIAS_RES_F32, M=M, res=res2d, **kw)
+        ops.sum_slices(part, out2d, base=res2d, ln=ln)
+        return ln is not None
+    ops.gemm(a, w, bias, out2d, PV_EPI_BIAS_RES_F32, M=M, res=res2d)
+    return False
 
 
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
@@ -557,9 +562,11 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
                  res=x.view(R, D), row_scale=row_scale,
                  ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale) if fuse2 else None)
+        ln2_done = fuse2
     else:
-        _residual_gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), x.view(R, D), R)
-    if not fuse2:
+        ln2_done = _residual_gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), x.view(R, D), R,
+                                  ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2))
+    if not ln2_done:
         ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
     ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
     fuse_next = next_ln is not None and _ln_fusable(D, M) and next_ln.normalized_shape == (D,)
@@ -572,7 +579,10 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
                  res=x1.view(R, D), rowsq_out=rowsq,
                  ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn, None) if fuse_next else None)
     else:
-        _residual_gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), x1.view(R, D), R)
+        want = next_ln is not None and next_ln.normalized_shape == (D,)
+        hn = workspace.get("h", (R, D), _lib.operand_dtype(), dev) if want else None           # "h" is dead once QKV has consumed it
+        fuse_next = _residual_gemm(g, bf16_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), x1.view(R, D), R,
+                                   ln=(_f32(next_ln.weight), _f32(next_ln.bias), next_ln.eps, hn) if want else None)
     if fuse_next:
         out._pv_ln = (hn, _ln_key(next_ln))
     if rowsq is not None:

@@ -297,13 +297,20 @@ def head(pooled: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
 
 
 # ---- backward building blocks ---------------------------------------------------------------------------------------
-def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = False, base: Optional[torch.Tensor] = None) -> torch.Tensor:
+def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = False, base: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
     """out (+)= partials.sum(0); partials fp32 [S, ...] contiguous, out fp32 of the trailing shape.  base (fp32, same shape as out, may be
-    out): out = base + partials.sum(0) - the finish of a split-K GEMM with a residual."""
+    out): out = base + partials.sum(0) - the finish of a split-K GEMM with a residual; with ln = (gamma, beta, eps, out16 [rows, D]) the same
+    pass also emits the 16-bit LayerNorm of the finished rows (out viewed as [rows, D])."""
     _chk(partials, torch.float32, "partials"); _chk(out, torch.float32, "out")
     S = partials.shape[0]
     with _timed("pv_sum_slices_f32", out.device, 0.0, 4.0 * (S + 1 + (base is not None)) * out.numel()):
-        if base is not None:
+        if ln is not None:
+            _chk(base, torch.float32, "base"); _chk(ln[3], _lib.operand_dtype(), "ln out")
+            D = ln[3].shape[-1]
+            assert base.numel() == out.numel() == ln[3].numel() and base.is_contiguous() and out.is_contiguous()
+            check(_lib.load().pv_sum_slices_add_ln_f32(_ptr(partials), _ptr(base), _ptr(out), out.numel() // D, D, S, _ptr(ln[0]), _ptr(ln[1]), float(ln[2]),
+                                                       _ptr(ln[3]), _stream(out)), "pv_sum_slices_add_ln_f32")
+        elif base is not None:
             _chk(base, torch.float32, "base")
             assert base.numel() == out.numel() and base.is_contiguous() and out.is_contiguous()
             check(_lib.load().pv_sum_slices_add_f32(_ptr(partials), _ptr(base), _ptr(out), out.numel(), S, _stream(out)), "pv_sum_slices_add_f32")
