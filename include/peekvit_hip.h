@@ -202,6 +202,10 @@ int pv_sum_slices_f32(const float* partials, float* out, int64_t n_elems, int64_
  * bias + residual add - the small-batch form of PV_EPI_BIAS_RES_F32 (models/vit.py:51,55), where the token rows alone would occupy a
  * dozen of the 256 CUs through a long K loop. */
 int pv_sum_slices_add_f32(const float* partials, const float* base, float* out, int64_t n_elems, int64_t slices, void* stream);
+/* Finish of a split-K GEMM with a 16-bit output [M, N] (contiguous): out = gelu(sum of slices) when `gelu` (fc1 + F.gelu, models/blocks.py:81-82),
+ * else the sum with columns < qcols times qscale (the in-projection's q pre-scale); range_flag as in pv_gemm_args. */
+int pv_sum_slices_act_bf16(const float* partials, uint16_t* out, int64_t M, int64_t N, int64_t slices, int gelu, int64_t qcols, float qscale,
+                           uint32_t* range_flag, void* stream);
 /* The same finish over rows of length D that also writes ln_out = 16-bit LayerNorm(out row; gamma, beta, eps) - the LayerNorm the consumer of
  * the finished rows applies first (models/vit.py:48,53), bit-identical to pv_layernorm_bf16 on `out`. */
 int pv_sum_slices_add_ln_f32(const float* partials, const float* base, float* out, int64_t rows, int64_t D, int64_t slices, const float* gamma,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pv_gemm_tn_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "pv_sum_slices_f32": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
     "pv_sum_slices_add_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    "pv_sum_slices_act_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, C.c_int, _i64, _f32, _p, _p]),
     "pv_sum_slices_add_ln_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p]),
     "pv_transpose_bf16": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
     "pv_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, C.c_int, _p]),

@@ -197,6 +197,37 @@ extern "C" int pv_sum_slices_add_f32(const float* partials, const float* base, f
     return pv_check_launch();
 }
 
+// Elementwise finish of a split-K GEMM with a 16-bit output (small batches): out16 = f(sum of slices), f = exact GELU (fc1, models/blocks.py:82) or
+// the q pre-scale of the in-projection (columns < qcols times qscale); slice 0 carries the bias.  Tracks the operand range like the GEMM epilogues.
+__global__ __launch_bounds__(256) void pv_sum_slices_act_kernel(const float* __restrict__ part, uint16_t* __restrict__ out, int64_t M, int N, int slices, int gelu,
+                                                                int qcols, float qscale, uint32_t* range_flag) {
+    const int64_t n = M * N, n4 = n >> 2;
+    float vmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int t = 1; t < slices; ++t) {
+            const float4 v = reinterpret_cast<const float4*>(part + (int64_t)t * n)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (gelu) {
+            s.x = pv_gelu_fast(s.x); s.y = pv_gelu_fast(s.y); s.z = pv_gelu_fast(s.z); s.w = pv_gelu_fast(s.w);
+        } else if ((int)((i * 4) % N) < qcols) {          // N % 4 == 0 and qcols % 4 == 0: the four columns are on one side
+            s.x *= qscale; s.y *= qscale; s.z *= qscale; s.w *= qscale;
+        }
+        reinterpret_cast<u32x2*>(out)[i] = (u32x2){pv_pack_bf16x2_tracked(s.x, s.y, vmax), pv_pack_bf16x2_tracked(s.z, s.w, vmax)};
+    }
+    pv_range_commit(vmax, range_flag);
+}
+
+extern "C" int pv_sum_slices_act_bf16(const float* partials, uint16_t* out, int64_t M, int64_t N, int64_t slices, int gelu, int64_t qcols, float qscale,
+                                      uint32_t* range_flag, void* stream) {
+    if (!partials || !out || M <= 0 || N <= 0 || slices <= 0) return PV_ERR_INVALID_ARG;
+    if (N % 4 || qcols % 4 || N > 0x7fffffff || ((uintptr_t)partials & 15) || ((uintptr_t)out & 7)) return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH(pv_sum_slices_act_kernel, dim3(pv_stream_grid(M * N / 4, 256)), dim3(256), 0, (hipStream_t)stream, partials, out, M, (int)N, (int)slices, gelu,
+              (int)qcols, qscale, range_flag);
+    return pv_check_launch();
+}
+
 // Row-wise finish of a split-K residual GEMM that ALSO emits the LayerNorm the consumer applies to the finished rows (small batches, where a
 // LayerNorm launch is latency, not bandwidth): one wave per row keeps it in registers - out = base + sum of slices, ln_out = 16-bit LN(out).
 // Same row arithmetic as pv_layernorm_bf16 (pv_ln_row).

@@ -475,6 +475,17 @@ def _residual_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out2d: 
     return False
 
 
+def _act_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, M: int, gelu: bool, qcols: int = 0, qscale: float = 1.0):
+    """16-bit output GEMM (in-projection with the q pre-scale, fc1 with GELU): one pass, or for few rows split-K + an elementwise finish."""
+    N, K = w.shape[0], a.shape[-1]
+    ks = _splitk_slices(M, N, K, 512) if gelu and out.is_contiguous() else 1       # fc1: 48 workgroups x 12 K-steps + GELU = 18 us at batch 1
+    if ks > 1:
+        part = workspace.get("splitk", (ks, M, N), torch.float32, a.device)
+        ops.gemm(a, w, bias, part, PV_EPI_BIAS_F32, M=M, ksplit=ks)
+        return ops.sum_slices_act(part, out, gelu=gelu, qcols=qcols, qscale=qscale)
+    return ops.gemm(a, w, bias, out, PV_EPI_BIAS_GELU_BF16 if gelu else PV_EPI_BIAS_BF16, M=M, qcols=qcols, qscale=qscale)
+
+
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
                   next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
@@ -568,7 +579,7 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
                                   ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2))
     if not ln2_done:
         ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
-    ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, PV_EPI_BIAS_GELU_BF16, M=R)
+    _act_gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, R, gelu=True)
     fuse_next = next_ln is not None and _ln_fusable(D, M) and next_ln.normalized_shape == (D,)
     hn = workspace.get("h", (R, D), _lib.operand_dtype(), dev) if fuse_next else None      # "h" is dead once QKV has consumed it
     rowsq = None

@@ -320,6 +320,18 @@ def sum_slices(partials: torch.Tensor, out: torch.Tensor, accumulate: bool = Fal
     return out
 
 
+def sum_slices_act(partials: torch.Tensor, out: torch.Tensor, gelu: bool = False, qcols: int = 0, qscale: float = 1.0) -> torch.Tensor:
+    """out (16-bit [M, N], contiguous) = gelu(partials.sum(0)) or the sum with the first qcols columns scaled: finish of a split-K fc1 / in-proj."""
+    _chk(partials, torch.float32, "partials"); _chk(out, _lib.operand_dtype(), "out")
+    S, M, N = partials.shape
+    assert out.shape == (M, N)
+    with _timed("pv_sum_slices_f32", out.device, 0.0, (4.0 * S + 2.0) * out.numel()):
+        check(_lib.load().pv_sum_slices_act_bf16(_ptr(partials), _ptr(out), M, N, S, int(gelu), int(qcols), float(qscale), _flag(out.device), _stream(out)),
+              "pv_sum_slices_act_bf16")
+    _count()
+    return out
+
+
 def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1, colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 [R,C] (row-strided view allowed) -> bf16 [C, ceil(R / pad_to) * pad_to], zero-filled beyond column R."""
     if not (src.is_cuda and src.dtype == _lib.operand_dtype() and src.dim() == 2 and src.stride(1) == 1):
