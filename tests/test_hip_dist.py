@@ -57,3 +57,43 @@ def test_bench_refuses_a_rank_count_that_does_not_match():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["PV_REPO"])
+import torch, torch.distributed as td
+from peekvit_amd import dist as pvdist, synth
+from peekvit_amd.models.vit import VisionTransformer
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+td.init_process_group("nccl", device_id=dev)                  # RCCL: the backend the multi-GPU job uses
+cfg = synth.MODEL_CONFIGS["vit_tiny"]
+m = VisionTransformer(**cfg); synth.load_synth_weights(m, cfg); m = m.to(dev).train()
+x = torch.randn(4, 3, cfg["image_size"], cfg["image_size"], device=dev); y = torch.arange(4, device=dev)
+torch.nn.functional.cross_entropy(m(x), y).backward()
+ref = [p.grad.clone() for p in m.parameters()]
+for p in m.parameters(): p.grad = None
+red = pvdist.OverlappedGradReducer(m.parameters(), bucket_bytes=64 << 10)
+torch.nn.functional.cross_entropy(m(x), y).backward()
+n = red.finish()
+same = all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))     # one rank: sum / 1 = the local gradient, through RCCL and back
+t = torch.tensor([1.5, 2.5], device=dev, dtype=torch.float64)
+td.all_reduce(t, op=td.ReduceOp.MAX)                                     # bench.py's MAX-over-ranks timing reduction
+td.barrier(); torch.cuda.synchronize()
+print(json.dumps({"buckets": n, "during_backward": red.launched_before_finish, "same": same, "max": t.tolist(), "backend": td.get_backend()}))
+td.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_rccl_process_group_with_one_rank_runs_the_overlapped_reducer():
+    """The N > 1 code path over the REAL backend (torch.distributed "nccl" = RCCL), as far as one GPU allows: a 1-rank RCCL process group
+    (init with device_id, barrier, the MAX all-reduce of bench.py's timings) and the bucketed, backward-overlapped gradient all-reduce of
+    the HIP training path reducing in place on the device - gradients come back bit-identical."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PV_REPO=REPO)
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=500, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["same"] and out["buckets"] > 4 and out["during_backward"] >= out["buckets"] - 1 and out["max"] == [1.5, 2.5]
