@@ -452,11 +452,11 @@ def _splitk_slices(M: int, N: int, K: int, min_k: int = 2048) -> int:
     if not _SMALL_M_SPLITK or K < min_k:
         return 1
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 96:
+    if tiles >= 256:                             # one workgroup per CU or more: the one-pass kernel (measured: split-K gains up to 150 tiles, batch 16-24)
         return 1
     best = 1
     for s_ in (2, 3, 4, 6, 8, 12, 16):
-        if K % (s_ * 64) == 0 and K // s_ >= 256 and tiles * s_ <= 384:
+        if K % (s_ * 64) == 0 and K // s_ >= 256 and tiles * s_ <= 768:
             best = s_
     return best
 
