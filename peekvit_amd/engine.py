@@ -228,24 +228,38 @@ class _Workspace:
     (default) stream - their launches interleave on it - and a buffer is only ever touched by launches on the stream it was created for.  `use_workspace` swaps the arena the engine draws
     from, so a captured hipGraph owns the buffers its nodes point at (peekvit_amd.graph)."""
 
+    _ITEMSIZE = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.float64: 8}
+
     def __init__(self):
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._views: Dict[tuple, torch.Tensor] = {}      # (key, dtype, shape) -> the typed view: three tensor ops saved per request (eager small batches
+                                                         # are host-bound: ~100 requests per forward)
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        key = (name, device, ops.raw_stream(device.index if device.index is not None else torch.cuda.current_device()), threading.get_ident())
+        shape = tuple(int(s) for s in shape)
+        vkey = (key, dtype, shape)
+        v = self._views.get(vkey)
+        if v is not None:
+            return v
         n = 1
         for s in shape:
-            n *= int(s)
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
-        key = (name, device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+            n *= s
+        nbytes = n * self._ITEMSIZE[dtype]
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             with torch.inference_mode(False):    # scratch outlives the call: a first use under torch.inference_mode() must not make it an inference tensor
                 buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
-        return buf[:nbytes].view(dtype).view(*shape)
+            for k in [k for k in self._views if k[0] == key]:      # views of the buffer this one replaces
+                del self._views[k]
+        with torch.inference_mode(False):
+            v = self._views[vkey] = buf[:nbytes].view(dtype).view(*shape)
+        return v
 
     def clear(self):
         self._bufs.clear()
+        self._views.clear()
 
 
 workspace = _Workspace()

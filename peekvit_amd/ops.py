@@ -72,10 +72,17 @@ def _stream(t: torch.Tensor):
     """torch's current stream on the tensor's device.  The launch goes to the CURRENT device (kernel attributes such as the > 64 KiB
     LDS opt-in are per device), so a tensor on another device is refused loudly: the model-level entry points make the input's
     device current (`engine.on_device`)."""
-    if t.device.index != torch.cuda.current_device():
+    idx = t.device.index
+    if idx != torch.cuda.current_device():
         raise _lib.PeekvitHipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
                                    "`with torch.cuda.device(tensor.device):`")
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(raw_stream(idx))
+
+
+def raw_stream(device_index: int) -> int:
+    """hipStream_t of torch's current stream on that device, without building a torch.cuda.Stream object (~100 launches per forward: the eager
+    small-batch path is host-bound)."""
+    return torch._C._cuda_getCurrentRawStream(device_index)
 
 
 # Operand-range guard (fp16-operand library, include/peekvit_hip.h `range_flag`): while `range_flag` holds a 1-element int32 GPU
