@@ -4,6 +4,8 @@ plain bf16 operands cannot (4e-3):
   "bf16x3" split operands concatenated along K on the same MFMA GEMM + exact-fp32 attention: ~1e-5 at 3x the GEMM work."""
 import math
 
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -247,6 +249,28 @@ def test_auto_mode_falls_back_to_bf16_when_an_activation_overflows_fp16():
     assert engine.fallback_count == n0 + 1
     assert torch.isfinite(auto).all() and torch.equal(auto, ref)
     assert not torch.isfinite(raw).all()                                   # what the guard protects from
+
+
+def test_range_guard_covers_the_small_batch_split_k_finish():
+    """ViT-B/16 at batch 2: fc1 runs split-K and its GELU comes out of the finish pass (pv_sum_slices_act_bf16) - that pass carries the range
+    guard too: an overflowing activation there sends the forward to the bf16 library like the one-pass epilogue does."""
+    from peekvit_amd import engine, ops
+    cfg, m = _model("vit", "vit_b_16")
+    with torch.no_grad():
+        blk = m.encoder.layers[2]
+        blk.mlp.fc1.bias.add_(1.0e5)
+        blk.mlp.fc2.weight.mul_(1.0e-4)
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    n0 = engine.fallback_count
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with ops.KernelTimer() as kt:
+            auto = m(x)
+        with engine.precision("bf16"):
+            ref = m(x)
+    torch.cuda.synchronize()
+    assert engine._splitk_slices(2 * 197, cfg["mlp_dim"], cfg["hidden_dim"], 512) > 1              # the split form is what ran
+    assert engine.fallback_count == n0 + 1 and torch.isfinite(auto).all() and torch.equal(auto, ref)
 
 
 def test_auto_mode_checks_parameter_bounds_once():
