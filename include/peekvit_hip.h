@@ -137,6 +137,10 @@ typedef struct pv_gemm_args {
      * row's segment.  models/rankvit.py:63 `torch.norm(input, dim=-1)` of the NEXT block is then sqrt(sum over tiles)
      * (pv_rank_topk_partials) and the separate pass over the tokens (pv_token_norm) disappears. */
     float* rowsq_out;
+    /* ResidualViT (ABI v6, PV_EPI_BIAS_RES_F32 with row_scale, 256- / 128-row tile kernels): nonzero = the residual row is scaled too,
+     * out = row_scale[m] * (res + acc + bias) - models/residualvit.py:226,254 with res = the UNMASKED tokens, so the masked copy of the
+     * tokens (mask * img) never has to be written: masked + mask * branch = mask * (img + branch). */
+    int32_t res_scaled;
 } pv_gemm_args;
 
 /* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length. */
@@ -287,7 +291,8 @@ int pv_gather_tokens(const float* x, const int32_t* keep, float* out, int64_t B,
  *   thr[b]    = sigmoid(x[b,S-1] . wb + bb)                               (budget_token_gate, :212)
  *   mask[b,i] = relu(sigmoid((x[b,1+i] . wg + bg)/temp + sbias) - thr[b])   i < S-2            (:217)
  *   x_out[b]  = [x[b,0] | mask[b,i] * x[b,1+i] | x[b,S-1]]                  (:220-227, masked_input)
- * x_in: fp32 [B,S,D] (layout [cls | N | budget], one special token); x_out: same shape, may alias x_in;
+ * x_in: fp32 [B,S,D] (layout [cls | N | budget], one special token); x_out: same shape, may alias x_in, or NULL (the masked tokens are
+ * not written: the caller uses pv_gemm_args.res_scaled and ln_out instead);
  * mask_out: fp32 [B,S-2] (block.mask); row_scale: fp32 [B,S] = [1, mask, 1] (:230-235 fwd_mask) for the
  * LN / out-proj epilogues.
  * thr_out: fp32 [B] or NULL - the per-image threshold (what the reference leaves in residual_gate.threshold, :66).

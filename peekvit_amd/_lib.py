@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
                 ("qscale", _f32), ("epilogue", _i32),
                 ("ln_gamma", _p), ("ln_beta", _p), ("ln_row_scale", _p), ("ln_out", _p), ("ln_eps", _f32),
                 ("ksplit", _i32), ("colsum_partial", _p),
-                ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p), ("range_flag", _p), ("rowsq_out", _p)]
+                ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p), ("range_flag", _p), ("rowsq_out", _p),
+                ("res_scaled", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares

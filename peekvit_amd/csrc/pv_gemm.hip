@@ -58,6 +58,7 @@ struct GemmDev {
                                // same gc weight tiles while it streams the activation row panels of its share of the rows
     uint32_t* range_flag;      // operand-range guard of the fp16 build (pv_common.h), or null
     float* rowsq_out;          // PV_EPI_BIAS_RES_F32: [tiles_n][M] sum of squares of each output row's segment (RankViT norms), or null
+    int res_scaled;            // PV_EPI_BIAS_RES_F32 with row_scale: the residual row is scaled too (ResidualViT: res = the unmasked tokens)
     int k_last;                // TN kernel: K extent of the last split-K slice (the slices need not be equal)
     float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
     // LayerNorm folding (opt-in): the PRODUCER (PV_EPI_BIAS_RES_F32) also emits the 16-bit copy of its
@@ -152,8 +153,8 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         u32x2 o = {pv_pack_bf16x2_tracked(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab), vmax), pv_pack_bf16x2_tracked(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab), vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
-        const float s = row_scale;
-        float4 o = make_float4(fmaf(s, v0, r[0]), fmaf(s, v1, r[1]), fmaf(s, v2, r[2]), fmaf(s, v3, r[3]));
+        const float s = row_scale, t = p.res_scaled ? row_scale : 1.0f;
+        float4 o = make_float4(fmaf(s, v0, t * r[0]), fmaf(s, v1, t * r[1]), fmaf(s, v2, t * r[2]), fmaf(s, v3, t * r[3]));
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_F32) {
         const float s = n < p.qcols ? p.qscale : 1.0f;
@@ -687,7 +688,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
                     o = (f32x4){v[0] * pv_gelu_grad_lut(rr[j][0], tab), v[1] * pv_gelu_grad_lut(rr[j][1], tab),
                                 v[2] * pv_gelu_grad_lut(rr[j][2], tab), v[3] * pv_gelu_grad_lut(rr[j][3], tab)};
-                } else if (EPI == PV_EPI_BIAS_RES_F32) o = (f32x4){fmaf(sc, v[0], rr[j][0]), fmaf(sc, v[1], rr[j][1]), fmaf(sc, v[2], rr[j][2]), fmaf(sc, v[3], rr[j][3])};
+                } else if (EPI == PV_EPI_BIAS_RES_F32) {
+                    const float tr = p.res_scaled ? sc : 1.0f;
+                    o = (f32x4){fmaf(sc, v[0], tr * rr[j][0]), fmaf(sc, v[1], tr * rr[j][1]), fmaf(sc, v[2], tr * rr[j][2]), fmaf(sc, v[3], tr * rr[j][3])};
+                }
                 else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
                 if (m0 + ps * 128 + row < p.M && col_ok) {
                     if (EPI == PV_EPI_GELU_GRAD_BF16) {
@@ -1332,6 +1336,8 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     p.rowsq_out = a->rowsq_out;
     if (a->rowsq_out && (a->epilogue != PV_EPI_BIAS_RES_F32 || ((uintptr_t)a->rowsq_out & 3) || a->ln_out || a->x16_out)) return PV_ERR_INVALID_ARG;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.res = a->res; p.row_scale = a->row_scale; p.pos = a->pos;
+    p.res_scaled = a->res_scaled;
+    if (a->res_scaled && (a->epilogue != PV_EPI_BIAS_RES_F32 || !a->row_scale)) return PV_ERR_INVALID_ARG;
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
     p.rpi = (int)a->rows_per_img_in; p.rpo = (int)a->rows_per_img_out; p.row_off = (int)a->row_off;
@@ -1407,6 +1413,7 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
     static const int fullrow_env = [] { const char* e = getenv("PV_GEMM_FULLROW"); return e ? atoi(e) : 1; }();
     const bool fullrow_shape = a->epilogue == PV_EPI_BIAS_RES_F32 && (p.N == 256 || p.N == 384 || p.N == 512) && p.ksplit <= 1 && !feat &&
                                (g_pv_fullrow >= 0 ? g_pv_fullrow != 0 : fullrow_env != 0) && force == 0;
+    if (a->res_scaled && (fullrow_shape || a->ln_out)) return PV_ERR_UNSUPPORTED;      // 256- / 128-row tile kernels only
     if (fullrow_shape && (a->ln_out || (p.M + 127) / 128 >= 96)) {
         p.tiles_m = (p.M + 127) / 128; p.tiles_n = 1;
         return p.N == 256 ? pv_launch_gemm_fullrow<4>(p, s) : p.N == 384 ? pv_launch_gemm_fullrow<6>(p, s) : pv_launch_gemm_fullrow<8>(p, s);

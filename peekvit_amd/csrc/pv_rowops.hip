@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, f
 #pragma unroll
             for (int j = 0; j < NCH; ++j) { r.v[j].x *= m; r.v[j].y *= m; r.v[j].z *= m; r.v[j].w *= m; }
         }
-        if (!special || xo != x) {
+        if (xo != nullptr && (!special || xo != x)) {       // xo == nullptr: the caller never reads the masked tokens (res_scaled residual + ln_out)
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 int idx = lane + 64 * j;
@@ -1119,7 +1119,8 @@ __global__ __launch_bounds__(256) void pv_residual_gate_kernel(const float* x, f
 extern "C" int pv_residual_gate(const float* x, float* xo, const float* wg, const float* bg, const float* wb, const float* bb, float temp,
                                 float sigmoid_bias, float* mask_out, float* row_scale, float* thr_out, const float* ln_gamma, const float* ln_beta,
                                 float ln_eps, uint16_t* ln_out, int64_t B, int64_t S, int64_t D, void* stream) {
-    if (!x || !xo || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
+    if (!x || !wg || !bg || !wb || !bb || !mask_out || !row_scale || B <= 0 || S < 3 || D <= 0 || temp == 0.f) return PV_ERR_INVALID_ARG;
+    if (!xo && !ln_out) return PV_ERR_INVALID_ARG;          // without the masked tokens the block needs at least its first LayerNorm from here
     if (D % 4 || D > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)xo & 15) || ((uintptr_t)wg & 15) || ((uintptr_t)wb & 15)) return PV_ERR_UNSUPPORTED;
     if (ln_out && (!ln_gamma || !ln_beta || ((uintptr_t)ln_gamma & 15) || ((uintptr_t)ln_beta & 15) || ((uintptr_t)ln_out & 7))) return PV_ERR_INVALID_ARG;
     dim3 grid((unsigned)B);

@@ -501,7 +501,8 @@ def _act_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.T
 
 
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
-                  next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None,
+                  res_scaled: bool = False) -> torch.Tensor:
     """x: fp32 [B,S,D] contiguous on the GPU.  Returns a NEW fp32 [B,S,D] tensor.
 
     Launches: [LN1] -> QKV GEMM (+bias, q*dh^-0.5) -> attention -> out-proj GEMM (+bias, +residual, fused LN2)
@@ -513,6 +514,8 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     next_ranks: the consumer of the output is a RankViT block with an active budget (encoder hint): the fc2 epilogue then also leaves the
     per-column-tile sums of squares of every output row (`out._pv_rowsq`), from which sort_and_drop ranks without a pass over the tokens.
     h1: row_scale * LN1(x) as 16-bit [B*S, D], already computed by the caller (ResidualViT: the gate kernel has the rows in registers).
+    res_scaled (with row_scale and h1): `x` is the UNMASKED token tensor and the out-proj epilogue scales the residual row as well,
+    x1 = row_scale * (x + branch) = masked + row_scale * branch - the masked copy of the tokens is never materialised.
     """
     if _mode() == "bf16x3":
         return _block_forward_x3(blk, x, eps, row_scale)
@@ -583,9 +586,11 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
              qcols=D, qscale=float(dh) ** -0.5)
     ops.attention(qkv, att, B, S, H, dh)
     fuse2 = _ln_fusable(D, D)
+    if res_scaled and (h1 is None or row_scale is None or fuse2):
+        raise PeekvitHipError("block_forward(res_scaled=True) needs row_scale, the caller's h1 and the tile GEMM (no full-row LayerNorm fusion)")
     if fuse2 or row_scale is not None:
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R,
-                 res=x.view(R, D), row_scale=row_scale,
+                 res=x.view(R, D), row_scale=row_scale, res_scaled=res_scaled,
                  ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale) if fuse2 else None)
         ln2_done = fuse2
     else:
@@ -618,6 +623,9 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
 _LAST_BLOCK_ROWS = os.environ.get("PEEKVIT_AMD_LAST_BLOCK_ROWS", "1") != "0"
 # ResidualViT: the gate kernel also emits row_scale * LN1(masked row) (it holds the row in registers); PEEKVIT_AMD_GATE_LN1=0 leaves LN1 to its own launch
 _GATE_LN1 = os.environ.get("PEEKVIT_AMD_GATE_LN1", "1") != "0"
+# ... and then the masked copy of the tokens is not written at all: the out-proj epilogue scales its residual row (pv_gemm_args.res_scaled);
+# PEEKVIT_AMD_GATE_MASKED=1 restores the copy
+_GATE_NO_MASKED = os.environ.get("PEEKVIT_AMD_GATE_MASKED", "0") != "1"
 
 
 def rows_only_ok(blk: nn.Module) -> bool:

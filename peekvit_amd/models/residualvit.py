@@ -155,21 +155,28 @@ class ResidualViTBlock(ResidualModule):
 
     def _hip_gated_block(self, input: torch.Tensor, rows: int = 0):
         x = input if input.is_contiguous() else input.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
         gate, bgate = self.residual_gate.projection, self.budget_token_gate
-        masked = torch.empty_like(x)
         thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
         # the gate kernel holds every row in registers: it also emits row_scale * LN1(masked row), the block's first step (residualvit.py:251)
         h1 = None
         if engine._PRECISION != "bf16x3" and engine._GATE_LN1:
             engine._check_ln_range(self.ln_1)
             h1 = engine.workspace.get("h", (x.shape[0] * x.shape[1], x.shape[2]), engine._lib.operand_dtype(), x.device)
+        # with h1 from the gate and a tile GEMM for out-proj the masked tokens themselves are never needed: the out-proj epilogue computes
+        # row_scale * (x + branch) from the unmasked rows (pv_gemm_args.res_scaled)
+        no_masked = h1 is not None and engine._GATE_NO_MASKED and not engine._ln_fusable(x.shape[2], x.shape[2])
+        masked = None if no_masked else torch.empty_like(x)
         f32 = engine._f32
         self.mask, row_scale = ops.residual_gate(x, masked, f32(gate.weight), f32(gate.bias), f32(bgate.weight), f32(bgate.bias),
                                                  self.residual_gate.temp, self.residual_gate.sigmoid_bias, thr_out=thr,
                                                  ln=None if h1 is None else (f32(self.ln_1.weight), f32(self.ln_1.bias), self.ln_1.eps, h1))
         self.residual_gate.threshold = thr.view(-1, 1, 1)           # what ResidualGate.forward leaves behind (residualvit.py:66; utils.py:131)
-        if rows:
-            return engine.block_forward_rows(self, masked, self.ln_1.eps, rows, row_scale=row_scale, h1=h1)
+        if rows:          # the rows read there (class tokens) carry scale 1: masked == unmasked
+            return engine.block_forward_rows(self, x if no_masked else masked, self.ln_1.eps, rows, row_scale=row_scale, h1=h1)
+        if no_masked:
+            return engine.block_forward(self, x, self.ln_1.eps, row_scale=row_scale, h1=h1, res_scaled=True)
         return engine.block_forward(self, masked, self.ln_1.eps, row_scale=row_scale, h1=h1)
 
     def _pv_forward_rows(self, input: torch.Tensor, nq: int):

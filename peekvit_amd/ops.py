@@ -177,14 +177,15 @@ def layernorm_bf16(x: torch.Tensor, gamma, beta, eps: float, out: torch.Tensor, 
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: int, *, M=None, res=None,
-         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None, x16_out=None, rowstat_out=None, fold=None, rowsq_out=None):
+         row_scale=None, pos=None, rows_per_img_in=0, rows_per_img_out=0, row_off=0, qcols=0, qscale=1.0, ln=None, ksplit=0, tag="", colsum_out=None, x16_out=None, rowstat_out=None, fold=None, rowsq_out=None, res_scaled=False):
     """out = epilogue(a[M,K] . w[N,K]^T).  a, w: bf16 2-D (row stride = shape[-1]).
     ksplit > 1: out is fp32 [ksplit, M, N] partial slices (PV_EPI_BIAS_F32), reduce with sum_slices().
     x16_out / rowstat_out (PV_EPI_BIAS_RES_F32) and fold = (stat [M,2], c1 [N], c2 [N]) (PV_EPI_BIAS_BF16 / _GELU_BF16, bias None): the
     producer / consumer halves of the folded LayerNorm (include/peekvit_hip.h).
     colsum_out (PV_EPI_GELU_GRAD_BF16): fp32 [N] tensor that receives the column sums of the output (bias gradient) - fused into the
     epilogue when the 256-row tile kernel serves the shape, a separate pv_colsum_f32 pass otherwise.
-    ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32)."""
+    ln = (gamma, beta, eps, ln_out_bf16, ln_row_scale | None): also emit bf16(LayerNorm(out)) (fused, PV_EPI_BIAS_RES_F32).
+    res_scaled (with row_scale, PV_EPI_BIAS_RES_F32): out = row_scale * (res + a.w^T + bias) - ResidualViT with res = the unmasked tokens."""
     K = a.shape[-1]
     if M is None:
         M = a.numel() // K
@@ -205,7 +206,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     x16_out=x16_out.data_ptr() if x16_out is not None else 0, rowstat_out=rowstat_out.data_ptr() if rowstat_out is not None else 0,
                     fold_stat=fold[0].data_ptr() if fold else 0, fold_c1=fold[1].data_ptr() if fold else 0, fold_c2=fold[2].data_ptr() if fold else 0,
                     range_flag=range_flag.data_ptr() if range_flag is not None and range_flag.device == a.device else 0,
-                    rowsq_out=rowsq_out.data_ptr() if rowsq_out is not None else 0)
+                    rowsq_out=rowsq_out.data_ptr() if rowsq_out is not None else 0, res_scaled=int(res_scaled))
     part = None
     if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
         part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)

@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_gemm_args_struct_matches_header_layout():
     import ctypes as C
     from peekvit_amd._lib import GemmArgs
-    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8 + 2 * 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers, range_flag, rowsq_out
-    assert GemmArgs.range_flag.offset == C.sizeof(GemmArgs) - 16 and GemmArgs.rowsq_out.offset == C.sizeof(GemmArgs) - 8
+    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8 + 2 * 8 + 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers, range_flag, rowsq_out, res_scaled (+ padding)
+    assert GemmArgs.range_flag.offset == C.sizeof(GemmArgs) - 24 and GemmArgs.rowsq_out.offset == C.sizeof(GemmArgs) - 16 and GemmArgs.res_scaled.offset == C.sizeof(GemmArgs) - 8
     assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
     assert GemmArgs.ln_gamma.offset == 19 * 8 and GemmArgs.ln_eps.offset == 23 * 8
 
