@@ -804,13 +804,38 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
         ops.im2col(img, P, cols)
     tokens = torch.empty((B, S, D), dtype=torch.float32, device=dev)
     pos = _f32(model.encoder.pos_embedding).view(-1, D)
-    ops.gemm(cols, (bf16x3_weight if x3 else bf16_weight)(model.conv_proj.weight), _f32(model.conv_proj.bias), tokens.view(B * S, D),
+    wconv = (bf16x3_weight if x3 else bf16_weight)(model.conv_proj.weight)
+    if K % 64 and not x3:
+        # patch sizes whose 3*P*P is not a multiple of the GEMM's K step (P = 14: 588): zero-padded columns on both operands
+        Kp = (K + 63) // 64 * 64
+        colsp = workspace.get("cols_pad", (B * Np, Kp), _lib.operand_dtype(), dev)
+        colsp[:, K:].zero_()
+        colsp[:, :K].copy_(cols)
+        cols, wconv = colsp, _padded_k(model.conv_proj.weight, wconv, Kp)
+    ops.gemm(cols, wconv, _f32(model.conv_proj.bias), tokens.view(B * S, D),
              PV_EPI_BIAS_POS_F32, M=B * Np, pos=pos, rows_per_img_in=Np, rows_per_img_out=S, row_off=n_special)
     special = _f32(model.class_tokens).view(-1, D)
     if model.num_registers > 0:
         special = torch.cat([special, _f32(model.register_tokens).view(-1, D)], dim=0)
     ops.token_prologue(tokens, special, pos, _f32(budget_token), budget, n_special)
     return tokens
+
+
+_wpadcache: Dict[tuple, tuple] = {}
+
+
+def _padded_k(p: torch.Tensor, w16: torch.Tensor, Kp: int) -> torch.Tensor:
+    """The 16-bit weight [N, K] with zero columns up to Kp, cached per parameter version."""
+    key = (id(p), _lib.OPERAND, Kp)
+    ver = (pver(p), p.data_ptr())
+    ent = _wpadcache.get(key)
+    if ent is not None and ent[0] == ver:
+        return ent[1]
+    with torch.inference_mode(False), torch.no_grad():
+        wp = torch.zeros((w16.shape[0], Kp), dtype=w16.dtype, device=w16.device)
+        wp[:, :w16.shape[1]] = w16
+    _wpadcache[key] = (ver, wp)
+    return wp
 
 
 def pool_and_head(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:

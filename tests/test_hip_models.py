@@ -640,3 +640,24 @@ def test_hip_graph_replay_of_the_pruning_models(kind, extra, budget):
         g = GraphedForward(m, x0)
         for x in (x0, x1, x0):
             assert torch.equal(g(x).clone(), m(x))
+
+
+def test_patch_size_whose_columns_are_not_a_multiple_of_64():
+    """P = 14 (ViT-H/14-style stems: 3 * 14 * 14 = 588 columns per patch, 257 tokens at 224 x 224): the patch-embedding GEMM runs on zero-padded
+    columns; logits against the stock-op composite of the same module."""
+    import os
+    from peekvit_amd.models.vit import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(image_size=224, patch_size=14, num_layers=2, num_heads=4, hidden_dim=256, mlp_dim=1024, num_classes=50).to(DEV).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.normal_(std=0.02)
+        x = torch.randn(5, 3, 224, 224, device=DEV)
+        y = m(x)
+        os.environ["PEEKVIT_AMD_BACKEND"] = "torch"
+        try:
+            ref = m(x)
+        finally:
+            del os.environ["PEEKVIT_AMD_BACKEND"]
+    assert rel_l2(y.cpu(), ref.cpu()) < 2e-3
