@@ -85,6 +85,11 @@ int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const flo
 #define PV_EPI_GELU_GRAD_BF16       7   /* out bf16 = (acc+bias) * gelu'(pre[m][n]), pre = bf16 matrix passed in `res` (row stride ldr elements) */
 
 typedef struct pv_gemm_args {
+    /* ABI v7: sizeof(pv_gemm_args) as the CALLER's binding knows it - the first field, so that it can be read whatever the caller's
+     * struct length is.  pv_gemm_bf16 / pv_gemm_tn_bf16 / pv_gemm_tile_rows return PV_ERR_INVALID_ARG when it differs from the
+     * library's own size (pv_gemm_args_size()): a binding made from an older header hands over a shorter struct, and the library must
+     * not read the fields it lacks (round 2 appended res_scaled without this check). */
+    uint64_t struct_size;
     const uint16_t* A;       /* bf16 [M,K], row stride lda            (activations)                    */
     const uint16_t* W;       /* bf16 [N,K], row stride ldw            (nn.Linear weight layout (out,in)) */
     const float* bias;       /* fp32 [N] or NULL                                                        */
@@ -142,6 +147,9 @@ typedef struct pv_gemm_args {
      * tokens (mask * img) never has to be written: masked + mask * branch = mask * (img + branch). */
     int32_t res_scaled;
 } pv_gemm_args;
+
+/* sizeof(pv_gemm_args) of THIS library build (ABI v7): a binding asserts it equals its own struct's size when it loads the library. */
+uint64_t pv_gemm_args_size(void);
 
 /* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length. */
 int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, void* stream);

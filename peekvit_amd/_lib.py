@@ -26,7 +26,7 @@ PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_GELU_GRAD_BF16 = 6, 7
 
 class GemmArgs(C.Structure):
     """Mirror of `pv_gemm_args` (include/peekvit_hip.h)."""
-    _fields_ = [("A", _p), ("W", _p), ("bias", _p), ("out", _p), ("res", _p), ("row_scale", _p), ("pos", _p),
+    _fields_ = [("struct_size", C.c_uint64), ("A", _p), ("W", _p), ("bias", _p), ("out", _p), ("res", _p), ("row_scale", _p), ("pos", _p),
                 ("M", _i64), ("N", _i64), ("K", _i64), ("lda", _i64), ("ldw", _i64), ("ldo", _i64), ("ldr", _i64),
                 ("rows_per_img_in", _i64), ("rows_per_img_out", _i64), ("row_off", _i64), ("qcols", _i64),
                 ("qscale", _f32), ("epilogue", _i32),
@@ -35,10 +35,15 @@ class GemmArgs(C.Structure):
                 ("x16_out", _p), ("rowstat_out", _p), ("fold_stat", _p), ("fold_c1", _p), ("fold_c2", _p), ("range_flag", _p), ("rowsq_out", _p),
                 ("res_scaled", _i32)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(GemmArgs)      # ABI v7: the library refuses a struct of another length
+
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
 SIGNATURES = {
     "pv_version": (C.c_int, []),
+    "pv_gemm_args_size": (C.c_uint64, []),
     "pv_arch": (C.c_char_p, []),
     "pv_error_string": (C.c_char_p, [C.c_int]),
     "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
@@ -81,7 +86,7 @@ SIGNATURES = {
     "pv_residual_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lock = threading.Lock()
 _libs: dict = {}
 
@@ -145,6 +150,8 @@ def load(operand=None):
             fn.restype, fn.argtypes = res, args
         if lib.pv_version() != ABI_VERSION:
             raise PeekvitHipError(f"{path} has ABI v{lib.pv_version()}, this package binds v{ABI_VERSION}: rebuild (python -m peekvit_amd._build)")
+        if lib.pv_gemm_args_size() != C.sizeof(GemmArgs):
+            raise PeekvitHipError(f"{path}: pv_gemm_args is {lib.pv_gemm_args_size()} bytes in the library, {C.sizeof(GemmArgs)} in this binding")
         if lib.pv_operand_type() != (1 if op == "f16" else 0):
             raise PeekvitHipError(f"{path} was built for a different operand type")
         _libs[op] = lib

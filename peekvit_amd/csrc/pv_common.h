@@ -60,7 +60,9 @@ __device__ __forceinline__ float pv_unpack_hi(uint32_t w) { return __builtin_bit
 // (|y| <= max|gamma| * sqrt(D) + max|beta|), attention outputs (convex combinations of v rows), weights.  The bf16 build compiles
 // the tracking away and never writes the flag.
 #ifdef PV_OPERAND_F16
-__device__ __forceinline__ void pv_range_track(float& m, float a, float b) { m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+// v_maximum3_f32 (gfx950): IEEE-754-2019 maximum, a NaN operand gives NaN - v_max3_f32 / fmaxf drop it, and pv_range_commit's
+// !(m <= 65504) then never saw a NaN the epilogue packed (round 2 ADVICE).  |a|, |b| are source modifiers: still ONE instruction per pair.
+__device__ __forceinline__ void pv_range_track(float& m, float a, float b) { asm("v_maximum3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(a), "v"(b)); }
 __device__ __forceinline__ void pv_range_commit(float m, uint32_t* flag) {
     if (flag != nullptr && !(m <= 65504.0f)) atomicOr(flag, 1u);
 }

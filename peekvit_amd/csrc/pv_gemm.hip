@@ -13,20 +13,82 @@
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-// exact-erf GELU by table: Phi(x) as a piecewise cubic on 64 intervals of [-8, 8) (pv_gelu_table.h pv_gelu_cub; |error| <= 8.7e-7,
-// relative L2 1.4e-7 vs fp64 - the class of torch's fp32 F.gelu).  9 VALU + ONE 16-byte gather per value; every 16-byte entry is
-// stored 16 times and a lane reads replica (lane & 15), so the ds_read_b128 lane groups (16 lanes each) are bank-conflict free
-// whatever intervals the lanes need (the previous 4096-entry linear table's 8-byte gathers conflicted ~4-way and the LDS, not
-// the VALU, set the epilogue's pace).  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2 kernel),
-// so both kernels round an element identically.  `tab` = table base + this lane's replica (f32x4 elements).
-template <typename TabPtr>
-__device__ __forceinline__ float pv_gelu_lut(float x, TabPtr tab) {
-    float t = fmaf(x, (float)PV_GELU_CUB_N / 16.0f, (float)PV_GELU_CUB_N / 2.0f);
-    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PV_GELU_CUB_N - 0.001f);
-    const int i = (int)t;
-    const float fr = __builtin_amdgcn_fractf(t);
-    const f32x4 c = tab[i * PV_GELU_CUB_REP];
-    return x * fmaf(fmaf(fmaf(c[3], fr, c[2]), fr, c[1]), fr, c[0]);
+// 1: the software-pipelined 16-bit epilogue of the 256^2 kernel (round 3); 0: round 2's one-pass form, kept for A/B builds (scripts/gemm_epi_ab.py)
+#ifndef PV_EPI_PIPE
+#define PV_EPI_PIPE 1
+#endif
+
+// exact-erf GELU by table: gelu(x) itself as a piecewise cubic in x on 64 entries of width 11/64 over [-5.5, 5.5) (zero below,
+// identity above; pv_gelu_table.h pv_gelu_cub, scripts/gen_gelu_table.py; |error| <= 7.3e-7, relative L2 5e-8 vs fp64 - the class of
+// torch's fp32 F.gelu).  The fc1 epilogue is VALU-issue bound (4 cycles per instruction per SIMD, packed fp32 included), so the form is
+// chosen for instruction count - 5.5 VALU + ONE 16-byte gather per value (round 2's Phi(x)-in-interval-coordinates form took 10):
+//   bits  = x * S + MAGIC        (v_pk_fma_f32 for two values; the magic addend leaves the entry index in the low mantissa bits)
+//   bits  = clamp(bits) as int   (v_med3_i32: huge / negative / NaN inputs land on the identity or the zero entry)
+//   addr  = (bits << 8) + base   (v_lshl_add_u32; entry i is 256 bytes = 16 replicas above entry i-1)
+//   (r0, r1) = (c1, c3) * x + (c0, c2)   (one v_pk_fma_f32 on the entry's register pairs: storage order {c0, c2, c1, c3})
+//   y = x * (x * r1) + r0        (not x^2 * r1: x^2 overflows where the identity entry must still return x)
+// Every 16-byte entry is stored 16 times and a lane reads replica (lane & 15), so the ds_read_b128 lane groups (16 lanes each) are
+// bank-conflict free whatever entries the lanes need.  The SAME arithmetic runs from LDS (256^2 kernel) or from global memory (128^2
+// kernel), so both kernels round an element identically.  `tab` = table base + this lane's replica (f32x4 elements).
+// The scalar steps are inline asm, not C operators: hipcc's SLP pass otherwise pairs the steps of two values into packed instructions
+// behind nine v_mov shuffles per four values.  The operations and their roundings are fmaf's / the product's.
+__device__ __forceinline__ float pv_fma_s(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float pv_mul_s(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float pv_gelu_poly(float x, const f32x4 c) {
+    const pv_f32x2_t c02 = {c[0], c[1]}, c13 = {c[2], c[3]}, xx = {x, x};
+    const pv_f32x2_t r = __builtin_elementwise_fma(c13, xx, c02);
+    return pv_fma_s(x, pv_mul_s(x, r[1]), r[0]);
+}
+// 0x4B400000 + entry index of two values (adjacent accumulator registers)
+__device__ __forceinline__ void pv_gelu_bits2(float x0, float x1, uint32_t& b0, uint32_t& b1) {
+    const pv_f32x2_t xs = {x0, x1}, sc = {PV_GELU_CUB_SCALE, PV_GELU_CUB_SCALE}, mg = {PV_GELU_CUB_MAGIC, PV_GELU_CUB_MAGIC};
+    const pv_f32x2_t t = __builtin_elementwise_fma(xs, sc, mg);
+    // (the WHOLE vector is bit-cast, then indexed: hipcc 7.2 compiles __builtin_bit_cast(int, t[1]) - a bit-cast of a vector ELEMENT - as a
+    // read of element 0, and both values took the first one's table entry; found in the ISA, reproduced in a ten-line kernel)
+    typedef __attribute__((ext_vector_type(2))) int pv_i32x2_t;
+    const pv_i32x2_t ti = __builtin_bit_cast(pv_i32x2_t, t);
+    const int lo = 0x4B400000, hi = 0x4B400000 + PV_GELU_CUB_N - 1;
+    b0 = (uint32_t)min(max(ti[0], lo), hi);
+    b1 = (uint32_t)min(max(ti[1], lo), hi);
+}
+// The polynomial for an entry that has just arrived from GLOBAL memory (128^2 kernel): scalar FMAs for (r0, r1).  The packed form
+// (pv_gelu_poly's v_pk_fma_f32 on the freshly loaded register pairs, directly behind the s_waitcnt vmcnt that covers the
+// global_load_dwordx4) returned a stale dword 2 (c1 = 0) in lanes 48-63 of a wave about 3e-6 of the time on MI355X / ROCm 7.2 -
+// scripts/dbg/gelu_glitch.py: 28 of 40 launches of a 2560 x 3072 x 768 GEMM had wrong elements with -DPV_GELU_GLOBAL_MODE=0, 0 of 40
+// with the scalar form.  Same operations, same roundings as pv_gelu_poly: both kernels still round an element identically.
+#ifndef PV_GELU_GLOBAL_MODE
+#define PV_GELU_GLOBAL_MODE 1
+#endif
+__device__ __forceinline__ float pv_gelu_poly_g(float x, const f32x4 c) {
+#if PV_GELU_GLOBAL_MODE == 0
+    return pv_gelu_poly(x, c);
+#else
+    const float r0 = fmaf(c[2], x, c[0]), r1 = fmaf(c[3], x, c[1]);
+    return pv_fma_s(x, pv_mul_s(x, r1), r0);
+#endif
+}
+__device__ __forceinline__ void pv_gelu_lut2(float& x0, float& x1, const f32x4* tab) {          // table in global memory, two values in place
+    uint32_t b0, b1;
+    pv_gelu_bits2(x0, x1, b0, b1);
+    const f32x4 c0 = tab[(b0 - 0x4B400000u) * PV_GELU_CUB_REP], c1 = tab[(b1 - 0x4B400000u) * PV_GELU_CUB_REP];
+    x0 = pv_gelu_poly_g(x0, c0); x1 = pv_gelu_poly_g(x1, c1);
+}
+__device__ __forceinline__ void pv_gelu_lut2(float& x0, float& x1, const __attribute__((address_space(3))) f32x4* tab) {   // table in LDS
+    uint32_t b0, b1;
+    pv_gelu_bits2(x0, x1, b0, b1);
+    // entry i lives i * 256 bytes above `tab`: (bits << 8) = 0x40000000 + i * 256 (mod 2^32) -> ONE v_lshl_add_u32 with a per-lane constant
+    const uint32_t base = (uint32_t)(uintptr_t)tab - 0x40000000u;
+    const f32x4 c0 = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)((b0 << 8) + base);
+    const f32x4 c1 = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)((b1 << 8) + base);
+    x0 = pv_gelu_poly(x0, c0); x1 = pv_gelu_poly(x1, c1);
 }
 
 // gelu'(x) = Phi(x) + x * phi(x) from its own table on the same grid (pv_gelu_grad_tab): the same 7 VALU + one gather
@@ -91,7 +153,7 @@ extern "C" void pv_debug_set_stamp_buffer(void* p) { g_pv_dbg = (unsigned long l
         unsigned long long t_;                                                                       \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                                           \
-        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 8 + (i)] = t_;                    \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 16 + (i)] = t_;                    \
     } while (0)
 #else
 #define PV_STAMP(i)
@@ -150,7 +212,9 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_GELU_BF16) {
         const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
-        u32x2 o = {pv_pack_bf16x2_tracked(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab), vmax), pv_pack_bf16x2_tracked(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab), vmax)};
+        float y0 = v0, y1 = v1, y2 = v2, y3 = v3;
+        pv_gelu_lut2(y0, y1, tab); pv_gelu_lut2(y2, y3, tab);
+        u32x2 o = {pv_pack_bf16x2_tracked(y0, y1, vmax), pv_pack_bf16x2_tracked(y2, y3, vmax)};
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else if (EPI == PV_EPI_BIAS_RES_F32) {
         const float s = row_scale, t = p.res_scaled ? row_scale : 1.0f;
@@ -161,7 +225,9 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0 * s, v1 * s, v2 * s, v3 * s);
     } else if (EPI == PV_EPI_BIAS_GELU_SPLIT_BF16) {
         const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
-        const PvHiLo a = pv_split2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), b = pv_split2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab));
+        float y0 = v0, y1 = v1, y2 = v2, y3 = v3;
+        pv_gelu_lut2(y0, y1, tab); pv_gelu_lut2(y2, y3, tab);
+        const PvHiLo a = pv_split2(y0, y1), b = pv_split2(y2, y3);
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
         *reinterpret_cast<u32x2*>(o) = (u32x2){a.hi, b.hi};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){a.lo, b.lo};
@@ -169,7 +235,9 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
     } else if (EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
         const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
-        *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(pv_gelu_lut(v0, tab), pv_gelu_lut(v1, tab)), pv_pack_bf16x2(pv_gelu_lut(v2, tab), pv_gelu_lut(v3, tab))};
+        float y0 = v0, y1 = v1, y2 = v2, y3 = v3;
+        pv_gelu_lut2(y0, y1, tab); pv_gelu_lut2(y2, y3, tab);
+        *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(y0, y1), pv_pack_bf16x2(y2, y3)};
         *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
     } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
         const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_grad_tab);
@@ -355,6 +423,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    PV_STAMP(14);
+#ifdef PV_STAMPS
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 13] = rt_; }
+#endif
 
     // ---- LDS-DMA sources: per half-tile two 1-KiB pieces per wave (rows j*64 + wid*8 + lane/8), swizzled chunk ----
     const int srow = wid * 8 + (lane >> 3);
@@ -480,19 +552,44 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
     PV_STAMP(0);
 #ifdef PV_STAMPS
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 8 + 6] = rt_; }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 6] = rt_; }
 #endif
-    if (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16) {
-        // GELU table (16 KiB replicated cubic; 32 KiB linear table for gelu') into the LDS above the staging buffers: the OLDEST
-        // operations of the kernel, so every later counted wait covers them and nothing else changes
+    stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
+    stage_a(1, 0, 1); stage_a(1, 1, 1);
+    constexpr bool HAS_TAB = EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16;
+    constexpr int NTAB = HAS_TAB ? (EPI == PV_EPI_GELU_GRAD_BF16 ? 4 : 2) : 0;
+    if (HAS_TAB) {
+        // GELU table (16 KiB replicated cubic; 32 KiB linear table for gelu') into the LDS above the staging buffers.  Issued AFTER the
+        // first K tiles (round 3; round 2 issued it first, so the K loop could not start before the table had landed: fc1's prologue took
+        // 4.0 k cycles against QKV's 2.4 k): the wait below leaves it in flight, and the first counted wait of the K loop - which leaves
+        // only the 4 youngest operations, all issued later - covers it long before the epilogue reads it.
 #pragma unroll
-        for (int i = 0; i < (EPI == PV_EPI_GELU_GRAD_BF16 ? 4 : 2); ++i)
+        for (int i = 0; i < NTAB; ++i)
             pv_glds16(reinterpret_cast<const char*>(EPI == PV_EPI_GELU_GRAD_BF16 ? pv_gelu_grad_tab : pv_gelu_cub) + (i * 512 + tid) * 16,
                       smem + G2_LDS + (i * 512 + wid * 64) * 16);
     }
-    stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
-    stage_a(1, 0, 1); stage_a(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // LayerNorm folding (consumer): the tile's row statistics [256][2] and column constants c1[256], c2[256] (4 KiB) behind the table,
+    // one 4-byte LDS-DMA each per thread (clamped at the ragged edges: those rows / columns are never stored) - two more operations
+    // that the counted waits of the K loop cover; the epilogue reads them from LDS instead of waiting for L2
+    const bool fold_dma = PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) && p.fold_stat != nullptr;
+    if (fold_dma) {
+        constexpr int FOLD_BASE = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);
+        const int r_ = m0 + (tid >> 1) < p.M ? m0 + (tid >> 1) : p.M - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.fold_stat + 2 * (int64_t)r_ + (tid & 1)),
+                                         (__attribute__((address_space(3))) void*)(smem + FOLD_BASE + wid * 256), 4, 0, 0);
+        const int c_ = n0 + (tid & 255) < p.N ? n0 + (tid & 255) : p.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((tid < 256 ? p.fold_c1 : p.fold_c2) + c_),
+                                         (__attribute__((address_space(3))) void*)(smem + FOLD_BASE + 2048 + wid * 256), 4, 0, 0);
+    }
+    // tile 0 has landed for this thread; the A halves of tile 1 (4 operations), the table and the fold constants stay in flight
+    if (fold_dma) {
+        if (NTAB == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        if (NTAB == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (NTAB == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PV_STAMP(1);
@@ -517,6 +614,151 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
     const int g = lane >> 4, i16 = lane & 15;
+    if (PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16)) {
+        // Round 3: the 16-bit epilogue as a software pipeline (in-kernel stamps of round 2's form, scripts/stamp_gemm.py: fc1 + folded
+        // LayerNorm spent 18.9 k ticks here against 27.7 k in its K loop).  What was wrong, from the stamps and the ISA:
+        //   - GELU ran latency-bound: hipcc kept 2 table gathers in flight per wave (256 VGPRs, all accumulators + 48 fold constants
+        //     live) and SLP-packed the polynomial into v_pk_fma_f32 behind v_mov shuffles: 3.6 k ticks per 32 values per lane;
+        //   - the 128 KiB of stores followed all the arithmetic, and a wave blocks at a store's ISSUE once the CU's memory path
+        //     (~28 B/clk) has its queue full: the path and the VALU were never busy together;
+        //   - the fold statistics were fetched from L2 at the start of the epilogue: 1.6 - 1.8 k ticks of exposed latency.
+        // Now: (1) the fold constants (row statistics, c1, c2: 4 KiB) are staged into LDS by the PROLOGUE's LDS-DMA and applied to all
+        // accumulators first (pure VALU), after which their registers are dead; (2) the lane's 16 units of 8 values (one 16-byte
+        // chunk of one image row each) run through [8 gathers issued | previous unit: polynomial, pack, LDS image write], the
+        // gathers of unit n+1 in flight under the arithmetic of unit n (inline-asm ds_read_b128 + counted lgkmcnt, results threaded
+        // through the wait so nothing is consumed early); (3) four units = one pass of 64 image rows: after its barrier every wave
+        // reads 8 whole rows back and issues their four 1-KiB stores ONE PER UNIT of the next pass, i.e. at the rate the memory path
+        // drains them.  Arithmetic per element is unchanged (bit-identical to the one-pass form, scripts/gemm_epi_ab.py).
+        float vmax = 0.f;          // operand-range guard (fp16 build): largest magnitude this lane packs
+        const bool fold = p.fold_stat != nullptr;
+        constexpr int FOLD_BASE = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);
+        if (fold) {
+            // x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]: the accumulators hold x16 . (gamma (.) W)^T
+            f32x4 k1[2][2], k2[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int col = wc * 64 + u * 32 + g * 8 + hh * 4;
+                    k1[u][hh] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + FOLD_BASE + 2048 + col * 4);
+                    k2[u][hh] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + FOLD_BASE + 3072 + col * 4);
+                }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const pv_f32x2_t st = *reinterpret_cast<const __attribute__((address_space(3))) pv_f32x2_t*>(cimg + FOLD_BASE + (wr * 128 + mt * 16 + i16) * 8);
+                const float f_mean = st[0], f_rstd = st[1];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * u][mt][e] = fmaf(f_rstd, fmaf(-f_mean, k1[u][0][e], acc[2 * u][mt][e]), k2[u][0][e]);
+                        acc[2 * u + 1][mt][e] = fmaf(f_rstd, fmaf(-f_mean, k1[u][1][e], acc[2 * u + 1][mt][e]), k2[u][1][e]);
+                    }
+            }
+        }
+        PV_STAMP(8);
+        const uint32_t tabc = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16) - 0x40000000u;
+        uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
+        const bool ocol_ok = n0 + (lane & 31) * 8 < p.N;
+        const int rb_row0 = (wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5);      // + 32 q + 2 j: the rows this wave stores in pass q
+        uint32_t rb_addr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = rb_row0 + 2 * j;
+            rb_addr[j] = (uint32_t)(uintptr_t)cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4);
+        }
+        f32x4 cf[2][8];            // gathered table entries of two units in flight (GELU only)
+        u32x4 rb[4];               // rows read back from the image, waiting for their store slot
+        auto unit_x = [&](int n, int e) -> float { return acc[2 * (n & 1) + (e >> 2)][n >> 1][e & 3]; };
+        auto issue = [&](int n) __attribute__((always_inline)) {
+            if (EPI == PV_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    uint32_t b0, b1;
+                    pv_gelu_bits2(unit_x(n, e), unit_x(n, e + 1), b0, b1);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[n & 1][e]) : "v"((b0 << 8) + tabc));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[n & 1][e + 1]) : "v"((b1 << 8) + tabc));
+                }
+            }
+        };
+        // the lgkmcnt wait that makes unit n's gathers (and everything older: the read-back rows of the previous pass) valid.  LDS
+        // operations return in order, so "at most N outstanding" = all but the N youngest have completed; the values pass through the
+        // statement, so no consumer can be scheduled above it.  with_rb: the read-back registers are threaded through as well (first
+        // unit after a read-back).
+        auto wait_unit = [&](int n, bool next_in_flight, bool with_rb) __attribute__((always_inline)) {
+            if (EPI == PV_EPI_BIAS_GELU_BF16) {
+                f32x4(&c)[8] = cf[n & 1];
+                if (next_in_flight && with_rb)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
+                                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
+                else if (next_in_flight)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+            } else if (with_rb) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
+            }
+        };
+        auto finish = [&](int n) __attribute__((always_inline)) {
+            const int mt = n >> 1, u = n & 1;
+            float y[8];
+            if (EPI == PV_EPI_BIAS_GELU_BF16) {
+                // pv_gelu_poly for the 8 values in lock step (step by step ACROSS the values): no instruction depends on its predecessor,
+                // so the wave issues back to back (value by value, hipcc padded every dependent pair of asm steps with an s_nop)
+                float x[8];
+                pv_f32x2_t r[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = unit_x(n, e);
+                    const f32x4 c = cf[n & 1][e];
+                    r[e] = __builtin_elementwise_fma((pv_f32x2_t){c[2], c[3]}, (pv_f32x2_t){x[e], x[e]}, (pv_f32x2_t){c[0], c[1]});
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = pv_mul_s(x[e], r[e][1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = pv_fma_s(x[e], y[e], r[e][0]);
+            } else {
+                // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
+                const float qs = en0 + u * 32 < p.qcols ? p.qscale : 1.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = unit_x(n, e) * qs;
+            }
+            const u32x4 pk = {pv_pack_bf16x2_tracked(y[0], y[1], vmax), pv_pack_bf16x2_tracked(y[2], y[3], vmax),
+                              pv_pack_bf16x2_tracked(y[4], y[5], vmax), pv_pack_bf16x2_tracked(y[6], y[7], vmax)};
+            const int row = wr * 128 + mt * 16 + i16, c = wc * 8 + u * 4 + g;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+        };
+        uint16_t* orow[4];         // output row of read-back slot j in pass 0; pass q is 32 rows further
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow[j] = ob + (int64_t)(m0 + rb_row0 + 2 * j) * p.ldo;
+        const int64_t pass_stride = 32 * p.ldo;
+        auto store_row = [&](int q, int j) __attribute__((always_inline)) {
+            const int row = rb_row0 + 32 * q + 2 * j;
+            if (m0 + row < p.M && ocol_ok) *reinterpret_cast<u32x4*>(orow[j] + q * pass_stride) = rb[j];
+        };
+        issue(0);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int q = n >> 2;
+            if (n + 1 < 16) issue(n + 1);
+            wait_unit(n, n + 1 < 16, q > 0 && (n & 3) == 0);
+            finish(n);
+            if (q > 0) store_row(q - 1, n & 3);                     // one 1-KiB store of the previous pass per unit
+            if ((n & 3) == 3) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's image writes (and the gathers issued before them)
+                PV_STAMP(9 + q);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)      // row rb_row0 + 32 q + 2 j: the swizzle term does not depend on q -> base + immediate
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"(q * 32 * 512));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_row(3, j);
+        pv_range_commit(vmax, p.range_flag);
+    } else
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
         // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7).  SPLIT (precision mode): the fp32
         // results stay in the accumulators; pass 0 stores their bf16 "hi" image to planes 0 and 2 of the [M, 3N] output, pass 1
@@ -578,7 +820,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         if (pass == 1) {
                             const __attribute__((address_space(3))) f32x4* tab = (const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
+                            for (int e = 0; e < 4; e += 2) {
+                                float t0 = lo[e], t1 = lo[e + 1], t2 = hi[e], t3 = hi[e + 1];
+                                pv_gelu_lut2(t0, t1, tab); pv_gelu_lut2(t2, t3, tab);
+                                lo[e] = t0; lo[e + 1] = t1; hi[e] = t2; hi[e + 1] = t3;
+                            }
                         }
                         pk = (u32x4){pv_pack_bf16x2_tracked(lo[0], lo[1], vmax), pv_pack_bf16x2_tracked(lo[2], lo[3], vmax),
                                      pv_pack_bf16x2_tracked(hi[0], hi[1], vmax), pv_pack_bf16x2_tracked(hi[2], hi[3], vmax)};
@@ -586,7 +832,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         if (pass == 0) {
                             const __attribute__((address_space(3))) f32x4* tab = (const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { lo[e] = pv_gelu_lut(lo[e], tab); hi[e] = pv_gelu_lut(hi[e], tab); }
+                            for (int e = 0; e < 4; e += 2) {
+                                float t0 = lo[e], t1 = lo[e + 1], t2 = hi[e], t3 = hi[e + 1];
+                                pv_gelu_lut2(t0, t1, tab); pv_gelu_lut2(t2, t3, tab);
+                                lo[e] = t0; lo[e + 1] = t1; hi[e] = t2; hi[e + 1] = t3;
+                            }
                             if (SPLIT) { acc[2 * u][mt] = lo; acc[2 * u + 1][mt] = hi; }
                         }
                         if (SPLIT) {
@@ -750,11 +1000,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.dbg[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        p.dbg[(size_t)blockIdx.x * 16 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PV_STAMP(4);
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 8 + 7] = rt_; }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 7] = rt_; }
 #endif
 }
 
@@ -990,7 +1240,8 @@ __global__ __launch_bounds__(512) void pv_gemm256_tn_kernel(const GemmDev p_in) 
 // out fp32 [ksplit][M][ldo] partial products of A^T . B over K slices; A bf16 [K, M] (row stride lda), B = args->W bf16 [K, N]
 // (row stride ldw).  M, N multiples of 128, K a multiple of 128 with at least ksplit blocks of 128 rows.
 extern "C" int pv_gemm_tn_bf16(const pv_gemm_args* a, void* stream) {
-    if (!a || !a->A || !a->W || !a->out || a->M < 8 || a->N < 8 || a->K <= 0) return PV_ERR_INVALID_ARG;
+    if (!a || a->struct_size != sizeof(pv_gemm_args)) return PV_ERR_INVALID_ARG;      // nothing past the first field is read before this
+    if (!a->A || !a->W || !a->out || a->M < 8 || a->N < 8 || a->K <= 0) return PV_ERR_INVALID_ARG;
     const int ks = a->ksplit > 1 ? a->ksplit : 1;
     if (a->M % 128 || a->N % 128 || a->K % (2 * G2_BK) || a->K / (2 * G2_BK) < ks) return PV_ERR_UNSUPPORTED;
     if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->M || a->ldw < a->N || a->ldo < a->N) return PV_ERR_INVALID_ARG;
@@ -1096,7 +1347,8 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
     constexpr int lds = G2_LDS + (EPI == PV_EPI_GELU_GRAD_BF16 ? PV_GELU_TAB_N * 8      // + 32 KiB gelu' table = all 160 KiB
                                   : (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)
-                                        ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);                  // + 16 KiB replicated cubic GELU table
+                                        ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0)                   // + 16 KiB replicated cubic GELU table
+                        + ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) ? 4096 : 0);         // + 4 KiB folded-LayerNorm constants
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
@@ -1319,13 +1571,14 @@ extern "C" void pv_debug_set_gemm_fullrow(int on) { g_pv_fullrow = on; }
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only);
 extern "C" int pv_gemm_bf16(const pv_gemm_args* a, void* stream) { return pv_gemm_dispatch(a, stream, false); }
 extern "C" int pv_gemm_tile_rows(const pv_gemm_args* a) {
-    if (!a) return PV_ERR_INVALID_ARG;
+    if (!a || a->struct_size != sizeof(pv_gemm_args)) return PV_ERR_INVALID_ARG;
     pv_gemm_args q = *a;
     q.colsum_partial = nullptr; q.x16_out = nullptr; q.rowstat_out = nullptr; q.fold_stat = nullptr; q.rowsq_out = nullptr;
     return pv_gemm_dispatch(&q, nullptr, true);
 }
 static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only) {
-    if (!a || !a->A || !a->W || !a->out || a->M <= 0 || a->N <= 0 || a->K <= 0) return PV_ERR_INVALID_ARG;
+    if (!a || a->struct_size != sizeof(pv_gemm_args)) return PV_ERR_INVALID_ARG;      // nothing past the first field is read before this
+    if (!a->A || !a->W || !a->out || a->M <= 0 || a->N <= 0 || a->K <= 0) return PV_ERR_INVALID_ARG;
     if (a->K % 64 || a->N % 4) return PV_ERR_UNSUPPORTED;
     if (a->lda % 8 || a->ldw % 8 || a->ldo % 4 || a->lda < a->K || a->ldw < a->K || a->ldo < a->N) return PV_ERR_INVALID_ARG;
     if (((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) || ((uintptr_t)a->out & 15) || (a->bias && ((uintptr_t)a->bias & 15))) return PV_ERR_INVALID_ARG;

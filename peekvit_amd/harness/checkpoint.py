@@ -57,9 +57,17 @@ def load_state(file: str, model: Optional[torch.nn.Module] = None, optimizer=Non
             raise ValueError(f"checkpoint of class {state['model_class']!r}: only {sorted(classes)} are built here")
         args = {k: v for k, v in _plain(state["model_args"] or {}).items() if k not in _NOT_CONSTRUCTOR_ARGS}
         model = classes[state["model_class"]](**args)
-    res = model.load_state_dict(state["state_dict"], strict=strict)
-    if len(res[0]) > 0:
-        print("Some parameters are not present in the checkpoint and will be randomly initialized: ", res[0])
+    try:
+        res = model.load_state_dict(state["state_dict"], strict=strict)
+        if len(res[0]) > 0:
+            print("Some parameters are not present in the checkpoint and will be randomly initialized: ", res[0])
+    except RuntimeError as e:
+        if strict:
+            raise
+        # the reference reports a checkpoint of another architecture and carries on (utils/utils.py:241-250)
+        print(e)
+        print("The model state dict could not be loaded. This is probably because the checkpoint has a different architecture.")
+        print("Checkpoint class: ", state["model_class"], " Model class: ", type(model).__name__, " Checkpoint args: ", state["model_args"])
     if optimizer is not None and state.get("optimizer") is not None:
         optimizer.load_state_dict(state["optimizer"])
     return model, state

@@ -71,11 +71,27 @@ def main(argv: Sequence[str] = ()) -> dict:
     history = {"loss": [], "val_accuracy": []}
     model_args = dict(cfg["model"])                            # as the reference stores it (train.py: dict(cfg.model), `_target_` included)
     start_epoch = 0
-    if cfg.get("load_from"):                                   # resume: weights, optimizer state and epoch of the last checkpoint
-        ck = checkpoint.get_checkpoint_path(cfg["load_from"])
-        if ck is not None:
-            _, st = checkpoint.load_state(ck, model=model, optimizer=optimizer)
-            start_epoch = int(st.get("epoch", -1)) + 1
+    if cfg.get("load_from"):
+        # the reference's semantics (train/train.py:64-70): INITIALISE THE WEIGHTS from a finished run - a .pth file or an experiment
+        # directory (its last checkpoint) - with strict=False; optimizer state and epoch are ignored and training runs epochs 0..N.
+        # This is how a ResidualViT / RankViT is fine-tuned from a trained ViT (different parameter sets, so the stored optimizer
+        # state could not be loaded anyway).
+        lf = cfg["load_from"]
+        ck = lf if str(lf).endswith(".pth") else checkpoint.get_checkpoint_path(lf)
+        if ck is None or not os.path.isfile(ck):
+            raise FileNotFoundError(f"load_from={lf!r}: no checkpoint found (a .pth file, or a directory with checkpoints/*.pth)")
+        print("Loading model from checkpoint: ", ck)
+        checkpoint.load_state(ck, model=model)
+    if cfg.get("resume_from"):
+        # NOT in the reference: continue an interrupted run of THIS model - weights, optimizer state and epoch of the last checkpoint
+        rf = cfg["resume_from"]
+        ck = rf if str(rf).endswith(".pth") else checkpoint.get_checkpoint_path(rf)
+        if ck is None or not os.path.isfile(ck):
+            raise FileNotFoundError(f"resume_from={rf!r}: no checkpoint found")
+        _, st = checkpoint.load_state(ck, model=model, optimizer=optimizer, strict=True)
+        start_epoch = int(st.get("epoch", -1)) + 1
+        if start_epoch >= tr["num_epochs"]:
+            print(f"resume_from: checkpoint {ck} is of epoch {start_epoch - 1}, training.num_epochs={tr['num_epochs']}: nothing left to train")
     for epoch in range(start_epoch, tr["num_epochs"]):
         history["loss"].append(train_epoch(model, loader, optimizer, device, tr.get("clip_grad_norm", 1.0), distributed))
         if (epoch + 1) % tr.get("eval_every", 1) == 0:

@@ -66,5 +66,32 @@ def test_training_resumes_with_optimizer_state(tmp_path):
     htrain.main(base + ["training.num_epochs=1"])
     st = torch.load(checkpoint.get_checkpoint_path(str(tmp_path)), weights_only=False)
     assert st["optimizer"] is not None and st["model_args"]["_target_"].endswith("VisionTransformer")       # stored as the reference stores it
-    hist = htrain.main(base + ["training.num_epochs=3", f"load_from={tmp_path}"])
+    hist = htrain.main(base + ["training.num_epochs=3", f"resume_from={tmp_path}"])
     assert len(hist["loss"]) == 2 and checkpoint.get_checkpoint_path(str(tmp_path)).endswith("epoch_002.pth")   # epochs 1 and 2 only
+
+
+def test_load_from_initialises_weights_only_like_the_reference(tmp_path):
+    """train/train.py:64-70: `load_from` (a .pth file or an experiment directory) loads the WEIGHTS with strict=False, ignores optimizer state
+    and epoch, and training still runs epochs 0..N - the reference's way to fine-tune a RankViT / ResidualViT from a finished ViT run."""
+    import pytest
+    src_dir, dst_dir = tmp_path / "vit", tmp_path / "rank"
+    htrain.main(MICRO + ["training.train_batch_size=8", "training.num_epochs=2", f"experiment_dir={src_dir}"])
+    ck = checkpoint.get_checkpoint_path(str(src_dir))
+    assert ck.endswith("epoch_001.pth")
+    # (1) a directory: another model family (extra / different parameters: the ViT's optimizer state could not even be loaded), all epochs run
+    hist = htrain.main(MICRO + ["model=rankvit_b_16", "model.rankvit_layers=[1]", "training.train_batch_size=8", "training.num_epochs=2",
+                                f"experiment_dir={dst_dir}", f"load_from={src_dir}"])
+    assert len(hist["loss"]) == 2 and checkpoint.get_checkpoint_path(str(dst_dir)).endswith("epoch_001.pth")
+    # (2) a .pth path is taken as the file itself; the weights really arrive (0 epochs: the saved model equals the checkpoint's)
+    from peekvit_amd.harness.config import instantiate, load_config
+    model = instantiate(load_config("train_config", MICRO)["model"])
+    checkpoint.load_state(ck, model=model)
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    hist = htrain.main(MICRO + ["training.train_batch_size=8", "training.num_epochs=0", f"load_from={ck}"])
+    assert hist["loss"] == []
+    # (3) set but nothing there: an error, never a silent training run from scratch
+    with pytest.raises(FileNotFoundError):
+        htrain.main(MICRO + ["training.num_epochs=1", f"load_from={tmp_path / 'nowhere'}"])
+    with pytest.raises(FileNotFoundError):
+        htrain.main(MICRO + ["training.num_epochs=1", f"load_from={tmp_path / 'nowhere.pth'}"])
+    assert all(torch.equal(want[k], v) for k, v in torch.load(ck, weights_only=False)["state_dict"].items())

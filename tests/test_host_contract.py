@@ -20,19 +20,82 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
-    assert lib.pv_version() == _lib.ABI_VERSION == 6 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
+    assert lib.pv_version() == _lib.ABI_VERSION == 7 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
     assert b"launch" in lib.pv_error_string(-3)
     lib16 = _lib.load("f16")                            # the fp16-operand build of the same sources exports the same ABI
-    assert lib16.pv_version() == 6 and lib16.pv_operand_type() == 1
+    assert lib16.pv_version() == 7 and lib16.pv_operand_type() == 1
+
+
+def _header_gemm_fields():
+    """(name, C type) of every pv_gemm_args field, parsed from include/peekvit_hip.h (comments removed)."""
+    import re
+    src = open(os.path.join(REPO, "include", "peekvit_hip.h")).read()
+    body = src[src.index("typedef struct pv_gemm_args {"):src.index("} pv_gemm_args;")].split("{", 1)[1]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        ctype, names = decl.rsplit(" ", 1)[0], decl
+        m = re.match(r"(const )?(\w+)(\*?) (.+)", decl)
+        base, ptr, names = m.group(2), m.group(3), m.group(4)
+        for n in names.split(","):
+            n = n.strip()
+            fields.append((n.lstrip("*"), "ptr" if (ptr or n.startswith("*")) else base))
+    return fields
+
+
+def _ctypes_kind(t):
+    import ctypes as C
+    return {C.c_void_p: "ptr", C.c_int64: "int64_t", C.c_uint64: "uint64_t", C.c_int32: "int32_t", C.c_float: "float"}[t]
 
 
 def test_gemm_args_struct_matches_header_layout():
     import ctypes as C
     from peekvit_amd._lib import GemmArgs
-    assert C.sizeof(GemmArgs) == 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8 + 2 * 8 + 8   # fused-LN fields, ln_eps + ksplit share 8 bytes, colsum_partial, 5 fold pointers, range_flag, rowsq_out, res_scaled (+ padding)
-    assert GemmArgs.range_flag.offset == C.sizeof(GemmArgs) - 24 and GemmArgs.rowsq_out.offset == C.sizeof(GemmArgs) - 16 and GemmArgs.res_scaled.offset == C.sizeof(GemmArgs) - 8
-    assert GemmArgs.qscale.offset == 18 * 8 and GemmArgs.epilogue.offset == 18 * 8 + 4
-    assert GemmArgs.ln_gamma.offset == 19 * 8 and GemmArgs.ln_eps.offset == 23 * 8
+    hdr = _header_gemm_fields()
+    assert hdr[0] == ("struct_size", "uint64_t")          # ABI v7: the length comes first, readable whatever the caller's struct is
+    assert [(n, _ctypes_kind(t)) for n, t in GemmArgs._fields_] == hdr
+    assert C.sizeof(GemmArgs) == 8 + 7 * 8 + 11 * 8 + 4 + 4 + 4 * 8 + 8 + 8 + 5 * 8 + 2 * 8 + 8   # size, 7 pointers, 11 int64, qscale + epilogue, fused-LN fields, ln_eps + ksplit, colsum_partial, 5 fold pointers, range_flag, rowsq_out, res_scaled (+ padding)
+    assert GemmArgs.struct_size.offset == 0 and GemmArgs.A.offset == 8
+    assert GemmArgs.qscale.offset == 19 * 8 and GemmArgs.epilogue.offset == 19 * 8 + 4
+    assert GemmArgs.ln_gamma.offset == 20 * 8 and GemmArgs.ln_eps.offset == 24 * 8
+    assert GemmArgs.res_scaled.offset == C.sizeof(GemmArgs) - 8
+    assert GemmArgs().struct_size == C.sizeof(GemmArgs) and GemmArgs(M=3).struct_size == C.sizeof(GemmArgs)
+
+
+def test_integration_md_stub_matches_header_field_for_field():
+    """The ctypes stub INTEGRATION.md tells a reference maintainer to paste is EXECUTED (with a stand-in for the library handle) and its
+    struct compared with include/peekvit_hip.h: round 2 appended a field to the header and the library without updating the document."""
+    import ctypes as C
+    import re
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = doc[doc.index("class pv_gemm_args(C.Structure):"):doc.index("_lib.pv_gemm_args_size.restype")]
+    ns = {"C": C}
+    exec(block, ns)
+    stub = ns["pv_gemm_args"]
+    assert [(n, _ctypes_kind(t)) for n, t in stub._fields_] == _header_gemm_fields()
+    from peekvit_amd._lib import GemmArgs, ABI_VERSION
+    assert C.sizeof(stub) == C.sizeof(GemmArgs) and stub(M=5).struct_size == C.sizeof(GemmArgs)
+    # the version the document asserts is the one the package binds and the library source returns
+    assert int(re.search(r"_lib\.pv_version\(\) == (\d+)", doc).group(1)) == ABI_VERSION
+    api = open(os.path.join(REPO, "peekvit_amd", "csrc", "pv_api.hip")).read()
+    assert int(re.search(r"pv_version\(void\) \{ return (\d+); \}", api).group(1)) == ABI_VERSION
+
+
+def test_library_refuses_a_struct_of_another_length():
+    """No GPU needed: pv_gemm_bf16 / pv_gemm_tn_bf16 / pv_gemm_tile_rows return PV_ERR_INVALID_ARG before reading anything but the
+    first field when struct_size is not the library's own sizeof(pv_gemm_args)."""
+    import ctypes as C
+    from peekvit_amd import _lib
+    lib = _lib.load()
+    assert lib.pv_version() == _lib.ABI_VERSION and lib.pv_gemm_args_size() == C.sizeof(_lib.GemmArgs)
+    short = (C.c_uint64 * 1)(C.sizeof(_lib.GemmArgs) - 8)          # a one-field "struct" claiming round 2's length
+    p = C.cast(short, C.POINTER(_lib.GemmArgs))
+    assert lib.pv_gemm_bf16(p, None) == -1 and lib.pv_gemm_tn_bf16(p, None) == -1 and lib.pv_gemm_tile_rows(p) == -1     # PV_ERR_INVALID_ARG
+    zero = (C.c_uint64 * 1)(0)
+    assert lib.pv_gemm_bf16(C.cast(zero, C.POINTER(_lib.GemmArgs)), None) == -1
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
