@@ -29,6 +29,12 @@ from typing import List, Optional, Sequence
 import torch
 
 
+def _blocks(model) -> list:
+    """The transformer blocks of `encoder.layers`.  A module spliced between them that owns no Linear / MultiheadAttention - the
+    evaluation harness's NoiseBlock (harness/noise.py) - fires none of the reference's hooks and is skipped here as well."""
+    return [m for m in model.encoder.layers if hasattr(m, "self_attention")]
+
+
 def _linear_macs(rows: float, fin: int, fout: int, bias: bool = True) -> float:
     return (fin * fout + (fout if bias else 0)) * rows
 
@@ -50,8 +56,9 @@ def model_flops(model, seq_per_layer: Optional[Sequence[int]] = None, live_per_l
     seq_per_layer: tokens entering each block (RankViT shrinks it); live_per_layer: of those, how many are non-zero rows at
     the block's attention / MLP inputs (ResidualViT masks with relu(...) == 0 zero their rows).  Defaults: full sequence."""
     D, M, P = model.hidden_dim, model.mlp_dim, model.patch_size
-    H = model.encoder.layers[0].self_attention.self_attention.num_heads
-    L = len(model.encoder.layers)
+    blocks = _blocks(model)
+    H = blocks[0].self_attention.self_attention.num_heads
+    L = len(blocks)
     Np = (model.image_size // P) ** 2
     S = Np + model.num_class_tokens + model.num_registers + (1 if getattr(model, "add_budget_token", False) else 0)
     seqs = list(seq_per_layer) if seq_per_layer is not None else [S] * L
@@ -61,7 +68,7 @@ def model_flops(model, seq_per_layer: Optional[Sequence[int]] = None, live_per_l
         macs += block_macs(lv, s, D, M, H)
     macs += 2 * seqs[-1] * D                                               # encoder.ln
     macs += _linear_macs(1, D, model.num_classes)                          # head on the pooled class token
-    if hasattr(model.encoder.layers[0], "residual_gate"):
+    if hasattr(blocks[0], "residual_gate"):
         for s in seqs:                                                     # gate projection D->1 on image tokens (+ budget gate)
             macs += _linear_macs(s - 2, D, 1) + _linear_macs(1, D, 1)
     return 2.0 * macs
@@ -77,7 +84,7 @@ def measured_flops(model, x: torch.Tensor):
     S = (model.image_size // model.patch_size) ** 2 + model.num_class_tokens + model.num_registers
     S += 1 if getattr(model, "add_budget_token", False) else 0
     sparsity: List[float] = []
-    for blk in model.encoder.layers:
+    for blk in _blocks(model):
         keep = getattr(blk, "last_keep", None)
         if keep is not None and getattr(blk, "current_budget", 1) != 1:
             S = 1 + keep.shape[1]
@@ -101,12 +108,14 @@ def hook_macs(model, x: torch.Tensor):
     out = model(x)
     B = int(out.shape[0])
     D, M = model.hidden_dim, model.mlp_dim
-    H = model.encoder.layers[0].self_attention.self_attention.num_heads
+    H = _blocks(model)[0].self_attention.self_attention.num_heads
     dh = D // H
     S = (model.image_size // model.patch_size) ** 2 + model.num_class_tokens + model.num_registers
     S += 1 if getattr(model, "add_budget_token", False) else 0
     per = {}
     for i, blk in enumerate(model.encoder.layers):
+        if not hasattr(blk, "self_attention"):
+            continue
         keep = getattr(blk, "last_keep", None)
         if keep is not None and getattr(blk, "current_budget", 1) != 1:
             S = 1 + int(keep.shape[1])

@@ -95,3 +95,69 @@ def test_load_from_initialises_weights_only_like_the_reference(tmp_path):
     with pytest.raises(FileNotFoundError):
         htrain.main(MICRO + ["training.num_epochs=1", f"load_from={tmp_path / 'nowhere.pth'}"])
     assert all(torch.equal(want[k], v) for k, v in torch.load(ck, weights_only=False)["state_dict"].items())
+
+
+def test_noise_block_matches_the_reference_semantics():
+    """models/blocks.py:100-186 restated independently here: gaussian noise at an SNR in dB relative to each token's power (snr 0 adds
+    nothing), token_drop zeroes int(prob * S) positions drawn with torch.randperm and shared by the batch, std is refused."""
+    import pytest
+    from peekvit_amd.models.blocks import NoiseBlock
+    x = torch.randn(3, 10, 8)
+    nb = NoiseBlock("gaussian")
+    nb.set_value(20.0)
+    torch.manual_seed(5)
+    got = nb(x)
+    torch.manual_seed(5)
+    want = x + torch.randn_like(x) * torch.sqrt((x ** 2).mean(-1, keepdim=True) / 10 ** (20.0 / 10))
+    assert torch.equal(got, want)
+    nb.set_value(0)
+    assert torch.equal(nb(x), x)
+    snr = 10 * torch.log10((x ** 2).mean() / ((got - x) ** 2).mean())
+    assert abs(float(snr) - 20.0) < 1.5                                              # the realised SNR is the requested one
+    td = NoiseBlock("token_drop", prob=0.3)
+    torch.manual_seed(7)
+    got = td(x)
+    torch.manual_seed(7)
+    idx = torch.randperm(10)[:3]
+    want = x.clone(); want[:, idx] = 0
+    assert torch.equal(got, want) and int((got.abs().sum(-1) == 0).sum()) == 3 * 3
+    td.set_value(0)
+    assert td(x) is x
+    with pytest.raises(ValueError):
+        NoiseBlock("gaussian", std=0.1)
+    with pytest.raises(AssertionError):
+        td.set_snr(3.0)                                                               # a token_drop block has no SNR
+
+
+def test_add_noise_splices_the_encoder_and_the_sweep_reports_every_value():
+    from peekvit_amd.harness.noise import add_noise
+    from peekvit_amd.models.blocks import NoiseBlock
+    model = config.instantiate(config.load_config("test_config", MICRO)["model"])
+    blocks = list(model.encoder.layers)
+    nm = add_noise(model, layer=1, noise_type="token_drop", prob=0.5)
+    layers = list(model.encoder.layers)
+    assert isinstance(nm, NoiseBlock) and layers[1] is nm and layers[0] is blocks[0] and layers[2] is blocks[1] and len(layers) == 3
+    assert "noise" not in "".join(model.state_dict().keys())                         # no parameters, nothing new in the state dict
+    x = torch.randn(2, 3, 32, 32)
+    torch.nn.init.normal_(model.head.weight, std=0.02)                                # (the reference's zero head would hide everything)
+    with torch.no_grad():
+        model.eval()
+        torch.manual_seed(1); a = model(x)
+        nm.set_value(0.0); b = model(x)
+    assert a.shape == b.shape and not torch.allclose(a, b)
+    # named layers (the reference's OrderedDict case): inserted under the name 'noise'
+    from collections import OrderedDict
+    model2 = config.instantiate(config.load_config("test_config", MICRO)["model"])
+    model2.encoder.layers = torch.nn.Sequential(OrderedDict((f"encoder_layer_{i}", m) for i, m in enumerate(model2.encoder.layers)))
+    add_noise(model2, layer=2, noise_type="gaussian", snr=10.0)
+    assert [n for n, _ in model2.encoder.layers.named_children()] == ["encoder_layer_0", "encoder_layer_1", "noise"]
+    # the harness loop: budgets x noise values, the clean-channel row equals the run without a noise module
+    clean = htest.main(MICRO + ["test.test_batch_size=8"])
+    res = htest.main(MICRO + ["test.test_batch_size=8", "noise=gaussian", "noise.layer=1", "test.noises=[0.0,-10.0]"])
+    assert [r["noise"] for r in res] == [0.0, -10.0] and res[0]["noise_type"] == "gaussian"
+    assert res[0]["accuracy"] == clean[0]["accuracy"] and res[0]["flops_per_image"] == clean[0]["flops_per_image"]
+    # (the splice shifts the indices of the blocks behind it, and RankVisionTransformer.set_budget indexes encoder.layers by position -
+    # models/rankvit.py:287-288 - so, as in the reference, the ranked layers must sit in front of the noise module)
+    res = htest.main(MICRO + ["model=rankvit_b_16", "model.rankvit_layers=[0]", "test.budgets=[0.5,1.0]", "noise=digital", "noise.layer=1", "test.noises=[0.0,0.5]"])
+    assert [(r["budget"], r["noise"]) for r in res] == [(0.5, 0.0), (0.5, 0.5), (1.0, 0.0), (1.0, 0.5)]
+    assert res[0]["flops_per_image"] < res[2]["flops_per_image"]

@@ -95,6 +95,40 @@ def test_block_level_standalone_and_surgery():
         assert m(_x(cfg).to(DEV)).shape == (2, cfg["num_classes"])
 
 
+def test_noise_block_splice_keeps_the_hip_path_running():
+    """validate/test.py:72-111 + utils/utils.py:162-191: the evaluation harness splices a NoiseBlock (stock PyTorch, RNG-driven) into
+    encoder.layers and sweeps its value.  The blocks around it keep running on the MI355X kernels; the block in front of it fuses
+    nothing for a consumer that is not a plain block; the logits equal the CPU composite's for the same dropped token positions."""
+    from peekvit_amd import ops
+    from peekvit_amd.harness.noise import add_noise
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg, m = _model("vit", "vit_tiny")
+    x = _x(cfg, 4)
+    with torch.no_grad():
+        clean = m(x.to(DEV)).cpu().numpy()
+    nm = add_noise(m, layer=2, noise_type="token_drop", prob=0.25)
+    ref = VisionTransformer(**cfg)
+    synth.load_synth_weights(ref, cfg, "vit", seed=0)
+    ref = ref.eval()
+    rn = add_noise(ref, layer=2, noise_type="token_drop", prob=0.25)
+    n0 = ops.launch_count
+    with torch.no_grad():
+        torch.manual_seed(11); got = m(x.to(DEV)).cpu().numpy()          # torch.randperm draws the positions from the HOST generator
+        torch.manual_seed(11); want = ref(x).numpy()
+    assert ops.launch_count - n0 >= 4 + 6 * cfg["num_layers"], "the blocks around the NoiseBlock left the HIP path"   # (30 observed: 4 blocks x 6-7 + stem + head)
+    assert rel_l2(got, want) < TOL_CONTRACT and rel_l2(got, clean) > 5e-2       # same noise, and it did something
+    nm.set_value(0.0); rn.set_value(0.0)
+    with torch.no_grad():
+        assert rel_l2(m(x.to(DEV)).cpu().numpy(), clean) < 1e-4                # prob 0: the clean channel (other summation order at most)
+    # gaussian noise at a huge SNR is the clean channel too; at -10 dB it is not
+    del m.encoder.layers[2]
+    gm = add_noise(m, layer=1, noise_type="gaussian")
+    with torch.no_grad():
+        gm.set_value(200.0); quiet = m(x.to(DEV)).cpu().numpy()
+        gm.set_value(-10.0); loud = m(x.to(DEV)).cpu().numpy()
+    assert rel_l2(quiet, clean) < TOL_CONTRACT and rel_l2(loud, clean) > 5e-2 and np.isfinite(loud).all()
+
+
 @pytest.mark.parametrize("name,layers,b", [("vit_micro", [0, 1], 0.5), ("vit_micro", [0, 1], 0.25), ("vit_tiny", [1, 2, 3], 0.5),
                                            ("vit_b_16", [3, 6, 9], 0.5)])
 def test_rankvit_parity(golden, name, layers, b):
@@ -116,13 +150,15 @@ def test_rankvit_parity(golden, name, layers, b):
     for li in layers:
         _, keep = O.sort_and_drop(ins[li], b)
         assert np.array_equal(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), keep.numpy())
-    # END-TO-END against the REAL reference: where every layer's kept SET equals the reference's the logits meet the contract
-    # tolerance; a near-tie at the keep boundary that the 16-bit layers before it resolve the other way swaps one survivor and costs more
-    same_sets = all(np.array_equal(np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1),
-                                   np.sort(g[f"{name}_b{b}_keep{li}"], axis=1)) for li in layers)
-    err = rel_l2(logits, g[f"{name}_b{b}_logits"])
-    print(f"rankvit {name} b={b}: keep sets {'equal' if same_sets else 'differ'}, logits rel-L2 {err:.2e}")
-    assert err < (TOL_CONTRACT if same_sets else 2.5e-2), (same_sets, err)
+    # END-TO-END against the REAL reference.  What happens on an MI355X for these golden inputs is on record
+    # (scripts/parity_observed.py -> profiles/r03_parity_observed.json): in ALL four cases every ranked layer keeps exactly the
+    # reference's token SET (the 16-bit layers in front of a ranking never resolve a near-tie the other way here) and the logits are
+    # 5.8e-4 .. 7.5e-4 from the reference's - so both are asserted unconditionally; round 2 chose between 1e-3 and 2.5e-2 by a branch
+    # that only a dropped print recorded.
+    for li in layers:
+        assert np.array_equal(np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1),
+                              np.sort(g[f"{name}_b{b}_keep{li}"], axis=1)), f"layer {li}: kept set differs from the reference's"
+    assert rel_l2(logits, g[f"{name}_b{b}_logits"]) < TOL_CONTRACT
     m.set_budget(1.0)
     with torch.no_grad():
         full = m(x.to(DEV)).cpu().numpy()
@@ -152,9 +188,10 @@ def test_residualvit_parity(golden, tag, name, gb):
         assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
         assert np.abs(masks - g[f"{tag}_b{b}_masks"]).max() < 2e-3            # every block's mask vs the REAL reference's
         if np.linalg.norm(g[f"{tag}_b{b}_logits"]) > 0:
-            # the contract tolerance holds on the BASELINE-sized model; the 2-layer, 18-token toy has no averaging over tokens / width
-            # behind its soft masks and sits at 1.1e-3 with fp16 operands (measured)
-            assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < (TOL_CONTRACT if name == "vit_b_16" else 2 * TOL_CONTRACT)
+            # the contract tolerance, on every case but ONE, whose observed value is committed instead of a blanket allowance
+            # (profiles/r03_parity_observed.json): the 2-layer, 18-token toy with the reference's gate bias of 10 at budget 0.2 - no
+            # averaging over tokens / width behind its soft masks - measures 1.07e-3 with fp16 operands (bf16x3: 6e-6)
+            assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < (1.25e-3 if (tag, b) == ("vit_micro", 0.2) else TOL_CONTRACT)
 
 
 def test_error_contract_matches_reference():

@@ -130,8 +130,7 @@ def test_rankvit_and_residualvit_within_tolerance(golden):
 
 
 def test_rankvit_and_residualvit_f16_within_tolerance(golden):
-    """fp16 operands: pruned / gated models also land within 1e-3 of the reference (near-tied token norms may rank differently
-    than in fp32, so the keep sets are compared by overlap, not bit for bit)."""
+    """fp16 operands: pruned / gated models also land within 1e-3 of the reference, with the reference's own kept token sets."""
     from peekvit_amd import engine
     cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
     x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
@@ -139,15 +138,12 @@ def test_rankvit_and_residualvit_f16_within_tolerance(golden):
     with torch.no_grad(), engine.precision("f16"):
         logits = m(x).cpu().numpy()
     g = golden("rankvit")
-    same_sets = True
+    # observed on an MI355X and committed (profiles/r03_parity_observed.json, "f16/vit_b_16/[3, 6, 9]/0.5"): all three ranked layers keep
+    # exactly the reference's token set, logits 5.8e-4 from the reference's - BASELINE config 4 meets the contract end to end
     for li in (3, 6, 9):
         got = np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1)
-        ref = np.sort(g[f"vit_b_16_b0.5_keep{li}"], axis=1)
-        assert (got == ref).mean() > 0.97
-        same_sets = same_sets and np.array_equal(got, ref)
-    err = rel_l2(logits, g["vit_b_16_b0.5_logits"])
-    print(f"rankvit_b_16 f16: keep sets {'equal' if same_sets else 'differ'}, logits rel-L2 {err:.2e}")
-    assert err < (TOL_NORTH_STAR if same_sets else 3 * TOL_NORTH_STAR)       # a swapped near-tie changes which token survives
+        assert np.array_equal(got, np.sort(g[f"vit_b_16_b0.5_keep{li}"], axis=1)), f"layer {li}: kept set differs from the reference's"
+    assert rel_l2(logits, g["vit_b_16_b0.5_logits"]) < TOL_NORTH_STAR
     extra = dict(gate_type="sigmoid", gate_temp=1, gate_bias=10, add_budget_token="learnable", gate_threshold=0.5)
     cfg, m = _model("res", "vit_b_16", **extra)
     m.set_budget(0.5)
