@@ -246,11 +246,11 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed, elapsed_instr = float(t[0].item()), float(t[1].item())
 
-    # the 16-bit operand type the timed steps really computed in: training -> bf16; inference in mode auto -> fp16 unless the range
-    # guard sent forwards to the bf16 library
+    # the 16-bit operand type the timed steps really computed in: training -> bf16; inference in mode auto -> fp16 unless a guard
+    # sent forwards to the fallback mode (split bf16 operands)
     fallbacks = engine.fallback_count - fallbacks0
     if args.precision == "auto":
-        dtype = "bf16" if (args.train or fallbacks or getattr(infer_model, "_pv_f16_unsafe", False)) else "f16"
+        dtype = "bf16" if args.train else ("bf16x3" if (fallbacks or engine.guard_state(infer_model).unsafe) else "f16")
     else:
         dtype = args.precision
     if rank == 0:

@@ -151,8 +151,11 @@ typedef struct pv_gemm_args {
 /* sizeof(pv_gemm_args) of THIS library build (ABI v7): a binding asserts it equals its own struct's size when it loads the library. */
 uint64_t pv_gemm_args_size(void);
 
-/* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length. */
-int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, void* stream);
+/* (mean, rstd) per row from the producer's partial sums: partials fp32 [tiles, rows, 2] -> stat fp32 [rows, 2]; D = row length.
+ * range_flag (ABI v7, optional): the device word of the operand-range guard; bit 2 is ORed in when a row's |mean| * rstd exceeds 1 -
+ * folding rounds the RAW row to 16 bits, and a row whose mean is large against its spread loses the spread (operand noise grows by
+ * sqrt(1 + (mean/std)^2)): the caller repeats the forward with the LayerNorm applied before the rounding. */
+int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, uint32_t* range_flag, void* stream);
 
 /* The M-tile height (256 or 128) pv_gemm_bf16 would choose for these arguments (no launch). */
 int pv_gemm_tile_rows(const pv_gemm_args* args);
@@ -170,15 +173,18 @@ int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
  *   also returns are discarded there and are not computed here).
  * qkv: bf16 [B,S,3*H*dh] packed q|k|v (nn.MultiheadAttention in_proj layout), out: bf16 [B,S,H*dh].
  * dh in {32,48,64}: S <= 416 keeps K and V of a head in the LDS (single-pass softmax), longer sequences stream 64-key blocks
- * with an online softmax; dh in {80,96,128}: the streaming kernel for every S. */
-int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
+ * with an online softmax; dh in {80,96,128}: the streaming kernel for every S.
+ * range_flag (ABI v7, optional): the device word of the operand-range guard; the fp16-operand build ORs 4 into it when the magnitude of
+ * a query's largest score exceeds 32 - the 16-bit rounding of q and k leaves an error proportional to the score in it, and beyond that
+ * the softmax no longer meets BASELINE's 1e-3 (measured sensitivity: DESIGN.md section 13).  The bf16 build ignores it. */
+int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag, void* stream);
 
 /* The same attention for the FIRST nq ROWS of every image only (queries) against all S keys: the last encoder block, of whose output
  * only the class-token rows are read (models/vit.py:242-246; the reference computes all S rows and drops the rest).
  * q: 16-bit [B*nq rows, ldq] (already scaled), kv: 16-bit [B*S rows, ldkv] with k in columns [0, H*dh) and v in [H*dh, 2*H*dh),
  * out: 16-bit [B*nq rows, ldo].  dh in {32,48,64,80,96,128}, any S; ld* in elements, multiples of 8. */
 int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B,
-                           int64_t S, int64_t nq, int64_t H, int64_t dh, void* stream);
+                           int64_t S, int64_t nq, int64_t H, int64_t dh, uint32_t* range_flag /* as pv_attention_bf16 */, void* stream);
 
 /* Backward of pv_attention_rows_bf16 for nq = 1 (one class token; other nq: PV_ERR_UNSUPPORTED).  out = the forward's result, dout = its
  * gradient; dq [B, lddq] is the gradient of the UNSCALED q (times qscale, like pv_attention_bwd_bf16), dkv [B*S, lddkv] = dk | dv of every

@@ -72,9 +72,9 @@ SIGNATURES = {
     "pv_operand_type": (C.c_int, []),
     "pv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "pv_gemm_tile_rows": (C.c_int, [C.POINTER(GemmArgs)]),
-    "pv_rowstat_finalize": (C.c_int, [_p, _p, _i64, _i64, _i64, _f32, _p]),
-    "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
-    "pv_attention_rows_bf16": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "pv_rowstat_finalize": (C.c_int, [_p, _p, _i64, _i64, _i64, _f32, _p, _p]),
+    "pv_attention_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "pv_attention_rows_bf16": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p]),
     "pv_attention_rows_bwd_bf16": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_cls_pool": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_head_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),

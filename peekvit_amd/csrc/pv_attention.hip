@@ -36,7 +36,7 @@ extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbo
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
-__global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
+__global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     PV_ASTAMP(2);
     bool v_ready = false;
 
+    float smax = 0.f;              // operand-range guard: the largest |row maximum of the scores| this lane has seen
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int qt = wid + 4 * t;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        pv_score_track(smax, m);
         // p = exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp per score
         const float nm = -m * 1.44269504088896340736f;
         float l = 0.f;
@@ -237,18 +239,19 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    pv_score_commit(smax, flag);
     PV_ASTAMP(3);
 }
 
 template <int DH, int NKT>
-static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int lds = 2 * NKT * 16 * DHP * 2;
     static PvPerDevice attr_set;
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H, flag);
     return pv_check_launch();
 }
 
@@ -260,7 +263,7 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
 // combined once at the end.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int nqb) {
+__global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int nqb, uint32_t* flag) {
     constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, KS = DHP / 32, NDT = DH / 16, KB = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KB * DHP * 2];
     __shared__ __attribute__((aligned(16))) char Vs[KB * DHP * 2];
@@ -358,6 +361,11 @@ __global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __r
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    {
+        float smax = 0.f;
+        pv_score_track(smax, m);       // the row's final maximum (every block's maximum has passed through it)
+        pv_score_commit(smax, flag);
+    }
     if (q0 + i16 < S) {
         const float inv = 1.0f / l;
         uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
@@ -370,23 +378,23 @@ __global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __r
 }
 
 template <int DH>
-static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
     const int nqb = (S + 63) / 64;
     if (B * H * nqb > 0x7fffffff) return PV_ERR_UNSUPPORTED;
-    PV_LAUNCH(pv_attn_stream_kernel<DH>, dim3((unsigned)(B * H * nqb)), dim3(256), 0, stream, qkv, out, S, H, nqb);
+    PV_LAUNCH(pv_attn_stream_kernel<DH>, dim3((unsigned)(B * H * nqb)), dim3(256), 0, stream, qkv, out, S, H, nqb, flag);
     return pv_check_launch();
 }
 
 template <int DH>
-static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
     switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, stream);
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
         PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13) PV_ATTN_CASE(14)
         PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20) PV_ATTN_CASE(21)
         PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
-        default: return pv_launch_attn_stream<DH>(qkv, out, B, S, H, stream);
+        default: return pv_launch_attn_stream<DH>(qkv, out, B, S, H, flag, stream);
     }
 }
 
@@ -830,7 +838,7 @@ extern "C" int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, 
 // every lane group runs its own online softmax over its keys, the groups are merged at the end.  All arithmetic fp32 (p is not rounded).
 template <int DH>
 __global__ __launch_bounds__(256) void pv_attn_rows_kernel(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kv, int64_t ldkv,
-                                                           uint16_t* __restrict__ out, int64_t ldo, int S, int H, int nq, int64_t total) {
+                                                           uint16_t* __restrict__ out, int64_t ldo, int S, int H, int nq, int64_t total, uint32_t* flag) {
     constexpr int NCH = DH / 8;
     constexpr int CPL = NCH <= 4 ? 4 : (NCH <= 8 ? 8 : 16);
     constexpr int KPI = 64 / CPL;
@@ -894,6 +902,11 @@ __global__ __launch_bounds__(256) void pv_attn_rows_kernel(const uint16_t* __res
         for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], d, 64) * a2;
         m = mn;
     }
+    {
+        float smax = 0.f;
+        pv_score_track(smax, m);       // after the merge every lane holds the row's maximum
+        pv_score_commit(smax, flag);
+    }
     if (g == 0 && act) {
         const float inv = 1.0f / l;
         u32x4 r;
@@ -905,26 +918,27 @@ __global__ __launch_bounds__(256) void pv_attn_rows_kernel(const uint16_t* __res
 
 template <int DH>
 static int pv_launch_attn_rows(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B, int S, int nq,
-                               int H, hipStream_t stream) {
+                               int H, uint32_t* flag, hipStream_t stream) {
     const int64_t total = B * H * nq;
-    PV_LAUNCH(pv_attn_rows_kernel<DH>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, q, ldq, kv, ldkv, out, ldo, S, H, nq, total);
+    PV_LAUNCH(pv_attn_rows_kernel<DH>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, q, ldq, kv, ldkv, out, ldo, S, H, nq, total, flag);
     return pv_check_launch();
 }
 
 extern "C" int pv_attention_rows_bf16(const uint16_t* q, int64_t ldq, const uint16_t* kv, int64_t ldkv, uint16_t* out, int64_t ldo, int64_t B,
-                                      int64_t S, int64_t nq, int64_t H, int64_t dh, void* stream) {
-    if (!q || !kv || !out || B <= 0 || S <= 0 || nq <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+                                      int64_t S, int64_t nq, int64_t H, int64_t dh, uint32_t* range_flag, void* stream) {
+    if (!q || !kv || !out || B <= 0 || S <= 0 || nq <= 0 || H <= 0 || dh <= 0 || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
+    uint32_t* const flag = range_flag;
     if (((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)out & 15) || (ldq & 7) || (ldkv & 7) || (ldo & 7)) return PV_ERR_INVALID_ARG;
     if (ldq < H * dh || ldo < H * dh || ldkv < 2 * H * dh) return PV_ERR_INVALID_ARG;
     if (B * H * nq > 0x7fffffffLL * 4 || S > 0x3fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
-        case 32: return pv_launch_attn_rows<32>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
-        case 48: return pv_launch_attn_rows<48>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
-        case 64: return pv_launch_attn_rows<64>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
-        case 80: return pv_launch_attn_rows<80>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
-        case 96: return pv_launch_attn_rows<96>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
-        case 128: return pv_launch_attn_rows<128>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, s);
+        case 32: return pv_launch_attn_rows<32>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
+        case 48: return pv_launch_attn_rows<48>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
+        case 64: return pv_launch_attn_rows<64>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
+        case 80: return pv_launch_attn_rows<80>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
+        case 96: return pv_launch_attn_rows<96>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
+        case 128: return pv_launch_attn_rows<128>(q, ldq, kv, ldkv, out, ldo, B, (int)S, (int)nq, (int)H, flag, s);
         default: return PV_ERR_UNSUPPORTED;
     }
 }
@@ -1092,19 +1106,20 @@ extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B
     }
 }
 
-extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
+extern "C" int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
+    uint32_t* const flag = range_flag;
     if (B * H > 0x7fffffff || S > 0x3fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     switch (dh) {
-        case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, s);
-        case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, s);
-        case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, s);
+        case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, flag, s);
+        case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, flag, s);
+        case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, flag, s);
         // wider heads (ViT-H: 80, 96, 128): the streaming kernel for every sequence length
-        case 80: return pv_launch_attn_stream<80>(qkv, out, B, (int)S, (int)H, s);
-        case 96: return pv_launch_attn_stream<96>(qkv, out, B, (int)S, (int)H, s);
-        case 128: return pv_launch_attn_stream<128>(qkv, out, B, (int)S, (int)H, s);
+        case 80: return pv_launch_attn_stream<80>(qkv, out, B, (int)S, (int)H, flag, s);
+        case 96: return pv_launch_attn_stream<96>(qkv, out, B, (int)S, (int)H, flag, s);
+        case 128: return pv_launch_attn_stream<128>(qkv, out, B, (int)S, (int)H, flag, s);
         default: return PV_ERR_UNSUPPORTED;
     }
 }

@@ -70,6 +70,22 @@ __device__ __forceinline__ void pv_range_commit(float m, uint32_t* flag) {
 __device__ __forceinline__ void pv_range_track(float&, float, float) {}
 __device__ __forceinline__ void pv_range_commit(float, uint32_t*) {}
 #endif
+// Attention-logit guard (ABI v7, bit 4 of the same flag word).  The error the 16-bit rounding of q and k leaves in a score grows with
+// the score: delta_s ~ 2^-11 * sqrt(2) * |s| / sqrt(d_eff), and softmax turns it into a RELATIVE error of the probabilities of the
+// keys that matter.  On Gaussian q, k (S = 197, d = 64) the attention output's relative error is 3.6e-4 at max|s| = 5, 8.6e-4 at 40,
+// 1.1e-3 at 73, 1.6e-3 at 147 (fp16 operands) - beyond PV_SCORE_LIMIT the fp16 path cannot promise BASELINE's
+// 1e-3, so the attention kernels of the fp16 build OR 4 into the flag when the magnitude of a row's largest score exceeds it, and the
+// caller repeats the forward in a mode that keeps q, k in fp32 (engine mode "auto" -> "bf16x3").  One v_max per query tile.
+#define PV_SCORE_LIMIT 32.0f
+#ifdef PV_OPERAND_F16
+__device__ __forceinline__ void pv_score_track(float& smax, float row_max) { smax = __builtin_fmaxf(smax, __builtin_fabsf(row_max)); }
+__device__ __forceinline__ void pv_score_commit(float smax, uint32_t* flag) {
+    if (flag != nullptr && !(smax <= PV_SCORE_LIMIT)) atomicOr(flag, 4u);
+}
+#else
+__device__ __forceinline__ void pv_score_track(float&, float) {}
+__device__ __forceinline__ void pv_score_commit(float, uint32_t*) {}
+#endif
 __device__ __forceinline__ uint32_t pv_pack_bf16x2_tracked(float lo, float hi, float& m) {
     pv_range_track(m, lo, hi);
     return pv_pack_bf16x2(lo, hi);

@@ -723,9 +723,15 @@ extern "C" int pv_masked_residual(const float* x, const uint16_t* u, const float
     return pv_check_launch();
 }
 
-// LayerNorm folding: per-row (mean, rstd) from the (sum, sum of squares) partials the producer GEMM wrote per column tile
+// LayerNorm folding: per-row (mean, rstd) from the (sum, sum of squares) partials the producer GEMM wrote per column tile.
+// Guard (ABI v7, bit 2 of the operand-range flag): folding rounds the RAW row to 16 bits instead of the normalised one, so a row whose
+// mean is large against its spread loses the spread - the operand noise of the consumer GEMM grows by sqrt(1 + (mean / std)^2), and
+// E[x^2] - mean^2 itself cancels in fp32 beyond mean / std ~ 1e3.  Rows with |mean| * rstd > PV_FOLD_MEAN_LIMIT raise the flag and the
+// caller repeats the forward with the LayerNorm applied before the rounding (engine.run_guarded).
+#define PV_FOLD_MEAN_LIMIT 1.0f
 __global__ __launch_bounds__(256) void pv_rowstat_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int tiles, int64_t rows,
-                                                                  float invD, float eps) {
+                                                                  float invD, float eps, uint32_t* flag) {
+    bool risky = false;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
         float s = 0.f, q = 0.f;
         for (int t = 0; t < tiles; ++t) {
@@ -734,15 +740,18 @@ __global__ __launch_bounds__(256) void pv_rowstat_finalize_kernel(const float* _
         }
         const float mean = s * invD;
         const float var = fmaxf(q * invD - mean * mean, 0.f);
-        *reinterpret_cast<float2*>(stat + 2 * r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+        const float rstd = 1.0f / sqrtf(var + eps);
+        *reinterpret_cast<float2*>(stat + 2 * r) = make_float2(mean, rstd);
+        risky |= !(fabsf(mean) * rstd <= PV_FOLD_MEAN_LIMIT);
     }
+    if (flag != nullptr && risky) atomicOr(flag, 2u);
 }
 
-extern "C" int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, void* stream) {
+extern "C" int pv_rowstat_finalize(const float* partials, float* stat, int64_t tiles, int64_t rows, int64_t D, float eps, uint32_t* range_flag, void* stream) {
     if (!partials || !stat || tiles <= 0 || rows <= 0 || D <= 0) return PV_ERR_INVALID_ARG;
-    if (((uintptr_t)partials & 7) || ((uintptr_t)stat & 7)) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)partials & 7) || ((uintptr_t)stat & 7) || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
     PV_LAUNCH(pv_rowstat_finalize_kernel, dim3(pv_stream_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, partials, stat, (int)tiles, rows,
-              1.0f / (float)D, eps);
+              1.0f / (float)D, eps, range_flag);
     return pv_check_launch();
 }
 

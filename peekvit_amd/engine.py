@@ -29,11 +29,15 @@ from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_
 # Operand precision of the MFMA products:
 #   "auto"   (default) INFERENCE runs on IEEE fp16 operands (libpeekvit_hip_f16.so: same kernels, same MFMA rate, 2^-11 instead
 #            of 2^-8 operand rounding, fp32 accumulate): 5e-4 relative logits error = inside BASELINE's 1e-3 contract at the
-#            speed of bf16 - behind an operand-range GUARD: fp16 overflows above 65504 where bf16 would not, so every forward
-#            carries a device flag that the kernels producing data-dependent operands raise (include/peekvit_hip.h range_flag),
-#            weights / LayerNorm bounds are checked once per parameter version, and a forward that trips either is REPEATED on
-#            bf16 operands (warning once).  TRAINING (autograd recording) runs on bf16 operands: fp16 gradients would need loss
-#            scaling.
+#            speed of bf16 - behind GUARDS for everything fp16 operands cannot carry inside that contract:
+#            a device flag word that the kernels raise - bit 1: a data-dependent 16-bit value overflowed (|v| > 65504: QKV / GELU
+#            epilogues, patch gather, x16 copies); bit 2: a row handed to a folded LayerNorm has a mean large against its spread
+#            (pv_rowstat_finalize); bit 4: an attention score beyond 32 (the softmax amplifies the rounding of q and k) - and host
+#            checks once per parameter version (weights finite and not in fp16's subnormal range, LayerNorm output bound).  A forward
+#            that trips a guard is REPEATED: with folding off if that is all that tripped, otherwise in mode "bf16x3" (6e-6 from the
+#            reference) - never returned from the arithmetic that tripped, and never repeated on plain bf16 operands (round 2 did:
+#            4e-3, outside the contract it was guarding).  TRAINING (autograd recording) runs on bf16 operands: fp16 gradients would
+#            need loss scaling.
 #   "bf16"   bf16 operands, fp32 accumulate: 4e-3 relative logits error vs the fp32 reference at random init (outside 1e-3)
 #   "f16"    fp16 operands unconditionally (no guard, no fallback): for A/B measurements
 #   "bf16x3" every GEMM operand split v = hi + lo and concatenated along K ([a_hi|a_lo|a_hi] . [w_hi|w_hi|w_lo]^T on the same
@@ -95,7 +99,7 @@ def on_device(t: torch.Tensor):
 _flags: Dict[tuple, torch.Tensor] = {}
 _region = threading.local()
 _warned = set()
-fallback_count = 0          # forwards repeated on bf16 operands because the fp16 range guard tripped (tests / bench read it)
+fallback_count = 0          # forwards repeated in FALLBACK_MODE because an fp16 guard tripped (tests / bench read it)
 
 
 def range_flag_for(device) -> torch.Tensor:
@@ -150,40 +154,111 @@ def forward_split(x: torch.Tensor, body):
     return torch.cat(outs, dim=0)
 
 
+class GuardState:
+    """What mode "auto" has learnt about one module (kept on the module as the plain attribute `_pv_guard`).
+    unsafe   a PARAMETER-derived bound does not fit fp16 (weights / LayerNorm output bound / weights that lose their small elements to
+             fp16's subnormal range), or the data-dependent guard tripped on three forwards in a row: go straight to the fallback mode
+    no_fold  a row mean large against its spread was seen: LayerNorm folding stays off for this module (fp16 operands otherwise)
+    gen      the optimizer-step generation the verdicts were made for; an optimizer step or load_state_dict() resets them"""
+    __slots__ = ("unsafe", "no_fold", "trips", "gen")
+
+    def __init__(self):
+        self.unsafe, self.no_fold, self.trips, self.gen = False, False, 0, _opt_generation
+
+
+def guard_state(owner: nn.Module) -> GuardState:
+    st = getattr(owner, "_pv_guard", None)
+    if st is None or st.gen != _opt_generation:
+        st = GuardState()
+        object.__setattr__(owner, "_pv_guard", st)
+    return st
+
+
+def reset_guard(owner: nn.Module, *_):
+    """Forget what mode "auto" concluded about `owner` (its parameters were replaced: load_state_dict post-hook of the model classes)."""
+    if getattr(owner, "_pv_guard", None) is not None:
+        object.__setattr__(owner, "_pv_guard", None)
+
+
+# The mode a guarded forward is REPEATED in when fp16 operands cannot promise BASELINE's tolerance: split bf16 operands (hi + lo, three
+# MFMA products) with q | k | v and the attention core in fp32 - 6e-6 from the reference on the golden models, ~3x the GEMM time.  Round 2
+# repeated on plain bf16 operands, which is 4-6e-3 from the reference: outside the contract it was guarding.
+FALLBACK_MODE = "bf16x3"
+fold_fallback_count = 0     # forwards repeated with LayerNorm folding off (still fp16 operands)
+
+# flag bits written by the kernels (include/peekvit_hip.h): 1 a 16-bit value overflowed fp16, 2 a folded row's mean is large against its
+# spread, 4 an attention score beyond PV_SCORE_LIMIT
+_FLAG_FOLD = 2
+
+
+def _run_fallback(fn):
+    try:
+        with precision(FALLBACK_MODE):
+            return fn()
+    except PeekvitHipError as e:          # a shape the split-operand kernels do not take (head dim outside {32, 48, 64}, ...)
+        _warn_once("fallback-shape", f"peekvit_amd: the {FALLBACK_MODE} fallback is not available for this model ({e}); this forward runs "
+                                     "on bf16 operands: ~4e-3 relative operand-rounding error, OUTSIDE the 1e-3 contract")
+        with precision("bf16"):
+            return fn()
+
+
 def run_guarded(owner: nn.Module, x: torch.Tensor, fn):
     """Run `fn()` (a sequence of C-ABI launches producing the result for input `x`) under the current precision mode.
 
-    Mode "auto": fp16 operands behind the range guard, repeated on bf16 operands when the guard trips (module docstring above).
-    Nested calls (a block inside a model forward) run inside the outer region.  Reading the flag synchronises the host with the
-    stream once per guarded forward; under stream capture (peekvit_amd.graph) the check is left to the replayer."""
-    global fallback_count
+    Mode "auto" = the fastest arithmetic that stays inside BASELINE's 1e-3: fp16 operands behind the guards (module docstring above);
+    when a guard trips the forward is REPEATED - with LayerNorm folding off if only the fold guard tripped (bit 2), in FALLBACK_MODE
+    otherwise - and never returned from the mode that tripped.  Nested calls (a block inside a model forward) run inside the outer
+    region.  Reading the flag synchronises the host with the stream once per guarded forward; under stream capture
+    (peekvit_amd.graph) the check is left to the replayer."""
+    global fallback_count, fold_fallback_count
     with on_device(x):
         if _mode() != "auto" or getattr(_region, "active", False):
             return fn()
         _region.active = True
         try:
-            if not getattr(owner, "_pv_f16_unsafe", False):
+            st = guard_state(owner)
+            if not st.unsafe:
                 flag = range_flag_for(x.device)
-                flag.zero_()
-                ops.set_range_flag(flag)
-                out = None
-                try:
-                    with precision("f16"):
-                        out = fn()
-                except F16RangeError as e:
-                    object.__setattr__(owner, "_pv_f16_unsafe", True)
-                    _warn_once(f"param:{id(owner)}", f"peekvit_amd: {e}; this module runs on bf16 operands from now on "
-                                                     "(logits then carry ~4e-3 relative operand-rounding error)")
-                finally:
-                    ops.set_range_flag(None)
-                if out is not None:
-                    if torch.cuda.is_current_stream_capturing() or int(flag.item()) == 0:
+                for attempt in range(2):
+                    flag.zero_()
+                    ops.set_range_flag(flag)
+                    _region.no_fold = st.no_fold
+                    out = None
+                    try:
+                        with precision("f16"):
+                            out = fn()
+                    except F16RangeError as e:
+                        st.unsafe = True
+                        _warn_once(f"param:{id(owner)}", f"peekvit_amd: {e}; this module runs in the {FALLBACK_MODE} mode from now on "
+                                                         "(split bf16 operands, fp32 attention: inside the 1e-3 contract at ~3x the GEMM time)")
+                    finally:
+                        ops.set_range_flag(None)
+                        _region.no_fold = False
+                    if out is None:
+                        break
+                    if torch.cuda.is_current_stream_capturing():
                         return out
-                    _warn_once("data", "peekvit_amd: an activation left the fp16 operand range (|v| > 65504); this forward was "
-                                       "repeated on bf16 operands (~4e-3 relative operand-rounding error instead of ~5e-4)")
+                    bits = int(flag.item())
+                    if bits == 0:
+                        st.trips = 0
+                        return out
+                    if bits == _FLAG_FOLD and not st.no_fold:
+                        # only the fold guard: the same forward again with the LayerNorm applied BEFORE the 16-bit rounding
+                        st.no_fold = True
+                        fold_fallback_count += 1
+                        _warn_once("fold", "peekvit_amd: a token row's mean is large against its spread (|mean| * rstd > 1): LayerNorm folding is "
+                                           "switched off for this module (the raw row would lose its spread in 16 bits)")
+                        continue
+                    st.trips += 1
+                    _warn_once("data", "peekvit_amd: an activation left what fp16 operands can carry inside the 1e-3 contract (|v| > 65504, or an "
+                                       f"attention score beyond 32); this forward was repeated in the {FALLBACK_MODE} mode")
+                    if st.trips >= 3:
+                        st.unsafe = True
+                        _warn_once(f"sticky:{id(owner)}", f"peekvit_amd: the fp16 guard tripped on three forwards in a row; this module runs in the "
+                                                          f"{FALLBACK_MODE} mode from now on (engine.reset_guard(module) to try fp16 operands again)")
+                    break
                 fallback_count += 1
-            with precision("bf16"):
-                return fn()
+            return _run_fallback(fn)
         finally:
             _region.active = False
 
@@ -319,6 +394,22 @@ def pver(p: torch.Tensor) -> tuple:
     return (p._version, _opt_generation if p.requires_grad else 0)
 
 
+def _check_f16_cast(src: torch.Tensor, w16: torch.Tensor):
+    """fp16 copy of a weight matrix: it must be finite (|w| <= 65504) and no output row / input column may lose more than 1e-3 of its
+    norm to the rounding.  Normal-range rounding costs <= 4.9e-4 per element; a row or column that sits in fp16's SUBNORMAL range
+    (|w| < 6.1e-5: absolute spacing 6e-8) loses far more, and a later layer can scale the damage back up (a small-init / layer-scale
+    channel followed by a large gain).  Small elements NEXT TO large ones in the same row and column are harmless - their absolute
+    error is 3e-8 against products of ordinary size - which is why the test is on norms, not on elements."""
+    if not bool(torch.isfinite(w16).all()):
+        raise F16RangeError("a weight does not fit the fp16 operand range (|w| > 65504 or non-finite)")
+    with torch.no_grad():
+        d2 = (w16.float() - src).square()
+        s2 = src.square()
+        bad = bool(((d2.sum(1) > 1e-6 * s2.sum(1)) .any() | (d2.sum(0) > 1e-6 * s2.sum(0)).any()).item())
+    if bad:
+        raise F16RangeError("a weight row / column lies in fp16's subnormal range (it would lose more than 1e-3 of its norm)")
+
+
 def bf16_weight(p: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a 2-D (or conv 4-D, viewed [out, -1]) fp32 parameter, refreshed when it changes.  The cast is a launch on the
     current stream: a hit from ANOTHER stream (forward_split) first waits for the event recorded behind that cast."""
@@ -339,8 +430,8 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
         src = src.contiguous()
     with torch.inference_mode(False):
         w = ops.cast_bf16(src.view(src.shape[0], -1))
-    if _lib.OPERAND == "f16" and not bool(torch.isfinite(w).all()):      # once per parameter version
-        raise F16RangeError("a weight does not fit the fp16 operand range (|w| > 65504 or non-finite)")
+    if _lib.OPERAND == "f16":                                            # once per parameter version
+        _check_f16_cast(src.view(src.shape[0], -1), w)
     ev = None
     if _STREAMS > 1 and not torch.cuda.is_current_stream_capturing():
         ev = (torch.cuda.current_stream(p.device).cuda_stream, torch.cuda.Event())
@@ -434,7 +525,10 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
         return ent[1]
     with torch.inference_mode(False), torch.no_grad():
         wf = w.detach().float()
-        wg = ops.cast_bf16((wf * ln.weight.detach().float()).contiguous())
+        wsrc = (wf * ln.weight.detach().float()).contiguous()
+        wg = ops.cast_bf16(wsrc)
+        if _lib.OPERAND == "f16":                       # the folded weights are operands like any other: same check as bf16_weight
+            _check_f16_cast(wsrc, wg)
         c1 = wg.float().sum(1).contiguous()
         c2 = (wf @ ln.bias.detach().float() + (b.detach().float() if b is not None else 0.0)).contiguous()
     _foldcache[key] = (ver, (wg, c1, c2))
@@ -444,6 +538,8 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
 def _fold_ok(R: int, D: int, M: int) -> bool:
     """Folding needs the 256-row tile kernel for all four token GEMMs (include/peekvit_hip.h): enough rows, 128-multiples."""
     if not (_FOLD_LN and _mode() in ("bf16", "f16") and D % 128 == 0 and M % 128 == 0) or _ln_fusable(D, D):
+        return False
+    if getattr(_region, "no_fold", False):          # the fold guard tripped for this module (run_guarded)
         return False
     key = (R, D, M, _lib.OPERAND)
     ok = _foldok_cache.get(key)

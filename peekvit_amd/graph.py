@@ -20,7 +20,7 @@ class GraphedForward:
     (clone it if it must survive the next call).  The graph owns its scratch: warm-up and capture draw from a private workspace
     arena, so a later eager forward that grows the shared arena cannot free memory the captured nodes point at.  Precision mode
     "auto": the capture is the fp16-operand forward incl. the zeroing of the range flag; every replay reads the flag and a
-    forward that tripped it is repeated eagerly (on bf16 operands)."""
+    forward that tripped it is repeated eagerly (engine.run_guarded: folding off or the bf16x3 mode, whichever the flag asks for)."""
 
     def __init__(self, model: torch.nn.Module, example: torch.Tensor, warmup: int = 2):
         assert example.is_cuda and not model.training, "GraphedForward needs an eval-mode model and a GPU tensor"

@@ -128,6 +128,8 @@ class _ViTBase(nn.Module):
         fan_in = 3 * self.patch_size * self.patch_size
         nn.init.trunc_normal_(self.conv_proj.weight, std=math.sqrt(1 / fan_in))
         nn.init.zeros_(self.conv_proj.bias)
+        # what precision mode "auto" has concluded about this model's parameters (engine.GuardState) does not outlive them
+        self.register_load_state_dict_post_hook(engine.reset_guard)
 
     def _check_image(self, x: torch.Tensor):
         # fp32 NCHW (the reference's contract) or, MI355X path only, the raw uint8 NHWC image (normalisation fused in-kernel)

@@ -226,7 +226,7 @@ def rowstat_finalize(partials: torch.Tensor, D: int, eps: float, out: Optional[t
     if out is None:
         out = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
     with _timed("pv_rowstat_finalize", partials.device, 0.0, 8.0 * (T + 1) * rows):
-        check(_lib.load().pv_rowstat_finalize(_ptr(partials), _ptr(out), T, rows, D, float(eps), _stream(partials)), "pv_rowstat_finalize")
+        check(_lib.load().pv_rowstat_finalize(_ptr(partials), _ptr(out), T, rows, D, float(eps), _flag(partials.device), _stream(partials)), "pv_rowstat_finalize")
     _count()
     return out
 
@@ -249,7 +249,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, part: torch.Tensor, ksplit: int, t
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
     with _timed("pv_attention_bf16", qkv.device, 4.0 * B * H * S * S * dh, 8.0 * B * S * H * dh):
-        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_bf16")
+        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _flag(qkv.device), _stream(qkv)), "pv_attention_bf16")
     _count()
     return out
 
@@ -264,7 +264,7 @@ def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int,
         raise _lib.PeekvitHipError("attention_rows: shape mismatch")
     with _timed("pv_attention_rows_bf16", q.device, 4.0 * B * H * nq * S * dh, 4.0 * B * S * H * dh + 4.0 * B * nq * H * dh):
         check(_lib.load().pv_attention_rows_bf16(_ptr(q), q.stride(0), _ptr(kv), kv.stride(0), _ptr(out), out.stride(0),
-                                                 B, S, nq, H, dh, _stream(q)), "pv_attention_rows_bf16")
+                                                 B, S, nq, H, dh, _flag(q.device), _stream(q)), "pv_attention_rows_bf16")
     _count()
     return out
 

@@ -160,6 +160,53 @@ def synth_state_dict(cfg: dict, variant: str = "vit", seed: int = 0) -> Dict[str
             for name, shape, kind, scale, shift in state_dict_spec(cfg, variant)}
 
 
+# E[10^(-12 u)], u ~ U[0, 1): mean square of a log-uniform magnitude over six decades
+_LOGU6_MS = (1.0 - 1e-12) / (12.0 * math.log(10.0))
+
+
+def hostile_state_dict(cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
+    """The plain-ViT synthetic state dict made numerically HOSTILE to 16-bit operands (round 3, tests/golden/hostile.npz), still a pure
+    function of (name, seed) and bf16-representable:
+      * every weight MATRIX (conv_proj, in-proj, out-proj, fc1, fc2, head) keeps its signs and its overall RMS but draws its
+        magnitudes log-uniformly over six decades, |w| = c * 10^(-6u), u ~ U[0,1): a third of the elements sit below fp16's smallest
+        normal number relative to the largest ones;
+      * three channels of every LayerNorm gain and four rows of every fc1 are multiplied by 100 (outlier channels);
+      * one token is massive: positional-embedding row 5 is multiplied by 5e4 (values ~ N(0, 1e3)), so that token's residual stream
+        is three orders of magnitude above its neighbours' through the whole encoder."""
+    sd = synth_state_dict(cfg, "vit", seed)
+    D = cfg["hidden_dim"]
+    out = {}
+    for name, w in sd.items():
+        v = w.astype(np.float64)
+        if w.ndim >= 2 and name not in ("class_tokens", "register_tokens", "encoder.pos_embedding"):
+            u = hash_uniform("hostile/" + name, w.size, seed).reshape(w.shape)
+            rms = math.sqrt(float(np.mean(v * v)))
+            v = np.sign(v) * (10.0 ** (-6.0 * u)) * (rms / math.sqrt(_LOGU6_MS))
+            if name.endswith("mlp.fc1.weight"):
+                v[[1, 50, 101, v.shape[0] - 3]] *= 100.0
+        elif name.endswith(("ln_1.weight", "ln_2.weight", "encoder.ln.weight")):
+            v[[3, 77 % D, D - 5]] *= 100.0
+        elif name == "encoder.pos_embedding":
+            v[0, 5] *= 5e4
+        out[name] = round_to_bf16(v.astype(np.float32))
+    return out
+
+
+def hostile_variants(cfg: dict, seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
+    """name -> state dict: the full hostile set and its ingredients one at a time (tests/golden/hostile.npz holds the reference's outputs)."""
+    base = synth_state_dict(cfg, "vit", seed)
+    host = hostile_state_dict(cfg, seed)
+    is_mat = lambda k, v: v.ndim >= 2 and k not in ("class_tokens", "register_tokens", "encoder.pos_embedding")
+    logu = {k: (host[k].copy() if is_mat(k, v) else v) for k, v in base.items()}
+    for k in logu:
+        if k.endswith("mlp.fc1.weight"):
+            rows = [1, 50, 101, logu[k].shape[0] - 3]
+            logu[k][rows] = round_to_bf16(logu[k][rows] / 100.0)                 # the magnitudes alone, without the x100 rows
+    gains = {k: (host[k] if k.endswith(("ln_1.weight", "ln_2.weight", "encoder.ln.weight")) else v) for k, v in base.items()}
+    massive = dict(base, **{"encoder.pos_embedding": host["encoder.pos_embedding"]})
+    return {"hostile": host, "loguniform": logu, "ln_gain": gains, "massive_token": massive}
+
+
 def synth_images(batch: int, image_size: int, seed: int = 0, name: str = "images") -> np.ndarray:
     """[B,3,R,R] fp32 ~ N(0,1), bf16-representable (ImageNet-normalised images are ~zero-mean/unit-var)."""
     return tensor(f"{name}/{image_size}", (batch, 3, image_size, image_size), "normal", 1.0, 0.0, seed)

@@ -60,6 +60,39 @@ for tag, name, gb in [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_mic
         out["residualvit"][f"{tag}/{b}"] = {"logits_rel_l2": rel_l2(logits, ref) if np.linalg.norm(ref) > 0 else None,
                                             "max_mask_error": float(np.abs(masks - gr[f"{tag}_b{b}_masks"]).max())}
         print(tag, b, out["residualvit"][f"{tag}/{b}"], flush=True)
+# hostile weights (tests/golden/hostile.npz): mode auto vs unguarded fp16 vs the fallback mode, and which guard bits the forward raised
+import warnings
+from peekvit_amd import ops
+from peekvit_amd.models.vit import VisionTransformer
+gh = np.load(os.path.join(GOLDEN, "hostile.npz"))
+out["hostile"] = {}
+for name, variant in [("vit_tiny", "loguniform"), ("vit_tiny", "massive_token"), ("vit_tiny", "ln_gain"), ("vit_tiny", "hostile"),
+                      ("vit_b_16", "loguniform"), ("vit_b_16", "hostile")]:
+    cfg = synth.MODEL_CONFIGS[name]
+    m = VisionTransformer(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.hostile_variants(cfg)[variant].items()})
+    m = m.eval().to(DEV)
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    ref = gh[f"{name}/{variant}/logits"]
+    row = {}
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n0 = engine.fallback_count
+        row["auto_rel_l2"] = rel_l2(m(x).cpu().numpy(), ref)
+        row["auto_repeated_in_fallback_mode"] = engine.fallback_count - n0
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.set_range_flag(flag)
+        try:
+            with engine.precision("f16"):
+                row["unguarded_f16_rel_l2"] = rel_l2(m(x).cpu().numpy(), ref)
+        finally:
+            ops.set_range_flag(None)
+        row["guard_bits_raised_by_the_f16_forward"] = int(flag.item())
+        for mode in ("bf16", "bf16x3"):
+            with engine.precision(mode):
+                row[mode + "_rel_l2"] = rel_l2(m(x).cpu().numpy(), ref)
+    out["hostile"][f"{name}/{variant}"] = row
+    print(name, variant, row, flush=True)
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_observed.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)

@@ -19,12 +19,12 @@ hip = C.CDLL("libamdhip64.so")
 sym = C.c_void_p(); size = C.c_size_t()
 # simpler: the kernel reads d_pv_adbg; write it with hipMemcpyToSymbol through the library's own symbol address
 addr = C.c_void_p.in_dll(lib, "d_pv_adbg") if False else None
-lib.pv_attention_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+lib.pv_attention_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
 lib.pv_debug_set_attn_stamp_buffer.argtypes = [C.c_void_p]
 lib.pv_debug_set_attn_stamp_buffer(dbg.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(3):
-    assert lib.pv_attention_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, dh, st) == 0
+    assert lib.pv_attention_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, dh, None, st) == 0
 torch.cuda.synchronize()
 d = dbg.view(B * H, 4, 8).cpu().double()
 for w in range(4):
