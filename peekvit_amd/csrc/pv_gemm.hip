@@ -411,6 +411,10 @@ static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
 //   WAR  a slot last read in phase q is free from interval 2q+2 on -> restaging in phase q+1 is safe for both groups;
 //   RAW  vmcnt(4) in P4 retires everything but the two youngest half-tiles (A0/A1 of t+2): all of tile t+1 has
 //        landed for THIS thread; after one more barrier pair it has for every thread -> first read in P1 of t+1.
+// (Measured, round 3: the same K-tile in TWO phases of 32 MFMAs - Q1 = all reads but B(n1) + both B halves staged, Q2 = B(n1) + both A
+//  halves staged; half the barriers, same slots and hazards, bit-identical - is within +-1.3 % on every token GEMM
+//  (profiles/r03_gemm_two_phase_ab.json: fc1 +1.0 %, fc2 +0.7 %, QKV -0.5 %, out-proj -0.7 %): the ~250 cycles per K-tile the barriers
+//  cost come back as clock, not as time, like every other saving inside the K loop since round 1.  Not kept.)
 // ------------------------------------------------------------------------------------------------
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_HALF = 128 * G2_BK * 2;     // 16 KiB half-tile slot
@@ -582,13 +586,12 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                                          (__attribute__((address_space(3))) void*)(smem + FOLD_BASE + 2048 + wid * 256), 4, 0, 0);
     }
     // tile 0 has landed for this thread; the A halves of tile 1 (4 operations), the table and the fold constants stay in flight
-    if (fold_dma) {
-        if (NTAB == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        if (NTAB == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (NTAB == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    {
+        const int inflight = 4 + NTAB + (fold_dma ? 2 : 0);      // workgroup-uniform; the immediate must be literal
+        if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (inflight == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (inflight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1008,6 +1011,12 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 #endif
 }
 
+// (Measured dead end, round 3 - again: the same tile function in a PERSISTENT launch, one workgroup per CU walking its XCD-contiguous share
+// of the list behind one barrier per tile, to save the 1.0 - 1.4 us the dispatcher leaves between two workgroups of a CU.  Bit-identical
+// and SLOWER on every token GEMM with loads at a tile's start: QKV + fold 1.428 vs 1.357 ms, out-proj 0.904 vs 0.829, fc2 1.911 vs 1.837,
+// fc1 + fold 2.056 vs 1.999 (profiles/r03_gemm_epilogue_persist_ab.json, "cur" = persistent).  The counter behind s_waitcnt vmcnt is in
+// order: the next tile's first wait for its LDS-DMA also waits for the previous tile's 128 - 384 KiB of stores, which a fresh workgroup
+// never has to - the hardware hand-off lets them drain under the successor's prologue.  Removed.)
 template <int EPI>
 __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -5,8 +5,10 @@
 
 Variants (all fp16-operand builds = the default inference library):
   r2      round 2's sources (git show <rev>: ten-instruction GELU, one-pass epilogue, GELU table staged first)
-  nopipe  this round's sources with -DPV_EPI_PIPE=0: six-instruction GELU + table staged after the first K tiles, one-pass epilogue
-  cur     this round's shipped library: the same + the four-pass epilogue whose stores drain under the next pass's arithmetic
+  nopipe  this round's sources with -DPV_EPI_PIPE=0: short GELU + table staged after the first K tiles, one-pass epilogue
+  cur     this round's shipped library: the software-pipelined 16-bit epilogue
+(profiles/r03_gemm_epilogue_persist_ab.json additionally holds a persistent-launch build, "cur" there, against "nopersist" = what ships:
+ slower, removed - pv_gemm.hip, comment above pv_gemm256_kernel)
 Interleaved rounds in ONE process (cdna_hip_programming.md rule 24); reports median and minimum per variant and shape, checks that
 `cur` and `nopipe` agree bit for bit and that every variant is within rounding of an fp64 reference on a sample of rows.
 """
@@ -84,8 +86,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=dev).manual_seed(0)
     M = a.M
+    from peekvit_amd._lib import PV_EPI_BIAS_RES_F32
     shapes = [("qkv", 2304, 768, PV_EPI_BIAS_BF16, False), ("qkv_fold", 2304, 768, PV_EPI_BIAS_BF16, True),
-              ("fc1", 3072, 768, PV_EPI_BIAS_GELU_BF16, False), ("fc1_fold", 3072, 768, PV_EPI_BIAS_GELU_BF16, True)]
+              ("fc1", 3072, 768, PV_EPI_BIAS_GELU_BF16, False), ("fc1_fold", 3072, 768, PV_EPI_BIAS_GELU_BF16, True),
+              ("out", 768, 768, PV_EPI_BIAS_RES_F32, False), ("fc2", 768, 3072, PV_EPI_BIAS_RES_F32, False)]
     result = {"M": M, "rounds": a.rounds, "iters": a.iters, "shapes": {}}
     for name, N, K, epi, fold in shapes:
         x = torch.randn(M, K, generator=g, device=dev)
@@ -94,7 +98,11 @@ def main():
         bias = torch.randn(N, generator=g, device=dev) * 0.1
         stat = torch.stack([torch.randn(M, generator=g, device=dev) * 0.05, 1.0 + 0.1 * torch.rand(M, generator=g, device=dev)], 1).contiguous()
         c1 = W.float().sum(1).contiguous()
-        outs = {t: torch.empty((M, N), dtype=torch.float16, device=dev) for t in libs}
+        odt = torch.float32 if epi == PV_EPI_BIAS_RES_F32 else torch.float16
+        outs = {t: torch.empty((M, N), dtype=odt, device=dev) for t in libs}
+        resid = torch.randn(M, N, generator=g, device=dev) if epi == PV_EPI_BIAS_RES_F32 else None
+        x16 = {t: torch.empty((M, N), dtype=torch.float16, device=dev) for t in libs} if resid is not None else None
+        rstat = {t: torch.empty((N // 256, M, 2), dtype=torch.float32, device=dev) for t in libs} if resid is not None else None
 
         def args(out, tag):
             ga = GemmArgsV6() if tag == "r2" else GemmArgs()
@@ -107,6 +115,9 @@ def main():
                 ga.fold_stat, ga.fold_c1, ga.fold_c2 = stat.data_ptr(), c1.data_ptr(), bias.data_ptr()
             else:
                 ga.bias = bias.data_ptr()
+            if resid is not None:                  # the residual GEMMs as the folded forward runs them: + 16-bit copy + row statistics
+                ga.res, ga.ldr = resid.data_ptr(), N
+                ga.x16_out, ga.rowstat_out = x16[tag].data_ptr(), rstat[tag].data_ptr()
             return ga
 
         gargs = {t: args(outs[t], t) for t in libs}
@@ -128,6 +139,8 @@ def main():
             ref = ref + bias.double()[None]
         if epi == PV_EPI_BIAS_GELU_BF16:
             ref = ref * 0.5 * torch.erfc(-ref / 2 ** 0.5)
+        elif epi == PV_EPI_BIAS_RES_F32:
+            ref = ref + resid[rows].double()
         else:
             ref[:, :768] *= 0.125
         errs = {}
@@ -165,7 +178,7 @@ def main():
         row["elements_differing_over_relaunches"] = repeat_diff
         print(f"{name:9s} cur == nopipe bitwise: {same}; elements differing over {a.repeat} relaunches: {repeat_diff}", flush=True)
         result["shapes"][name] = row
-        del A, W, x, outs
+        del A, W, x, outs, resid, x16, rstat
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         with open(a.out, "w") as f:
