@@ -12,6 +12,10 @@ LIB = os.path.join(HERE, "libpeekvit_hip.so")
 LIB_F16 = os.path.join(HERE, "libpeekvit_hip_f16.so")      # same sources, -DPV_OPERAND_F16: fp16 operands (precision mode "f16")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# per-source extra flags.  pv_attention.hip: MFMA results in VGPRs.  hipcc otherwise puts the score / output tiles of the attention
+# kernels into AGPRs and copies every one of them out with v_accvgpr_read_b32 before the softmax can touch it - 272 of a wave's
+# 1 795 vector instructions in a kernel that is VALU-issue bound (round 3, rocprofv3 + ISA); with the flag: no copies, 116 VGPRs.
+FILE_FLAGS = {"pv_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -39,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for src in sources():
             obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
             objs[lib].append(obj)
-            cmd = [HIPCC, *FLAGS, *defs, "-c", src, "-o", obj]
+            cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *defs, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -69,7 +73,8 @@ def build_variant(tag: str, defs, force: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *defs, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src, subprocess.Popen([HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *defs, "-c", src, "-o", obj],
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

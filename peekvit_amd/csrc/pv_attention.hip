@@ -35,6 +35,14 @@ extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbo
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
+#ifndef PV_P_SHIFT
+#ifdef PV_OPERAND_F16
+#define PV_P_SHIFT 14.0f
+#else
+#define PV_P_SHIFT 0.0f
+#endif
+#endif
+
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
 __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
     constexpr int DHP = (DH + 31) / 32 * 32;
@@ -145,7 +153,6 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     PV_ASTAMP(2);
     bool v_ready = false;
 
-    float smax = 0.f;              // operand-range guard: the largest |row maximum of the scores| this lane has seen
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
         const int qt = wid + 4 * t;
@@ -177,9 +184,15 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        pv_score_track(smax, m);
-        // p = exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp per score
-        const float nm = -m * 1.44269504088896340736f;
+        pv_score_guard(m, flag);
+        // p = exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp per score.
+        // (+ PV_P_SHIFT: the probabilities are packed as p * 2^14.  The fp16 MFMA path flushes subnormal operands, and with scores spread
+        //  over ~17 units more than half of a row's p = exp(s - m) lie below fp16's smallest normal 6.1e-5 - up to 0.7 % of a row's mass;
+        //  scaled, everything down to 3.7e-9 stays normal, and the factor cancels in O / l.  Free: it rides in the FMA's addend.)
+        // Measured and NOT kept (round 3, scripts/attn_ab.py, profiles/r03_attention_ab.json): the exp argument as a packed FMA and the
+        // row sum as one more MFMA tile (P^T times a tile of ones) take 30 % of the wave's VALU instructions away and not one percent of
+        // the kernel's time - it is not VALU-bound, whatever the 54 % VALU issue utilisation suggests.
+        const float nm = -m * 1.44269504088896340736f + PV_P_SHIFT;
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -239,7 +252,6 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    pv_score_commit(smax, flag);
     PV_ASTAMP(3);
 }
 
@@ -361,11 +373,7 @@ __global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __r
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    {
-        float smax = 0.f;
-        pv_score_track(smax, m);       // the row's final maximum (every block's maximum has passed through it)
-        pv_score_commit(smax, flag);
-    }
+    pv_score_guard(m, flag);           // the row's final maximum (every block's maximum has passed through it)
     if (q0 + i16 < S) {
         const float inv = 1.0f / l;
         uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
@@ -902,11 +910,7 @@ __global__ __launch_bounds__(256) void pv_attn_rows_kernel(const uint16_t* __res
         for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], d, 64) * a2;
         m = mn;
     }
-    {
-        float smax = 0.f;
-        pv_score_track(smax, m);       // after the merge every lane holds the row's maximum
-        pv_score_commit(smax, flag);
-    }
+    pv_score_guard(m, flag);           // after the merge every lane holds the row's maximum
     if (g == 0 && act) {
         const float inv = 1.0f / l;
         u32x4 r;

@@ -77,14 +77,19 @@ __device__ __forceinline__ void pv_range_commit(float, uint32_t*) {}
 // 1e-3, so the attention kernels of the fp16 build OR 4 into the flag when the magnitude of a row's largest score exceeds it, and the
 // caller repeats the forward in a mode that keeps q, k in fp32 (engine mode "auto" -> "bf16x3").  One v_max per query tile.
 #define PV_SCORE_LIMIT 32.0f
+#ifndef PV_SCORE_GUARD
+#define PV_SCORE_GUARD 1          // 0: compiled out (A/B, scripts/attn_ab.py)
+#endif
+// A row's maximum is tested WHERE IT IS COMPUTED (one compare per query tile, an atomic only when it trips).  Round 3 first carried a
+// running maximum to the kernel's end: hipcc restructured the unrolled query-tile loop of the LDS-resident kernel around the extra
+// live value - +6 % time, and (with the 2^14 probability scale) non-finite outputs in 0.4 % of the rows, a miscompile or a latent
+// hazard that form exposed; profiles/r03_attention_ab.json.  The form below times and rounds exactly like the kernel without a guard.
 #ifdef PV_OPERAND_F16
-__device__ __forceinline__ void pv_score_track(float& smax, float row_max) { smax = __builtin_fmaxf(smax, __builtin_fabsf(row_max)); }
-__device__ __forceinline__ void pv_score_commit(float smax, uint32_t* flag) {
-    if (flag != nullptr && !(smax <= PV_SCORE_LIMIT)) atomicOr(flag, 4u);
+__device__ __forceinline__ void pv_score_guard(float row_max, uint32_t* flag) {
+    if (PV_SCORE_GUARD && flag != nullptr && !(__builtin_fabsf(row_max) <= PV_SCORE_LIMIT)) atomicOr(flag, 4u);
 }
 #else
-__device__ __forceinline__ void pv_score_track(float&, float) {}
-__device__ __forceinline__ void pv_score_commit(float, uint32_t*) {}
+__device__ __forceinline__ void pv_score_guard(float, uint32_t*) {}
 #endif
 __device__ __forceinline__ uint32_t pv_pack_bf16x2_tracked(float lo, float hi, float& m) {
     pv_range_track(m, lo, hi);
@@ -149,6 +154,21 @@ __device__ __forceinline__ float pv_reduce16_rows(const float (&v)[16], int lane
     t1 += __shfl_xor(t1, 2, 64);
     t1 += __shfl_xor(t1, 1, 64);
     return t1;                       // row ((lane >> 2) & 15)
+}
+// the same for 8 rows: v[r] (r = 0..7) per lane -> the sum over all 64 lanes of v[r], delivered to lanes 8r .. 8r+7 (4 + 2 + 1 exchanges that
+// halve the rows a lane carries, then three plain steps)
+__device__ __forceinline__ float pv_reduce8_rows(const float (&v)[8], int lane) {
+    float t4[4], t2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t4[i] = (b5 ? v[i + 4] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 4], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t2[i] = (b4 ? t4[i + 2] : t4[i]) + __shfl_xor(b4 ? t4[i] : t4[i + 2], 16, 64);
+    float t1 = (b3 ? t2[1] : t2[0]) + __shfl_xor(b3 ? t2[0] : t2[1], 8, 64);
+    t1 += __shfl_xor(t1, 4, 64);
+    t1 += __shfl_xor(t1, 2, 64);
+    t1 += __shfl_xor(t1, 1, 64);
+    return t1;                       // row ((lane >> 3) & 7)
 }
 __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll

@@ -617,7 +617,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
     const int g = lane >> 4, i16 = lane & 15;
-    if (PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16)) {
+    if (PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)) {
         // Round 3: the 16-bit epilogue as a software pipeline (in-kernel stamps of round 2's form, scripts/stamp_gemm.py: fc1 + folded
         // LayerNorm spent 18.9 k ticks here against 27.7 k in its K loop).  What was wrong, from the stamps and the ISA:
         //   - GELU ran latency-bound: hipcc kept 2 table gathers in flight per wave (256 VGPRs, all accumulators + 48 fold constants
@@ -634,7 +634,12 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // drains them.  Arithmetic per element is unchanged (bit-identical to the one-pass form, scripts/gemm_epi_ab.py).
         float vmax = 0.f;          // operand-range guard (fp16 build): largest magnitude this lane packs
         const bool fold = p.fold_stat != nullptr;
-        constexpr int FOLD_BASE = G2_LDS + (EPI == PV_EPI_BIAS_GELU_BF16 ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);
+        constexpr int FOLD_BASE = G2_LDS + (EPI != PV_EPI_BIAS_BF16 ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);
+        // PAIR (training forward of fc1): TWO output planes from the same accumulators - 32 virtual units: units 0-15 pack the raw
+        // pre-activation (plane 1 of the [M, 2N] output, saved for backward), units 16-31 its GELU (plane 0); the image regions are reused
+        // four passes later, three barriers after they were read back
+        constexpr bool PAIR2 = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+        constexpr int NU = PAIR2 ? 32 : 16;
         if (fold) {
             // x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]: the accumulators hold x16 . (gamma (.) W)^T
             f32x4 k1[2][2], k2[2][2];
@@ -670,50 +675,56 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             const int row = rb_row0 + 2 * j;
             rb_addr[j] = (uint32_t)(uintptr_t)cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4);
         }
-        f32x4 cf[2][8];            // gathered table entries of two units in flight (GELU only)
+        f32x4 cf[2][8];            // gathered table entries of two units in flight (GELU units only)
         u32x4 rb[4];               // rows read back from the image, waiting for their store slot
-        auto unit_x = [&](int n, int e) -> float { return acc[2 * (n & 1) + (e >> 2)][n >> 1][e & 3]; };
-        auto issue = [&](int n) __attribute__((always_inline)) {
-            if (EPI == PV_EPI_BIAS_GELU_BF16) {
+        // virtual unit vn: accumulator unit n = vn & 15 (16-row tile mt = n >> 1, column half u = n & 1), plane vn >> 4
+        auto unit_x = [&](int vn, int e) -> float { return acc[2 * (vn & 1) + (e >> 2)][(vn & 15) >> 1][e & 3]; };
+        auto is_gelu = [&](int vn) -> bool { return EPI == PV_EPI_BIAS_GELU_BF16 || (PAIR2 && vn >= 16); };
+        auto issue = [&](int vn) __attribute__((always_inline)) {
+            if (is_gelu(vn)) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     uint32_t b0, b1;
-                    pv_gelu_bits2(unit_x(n, e), unit_x(n, e + 1), b0, b1);
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[n & 1][e]) : "v"((b0 << 8) + tabc));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[n & 1][e + 1]) : "v"((b1 << 8) + tabc));
+                    pv_gelu_bits2(unit_x(vn, e), unit_x(vn, e + 1), b0, b1);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[vn & 1][e]) : "v"((b0 << 8) + tabc));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[vn & 1][e + 1]) : "v"((b1 << 8) + tabc));
                 }
             }
         };
-        // the lgkmcnt wait that makes unit n's gathers (and everything older: the read-back rows of the previous pass) valid.  LDS
+        // the lgkmcnt wait that makes unit vn's gathers (and everything older: the read-back rows of the previous pass) valid.  LDS
         // operations return in order, so "at most N outstanding" = all but the N youngest have completed; the values pass through the
         // statement, so no consumer can be scheduled above it.  with_rb: the read-back registers are threaded through as well (first
         // unit after a read-back).
-        auto wait_unit = [&](int n, bool next_in_flight, bool with_rb) __attribute__((always_inline)) {
-            if (EPI == PV_EPI_BIAS_GELU_BF16) {
-                f32x4(&c)[8] = cf[n & 1];
+        auto wait_unit = [&](int vn, bool next_in_flight, bool with_rb) __attribute__((always_inline)) {
+            if (is_gelu(vn)) {
+                f32x4(&c)[8] = cf[vn & 1];
                 if (next_in_flight && with_rb)
                     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                                  "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
                 else if (next_in_flight)
                     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+                else if (with_rb)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
+                                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
                 else
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
             } else if (with_rb) {
+                // (a plain unit whose successor's gathers are already in flight - unit 15 of PAIR - never carries a read-back: 15 & 3 != 0)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
             }
         };
-        auto finish = [&](int n) __attribute__((always_inline)) {
-            const int mt = n >> 1, u = n & 1;
+        auto finish = [&](int vn) __attribute__((always_inline)) {
+            const int n = vn & 15, mt = n >> 1, u = n & 1;
             float y[8];
-            if (EPI == PV_EPI_BIAS_GELU_BF16) {
+            if (is_gelu(vn)) {
                 // pv_gelu_poly for the 8 values in lock step (step by step ACROSS the values): no instruction depends on its predecessor,
                 // so the wave issues back to back (value by value, hipcc padded every dependent pair of asm steps with an s_nop)
                 float x[8];
                 pv_f32x2_t r[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    x[e] = unit_x(n, e);
-                    const f32x4 c = cf[n & 1][e];
+                    x[e] = unit_x(vn, e);
+                    const f32x4 c = cf[vn & 1][e];
                     r[e] = __builtin_elementwise_fma((pv_f32x2_t){c[2], c[3]}, (pv_f32x2_t){x[e], x[e]}, (pv_f32x2_t){c[0], c[1]});
                 }
 #pragma unroll
@@ -722,44 +733,45 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 for (int e = 0; e < 8; ++e) y[e] = pv_fma_s(x[e], y[e], r[e][0]);
             } else {
                 // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
-                const float qs = en0 + u * 32 < p.qcols ? p.qscale : 1.0f;
+                const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = unit_x(n, e) * qs;
+                for (int e = 0; e < 8; ++e) y[e] = unit_x(vn, e) * qs;
             }
             const u32x4 pk = {pv_pack_bf16x2_tracked(y[0], y[1], vmax), pv_pack_bf16x2_tracked(y[2], y[3], vmax),
                               pv_pack_bf16x2_tracked(y[4], y[5], vmax), pv_pack_bf16x2_tracked(y[6], y[7], vmax)};
             const int row = wr * 128 + mt * 16 + i16, c = wc * 8 + u * 4 + g;
             *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
         };
-        uint16_t* orow[4];         // output row of read-back slot j in pass 0; pass q is 32 rows further
+        uint16_t* orow[4];         // output row of read-back slot j in image region 0; region q is 32 rows further
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow[j] = ob + (int64_t)(m0 + rb_row0 + 2 * j) * p.ldo;
         const int64_t pass_stride = 32 * p.ldo;
-        auto store_row = [&](int q, int j) __attribute__((always_inline)) {
-            const int row = rb_row0 + 32 * q + 2 * j;
-            if (m0 + row < p.M && ocol_ok) *reinterpret_cast<u32x4*>(orow[j] + q * pass_stride) = rb[j];
+        auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // virtual pass vq: image region vq & 3, plane vq >> 2
+            const int row = rb_row0 + 32 * (vq & 3) + 2 * j;
+            uint16_t* o = orow[j] + (vq & 3) * pass_stride + ((PAIR2 && vq < 4) ? p.N : 0);
+            if (m0 + row < p.M && ocol_ok) *reinterpret_cast<u32x4*>(o) = rb[j];
         };
         issue(0);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            const int q = n >> 2;
-            if (n + 1 < 16) issue(n + 1);
-            wait_unit(n, n + 1 < 16, q > 0 && (n & 3) == 0);
-            finish(n);
-            if (q > 0) store_row(q - 1, n & 3);                     // one 1-KiB store of the previous pass per unit
-            if ((n & 3) == 3) {
+        for (int vn = 0; vn < NU; ++vn) {
+            const int vq = vn >> 2;
+            if (vn + 1 < NU) issue(vn + 1);
+            wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
+            finish(vn);
+            if (vq > 0) store_row(vq - 1, vn & 3);                  // one 1-KiB store of the previous pass per unit
+            if ((vn & 3) == 3) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's image writes (and the gathers issued before them)
-                PV_STAMP(9 + q);
+                if (vq < 4) { PV_STAMP(9 + vq); }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)      // row rb_row0 + 32 q + 2 j: the swizzle term does not depend on q -> base + immediate
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"(q * 32 * 512));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"((vq & 3) * 32 * 512));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store_row(3, j);
+        for (int j = 0; j < 4; ++j) store_row(NU / 4 - 1, j);
         pv_range_commit(vmax, p.range_flag);
     } else
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
@@ -884,102 +896,124 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // PV_EPI_GELU_GRAD_BF16: this lane's 4 columns summed over the rows its wave stores
         float vmax = 0.f;                           // operand-range guard of the x16_out copy (fp16 build)
+        // Every wave owns 16 whole rows of a pass (2 passes of 128 rows), handled as four HALF-steps of 8 rows.  Round 3: the residual /
+        // positional / pre-activation rows of half-step h+2 are requested BEFORE the stores of half-step h+1 are issued - VMEM order
+        // L0 L1 S0 L2 S1 L3 S2 S3 - because the counter behind s_waitcnt vmcnt is in order: round 2 issued L(pass 1) after S(pass 0), so the
+        // wait for pass 1's rows also waited for 192 KiB of pass 0's stores to drain, and the CU's memory path (the bound of this
+        // epilogue: 640 KiB per tile at ~28 B/clk) idled in between.  Same arithmetic per element: bit-identical outputs.
+        const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
+        const int ncol = col_ok ? n0 + lane * 4 : 0;
+        f32x4 rr[2][8];
+        float rsc[2] = {1.0f, 1.0f};                       // PV_EPI_BIAS_RES_F32 row scale: lane j (< 8) holds slot j's (loaded with the rows: never after a store)
+        auto row_of = [&](int hs, int j) -> int64_t {      // output row of slot j of half-step hs (clamped at the ragged bottom edge)
+            int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + j;
+            m = m < p.M ? m : p.M - 1;
+            if (EPI == PV_EPI_BIAS_POS_F32) { const int img = m / p.rpi, pi = m - img * p.rpi; return (int64_t)img * p.rpo + p.row_off + pi; }
+            return m;
+        };
+        auto fetch = [&](int hs) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            // every wave owns 16 whole rows of the pass: fetch their residual / positional rows first (1 KiB per instruction)
-            f32x4 rr[16];
-            int64_t orow[16];
-            float fs[16], fq[16];          // LayerNorm folding (producer): per-lane partial (sum, sum of squares) of the 16 rows
-            const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
-            const int ncol = col_ok ? n0 + lane * 4 : 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int m = m0 + ps * 128 + wid * 16 + j;
+            for (int j = 0; j < 8; ++j) {
+                int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + j;
                 m = m < p.M ? m : p.M - 1;
+                f32x4& r = rr[hs & 1][j];
                 if (EPI == PV_EPI_BIAS_F32) {
-                    orow[j] = m;
-                    rr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    r = (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved bf16 pre-activation row, 512 B per instruction
-                    orow[j] = m;
                     const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + ncol);
-                    rr[j] = (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]),
-                                    pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
+                    r = (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]), pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
-                    orow[j] = m;
-                    rr[j] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
+                    r = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
                 } else {
                     const int img = m / p.rpi, pi = m - img * p.rpi;
-                    orow[j] = (int64_t)img * p.rpo + p.row_off + pi;
-                    rr[j] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + ncol);
+                    r = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + ncol);
                 }
             }
-            if (ps == 1) __builtin_amdgcn_s_barrier();      // pass 0's image has been consumed by every wave
-            if (wr == ps) {
+            if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) {
+                int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + (lane & 7);
+                rsc[hs & 1] = p.row_scale[m < p.M ? m : p.M - 1];
+            }
+        };
+        fetch(0);
+        fetch(1);
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    const int row = mt * 16 + i16;
+        for (int hs = 0; hs < 4; ++hs) {
+            const int ps = hs >> 1;
+            if ((hs & 1) == 0) {
+                if (ps == 1) __builtin_amdgcn_s_barrier();      // pass 0's image has been consumed by every wave
+                if (wr == ps) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int c = wc * 16 + (nt >> 1) * 8 + g * 2 + (nt & 1);
-                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
+                    for (int mt = 0; mt < 8; ++mt) {
+                        const int row = mt * 16 + i16;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int c = wc * 16 + (nt >> 1) * 8 + g * 2 + (nt & 1);
+                            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
+                        }
                     }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            float fs[8], fq[8];            // LayerNorm folding (producer) / rank norms: per-lane partial (sum, sum of squares) of the 8 rows
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int row = wid * 16 + j;
+            for (int j = 0; j < 8; ++j) {
+                const int jj = (hs & 1) * 8 + j;
+                const int row = wid * 16 + jj;
+                const int64_t orow = row_of(hs, j);
                 const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((lane ^ (row & 7)) << 4));
-                float sc = 1.0f;
-                if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) sc = p.row_scale[orow[j]];
+                const f32x4 r = rr[hs & 1][j];
+                // row scale of slot j: lane j of the set holds it (one register per set instead of eight)
+                const float sc = (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale)
+                                     ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc[hs & 1]), j)) : 1.0f;
                 f32x4 o;
                 if (EPI == PV_EPI_BIAS_F32) {
                     const float qs = ncol < p.qcols ? p.qscale : 1.0f;
                     o = (f32x4){v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs};
                 } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
                     const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
-                    o = (f32x4){v[0] * pv_gelu_grad_lut(rr[j][0], tab), v[1] * pv_gelu_grad_lut(rr[j][1], tab),
-                                v[2] * pv_gelu_grad_lut(rr[j][2], tab), v[3] * pv_gelu_grad_lut(rr[j][3], tab)};
+                    o = (f32x4){v[0] * pv_gelu_grad_lut(r[0], tab), v[1] * pv_gelu_grad_lut(r[1], tab),
+                                v[2] * pv_gelu_grad_lut(r[2], tab), v[3] * pv_gelu_grad_lut(r[3], tab)};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     const float tr = p.res_scaled ? sc : 1.0f;
-                    o = (f32x4){fmaf(sc, v[0], tr * rr[j][0]), fmaf(sc, v[1], tr * rr[j][1]), fmaf(sc, v[2], tr * rr[j][2]), fmaf(sc, v[3], tr * rr[j][3])};
+                    o = (f32x4){fmaf(sc, v[0], tr * r[0]), fmaf(sc, v[1], tr * r[1]), fmaf(sc, v[2], tr * r[2]), fmaf(sc, v[3], tr * r[3])};
                 }
-                else o = (f32x4){rr[j][0] + v[0], rr[j][1] + v[1], rr[j][2] + v[2], rr[j][3] + v[3]};
-                if (m0 + ps * 128 + row < p.M && col_ok) {
+                else o = (f32x4){r[0] + v[0], r[1] + v[1], r[2] + v[2], r[3] + v[3]};
+                const bool ok = m0 + ps * 128 + row < p.M && col_ok;
+                if (ok) {
                     if (EPI == PV_EPI_GELU_GRAD_BF16) {
                         const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow[j] * p.ldo + ncol) = pk;
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + ncol) = pk;
                         csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
                     } else
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow[j] * p.ldo + ncol) = o;
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol) = o;
                 }
-                if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out) {    // (workgroup-uniform) token norms for the next block's ranking
-                    const bool ok = m0 + ps * 128 + row < p.M && col_ok;
-                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the loop
-                }
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out)      // (workgroup-uniform) token norms for the next block's ranking
+                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the half-step
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
-                    const bool ok = m0 + ps * 128 + row < p.M && col_ok;
                     if (ok)
-                        *reinterpret_cast<u32x2*>(p.x16_out + orow[j] * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
-                    // this lane's share of row j's (sum, sum of squares); the 64-lane reduction of all 16 rows follows the loop
+                        *reinterpret_cast<u32x2*>(p.x16_out + orow * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
+                    // this lane's share of the row's (sum, sum of squares); the 64-lane reduction of the 8 rows follows the half-step
                     fs[j] = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
                     fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
                 }
             }
-            if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out && !p.x16_out) {
-                const float tq = pv_reduce16_rows(fq, lane);
-                const int r_ = (lane >> 2) & 15;
-                if ((lane & 3) == 0 && m0 + ps * 128 + wid * 16 + r_ < p.M)
-                    p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + (m0 + ps * 128 + wid * 16 + r_)] = tq;
-            }
-            if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {
-                // 16 rows x 64 lanes -> 16 totals in 17 cross-lane steps per quantity (halving the rows a lane carries at every step)
-                // instead of 16 full wave reductions; lanes 4r .. 4r+3 end up with row r's totals
-                const float ts = pv_reduce16_rows(fs, lane), tq = pv_reduce16_rows(fq, lane);
-                const int r_ = (lane >> 2) & 15;
-                if ((lane & 3) == 0 && m0 + ps * 128 + wid * 16 + r_ < p.M)
-                    *reinterpret_cast<float2*>(p.rowstat_out + ((int64_t)(n0 / G2_BN) * p.M + (m0 + ps * 128 + wid * 16 + r_)) * 2) = make_float2(ts, tq);
+            // the rows of half-step hs + 2 into the slot set just consumed: requested before the NEXT half-step's stores, so the wait for
+            // them (two half-steps from now) has only this half-step's stores in front of it, long since drained
+            if (hs + 2 < 4) fetch(hs + 2);
+            {
+                // 8 rows x 64 lanes -> 8 totals in 10 cross-lane steps per quantity (halving the rows a lane carries at every exchange)
+                // instead of 8 full wave reductions; lanes 8r .. 8r+7 end up with row r's totals
+                const int r_ = (lane >> 3) & 7, mrow = m0 + ps * 128 + wid * 16 + (hs & 1) * 8 + r_;
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out && !p.x16_out) {
+                    const float tq = pv_reduce8_rows(fq, lane);
+                    if ((lane & 7) == 0 && mrow < p.M) p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + mrow] = tq;
+                }
+                if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {
+                    const float ts = pv_reduce8_rows(fs, lane), tq = pv_reduce8_rows(fq, lane);
+                    if ((lane & 7) == 0 && mrow < p.M)
+                        *reinterpret_cast<float2*>(p.rowstat_out + ((int64_t)(n0 / G2_BN) * p.M + mrow) * 2) = make_float2(ts, tq);
+                }
             }
         }
         if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) pv_range_commit(vmax, p.range_flag);
