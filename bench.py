@@ -272,7 +272,7 @@ def main():
         # HBM/fabric bytes per launch of this kernel from the committed PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r01_kernel_summary.json
         try:
-            prof = next(f for f in ("r02_kernel_summary.json", "r01_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            prof = next(f for f in ("r03_kernel_summary.json", "r02_kernel_summary.json", "r01_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             roof["traffic_source"] = "profiles/" + prof
             summ = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
             fam = [v for k, v in summ.items() if k.startswith(dom.replace("_bf16", "").replace("pv_", "pv_")) and "hbm_read_MB" in v]

@@ -97,6 +97,7 @@ def on_device(t: torch.Tensor):
 
 
 _flags: Dict[tuple, torch.Tensor] = {}
+_flags_lock = threading.Lock()
 _region = threading.local()
 _warned = set()
 fallback_count = 0          # forwards repeated in FALLBACK_MODE because an fp16 guard tripped (tests / bench read it)
@@ -106,7 +107,10 @@ def range_flag_for(device) -> torch.Tensor:
     key = (device, threading.get_ident())            # one word per device AND thread: a thread zeroes / reads only its own
     f = _flags.get(key)
     if f is None:
-        with torch.inference_mode(False):        # a buffer that outlives the call: never an inference tensor (those refuse in-place updates later)
+        with _flags_lock, torch.inference_mode(False):   # (a buffer that outlives the call: never an inference tensor - those refuse in-place updates later)
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _flags if k[1] not in alive]:      # words of threads that have exited
+                del _flags[k]
             f = _flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return f
 
@@ -263,6 +267,15 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn):
             _region.active = False
 
 
+def _evict_with(owner, cache: dict, key):
+    """Drop `cache[key]` when `owner` (the parameter / module whose id() is in the key) is collected: an id-keyed entry must not outlive
+    its object - device memory would pile up across model loads, and a recycled id could be served another object's derivative."""
+    try:
+        weakref.finalize(owner, cache.pop, key, None)
+    except TypeError:
+        pass
+
+
 _lnok: Dict[int, tuple] = {}
 
 
@@ -275,6 +288,8 @@ def _check_ln_range(ln: nn.LayerNorm):
     if ent is None or ent[0] != ver:
         D = ln.normalized_shape[0]
         bound = float(ln.weight.detach().abs().max()) * math.sqrt(D) + float(ln.bias.detach().abs().max())
+        if key not in _lnok:
+            _evict_with(ln, _lnok, key)
         ent = _lnok[key] = (ver, bound)
     if not ent[1] <= 65504.0:
         raise F16RangeError(f"a LayerNorm output bound ({ent[1]:.3g}) exceeds the fp16 range")
@@ -306,6 +321,7 @@ class _Workspace:
     _ITEMSIZE = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.float64: 8}
 
     def __init__(self):
+        self._lock = threading.Lock()
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._views: Dict[tuple, torch.Tensor] = {}      # (key, dtype, shape) -> the typed view: three tensor ops saved per request (eager small batches
                                                          # are host-bound: ~100 requests per forward)
@@ -321,15 +337,23 @@ class _Workspace:
         for s in shape:
             n *= s
         nbytes = n * self._ITEMSIZE[dtype]
-        buf = self._bufs.get(key)
-        if buf is None or buf.numel() < nbytes:
-            with torch.inference_mode(False):    # scratch outlives the call: a first use under torch.inference_mode() must not make it an inference tensor
-                buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self._bufs[key] = buf
-            for k in [k for k in self._views if k[0] == key]:      # views of the buffer this one replaces
-                del self._views[k]
-        with torch.inference_mode(False):
-            v = self._views[vkey] = buf[:nbytes].view(dtype).view(*shape)
+        with self._lock:                         # the slow path only (a new buffer / view): threads iterate and edit the same two dicts
+            buf = self._bufs.get(key)
+            if buf is None and not any(k[3] == key[3] for k in self._bufs):
+                # first request of this thread: drop what threads that have exited left behind (arenas are keyed by thread id)
+                alive = {t.ident for t in threading.enumerate()}
+                for k in [k for k in self._bufs if k[3] not in alive]:
+                    del self._bufs[k]
+                for k in [k for k in self._views if k[0][3] not in alive]:
+                    del self._views[k]
+            if buf is None or buf.numel() < nbytes:
+                with torch.inference_mode(False):    # scratch outlives the call: a first use under torch.inference_mode() must not make it an inference tensor
+                    buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+                self._bufs[key] = buf
+                for k in [k for k in self._views if k[0] == key]:      # views of the buffer this one replaces
+                    del self._views[k]
+            with torch.inference_mode(False):
+                v = self._views[vkey] = buf[:nbytes].view(dtype).view(*shape)
         return v
 
     def clear(self):
@@ -337,17 +361,36 @@ class _Workspace:
         self._views.clear()
 
 
-workspace = _Workspace()
+_shared_workspace = _Workspace()
+_ws_tls = threading.local()
+
+
+class _ActiveWorkspace:
+    """`engine.workspace`: the arena the CALLING THREAD draws scratch from - the shared one unless that thread is inside `use_workspace`
+    (round 2 rebound a process-global there: a thread capturing a hipGraph and another running an eager forward could restore each other's
+    arena out of order and leave the global pointing at a graph's private buffers)."""
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        return getattr(_ws_tls, "ws", _shared_workspace).get(name, shape, dtype, device)
+
+    def clear(self):
+        getattr(_ws_tls, "ws", _shared_workspace).clear()
+
+
+workspace = _ActiveWorkspace()
 
 
 @contextlib.contextmanager
 def use_workspace(ws: "_Workspace"):
-    global workspace
-    old, workspace = workspace, ws
+    old = getattr(_ws_tls, "ws", None)
+    _ws_tls.ws = ws
     try:
         yield ws
     finally:
-        workspace = old
+        if old is None:
+            del _ws_tls.ws
+        else:
+            _ws_tls.ws = old
 
 
 # ------------------------------------------------------------------------------------------------
@@ -531,6 +574,9 @@ def _fold_weights(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm):
             _check_f16_cast(wsrc, wg)
         c1 = wg.float().sum(1).contiguous()
         c2 = (wf @ ln.bias.detach().float() + (b.detach().float() if b is not None else 0.0)).contiguous()
+    if key not in _foldcache:
+        _evict_with(w, _foldcache, key)
+        _evict_with(ln.weight, _foldcache, key)
     _foldcache[key] = (ver, (wg, c1, c2))
     return wg, c1, c2
 
@@ -930,6 +976,8 @@ def _padded_k(p: torch.Tensor, w16: torch.Tensor, Kp: int) -> torch.Tensor:
     with torch.inference_mode(False), torch.no_grad():
         wp = torch.zeros((w16.shape[0], Kp), dtype=w16.dtype, device=w16.device)
         wp[:, :w16.shape[1]] = w16
+    if key not in _wpadcache:
+        _evict_with(p, _wpadcache, key)
     _wpadcache[key] = (ver, wp)
     return wp
 

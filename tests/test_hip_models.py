@@ -165,6 +165,27 @@ def test_rankvit_parity(golden, name, layers, b):
     assert rel_l2(full, g[f"{name}_b1.0_logits"]) < TOL_CONTRACT
 
 
+def test_rankvit_keep_sets_do_not_depend_on_the_batch_size():
+    """Round 2 ADVICE: at large batches the token norms a ranked block sorts by come out of the previous block's fc2 epilogue (per-tile
+    sums of squares, another summation order than pv_token_norm's) and LayerNorm is folded into the GEMMs - near-tied tokens could be
+    kept or dropped differently depending on the batch an image arrives in.  RankViT-B/16 [3,6,9] @ 0.5: the two golden images inside
+    a batch of 64 (256-row tile kernels, fused norms, folded LayerNorm) keep exactly the token sets they keep as a batch of 2, which are
+    the reference's (test_rankvit_parity)."""
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    m.set_budget(0.5)
+    small = _x(cfg)
+    big = torch.from_numpy(synth.synth_images(64, cfg["image_size"], seed=5))
+    big[7], big[40] = small[0], small[1]
+    keeps = {}
+    for tag, x in (("small", small), ("big", big)):
+        with torch.no_grad():
+            logits = m(x.to(DEV)).cpu()
+        keeps[tag] = ([np.sort(m.encoder.layers[li].last_keep.cpu().numpy().astype(np.int64), axis=1) for li in (3, 6, 9)], logits)
+    for a, b in zip(keeps["small"][0], keeps["big"][0]):
+        assert np.array_equal(a, b[[7, 40]])
+    assert rel_l2(keeps["big"][1][[7, 40]].numpy(), keeps["small"][1].numpy()) < TOL_CONTRACT
+
+
 @pytest.mark.parametrize("tag,name,gb", [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_micro", 0), ("vit_b_16", "vit_b_16", 10)])
 def test_residualvit_parity(golden, tag, name, gb):
     g = golden("residualvit")
