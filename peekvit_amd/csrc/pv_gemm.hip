@@ -669,11 +669,17 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
         const bool ocol_ok = n0 + (lane & 31) * 8 < p.N;
         const int rb_row0 = (wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5);      // + 32 q + 2 j: the rows this wave stores in pass q
+        // The image of a pass: 64 rows x 512 B = 32 KiB, local row lr = (wave group) * 32 + (tile row % 32); two such regions alternate
+        // (pass q -> region q & 1) inside K-tile buffer 1 ONLY: buffer 0 stays free, so the prefetching launch can stage the next
+        // tile's first K-tile into it while this epilogue runs.  Region q & 1 is rewritten in pass q + 2, after barrier q + 1 - by
+        // which every wave has completed its read-back of pass q (it needed the rows for the stores it issued during pass q + 1).
+        lds_c* const img = cimg + G2_BUF;
+        const int rb_lrow0 = (wid >> 2) * 32 + (wid & 3) * 8 + (lane >> 5);      // + 2 j
         uint32_t rb_addr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = rb_row0 + 2 * j;
-            rb_addr[j] = (uint32_t)(uintptr_t)cimg + row * 512 + (((lane & 31) ^ (row & 7)) << 4);
+            const int row = rb_lrow0 + 2 * j;
+            rb_addr[j] = (uint32_t)(uintptr_t)img + row * 512 + (((lane & 31) ^ (row & 7)) << 4);
         }
         f32x4 cf[2][8];            // gathered table entries of two units in flight (GELU units only)
         u32x4 rb[4];               // rows read back from the image, waiting for their store slot
@@ -739,8 +745,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             }
             const u32x4 pk = {pv_pack_bf16x2_tracked(y[0], y[1], vmax), pv_pack_bf16x2_tracked(y[2], y[3], vmax),
                               pv_pack_bf16x2_tracked(y[4], y[5], vmax), pv_pack_bf16x2_tracked(y[6], y[7], vmax)};
-            const int row = wr * 128 + mt * 16 + i16, c = wc * 8 + u * 4 + g;
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cimg + row * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+            const int lrow = wr * 32 + (mt & 1) * 16 + i16, c = wc * 8 + u * 4 + g;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(img + ((mt >> 1) & 1) * 32768 + lrow * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
         };
         uint16_t* orow[4];         // output row of read-back slot j in image region 0; region q is 32 rows further
 #pragma unroll
@@ -765,8 +771,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)      // row rb_row0 + 32 q + 2 j: the swizzle term does not depend on q -> base + immediate
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"((vq & 3) * 32 * 512));
+                for (int j = 0; j < 4; ++j)      // local row rb_lrow0 + 2 j of region q & 1: base + immediate
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"((vq & 1) * 32768));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
@@ -896,27 +902,31 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // PV_EPI_GELU_GRAD_BF16: this lane's 4 columns summed over the rows its wave stores
         float vmax = 0.f;                           // operand-range guard of the x16_out copy (fp16 build)
-        // Every wave owns 16 whole rows of a pass (2 passes of 128 rows), handled as four HALF-steps of 8 rows.  Round 3: the residual /
-        // positional / pre-activation rows of half-step h+2 are requested BEFORE the stores of half-step h+1 are issued - VMEM order
-        // L0 L1 S0 L2 S1 L3 S2 S3 - because the counter behind s_waitcnt vmcnt is in order: round 2 issued L(pass 1) after S(pass 0), so the
-        // wait for pass 1's rows also waited for 192 KiB of pass 0's stores to drain, and the CU's memory path (the bound of this
+        // FOUR passes of 64 tile rows; the fp32 image of a pass (64 rows x 1 KiB, chunk c of row r at c ^ (r & 7)) lives in K-tile buffer 1
+        // ONLY - buffer 0 stays free for the prefetching launch to stage the next tile's first K-tile during this epilogue.  Pass q: the
+        // wave group that holds rows 64 q .. 64 q + 63 (wr = q >> 1, its 16-row tiles 4 (q & 1) .. + 3) writes them, then every wave takes 8
+        // whole rows: residual / positional / pre-activation row + image row -> result row (1 KiB per instruction).
+        // Round 3: the rows of pass q + 2 are requested BEFORE the stores of pass q + 1 are issued - VMEM order L0 L1 S0 L2 S1 L3 S2 S3 -
+        // because the counter behind s_waitcnt vmcnt is in order: round 2 issued its second batch of loads behind the first batch of
+        // stores, so the wait for the rows also waited for 192 KiB of stores to drain, and the CU's memory path (the bound of this
         // epilogue: 640 KiB per tile at ~28 B/clk) idled in between.  Same arithmetic per element: bit-identical outputs.
+        lds_c* const img = cimg + G2_BUF;
         const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
         const int ncol = col_ok ? n0 + lane * 4 : 0;
         f32x4 rr[2][8];
         float rsc[2] = {1.0f, 1.0f};                       // PV_EPI_BIAS_RES_F32 row scale: lane j (< 8) holds slot j's (loaded with the rows: never after a store)
-        auto row_of = [&](int hs, int j) -> int64_t {      // output row of slot j of half-step hs (clamped at the ragged bottom edge)
-            int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + j;
+        auto row_of = [&](int q, int j) -> int64_t {       // output row of slot j of pass q (clamped at the ragged bottom edge)
+            int m = m0 + q * 64 + wid * 8 + j;
             m = m < p.M ? m : p.M - 1;
-            if (EPI == PV_EPI_BIAS_POS_F32) { const int img = m / p.rpi, pi = m - img * p.rpi; return (int64_t)img * p.rpo + p.row_off + pi; }
+            if (EPI == PV_EPI_BIAS_POS_F32) { const int img_ = m / p.rpi, pi = m - img_ * p.rpi; return (int64_t)img_ * p.rpo + p.row_off + pi; }
             return m;
         };
-        auto fetch = [&](int hs) __attribute__((always_inline)) {
+        auto fetch = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + j;
+                int m = m0 + q * 64 + wid * 8 + j;
                 m = m < p.M ? m : p.M - 1;
-                f32x4& r = rr[hs & 1][j];
+                f32x4& r = rr[q & 1][j];
                 if (EPI == PV_EPI_BIAS_F32) {
                     r = (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved bf16 pre-activation row, 512 B per instruction
@@ -925,47 +935,43 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     r = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
                 } else {
-                    const int img = m / p.rpi, pi = m - img * p.rpi;
+                    const int img_ = m / p.rpi, pi = m - img_ * p.rpi;
                     r = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)(p.row_off + pi) * p.N + ncol);
                 }
             }
             if (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale) {
-                int m = m0 + (hs >> 1) * 128 + wid * 16 + (hs & 1) * 8 + (lane & 7);
-                rsc[hs & 1] = p.row_scale[m < p.M ? m : p.M - 1];
+                int m = m0 + q * 64 + wid * 8 + (lane & 7);
+                rsc[q & 1] = p.row_scale[m < p.M ? m : p.M - 1];
             }
         };
         fetch(0);
         fetch(1);
 #pragma unroll
-        for (int hs = 0; hs < 4; ++hs) {
-            const int ps = hs >> 1;
-            if ((hs & 1) == 0) {
-                if (ps == 1) __builtin_amdgcn_s_barrier();      // pass 0's image has been consumed by every wave
-                if (wr == ps) {
+        for (int q = 0; q < 4; ++q) {
+            if (q > 0) __builtin_amdgcn_s_barrier();      // the previous pass's image has been consumed by every wave
+            if (wr == (q >> 1)) {
 #pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) {
-                        const int row = mt * 16 + i16;
+                for (int ml = 0; ml < 4; ++ml) {
+                    const int mt = 4 * (q & 1) + ml, row = ml * 16 + i16;
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) {
-                            const int c = wc * 16 + (nt >> 1) * 8 + g * 2 + (nt & 1);
-                            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
-                        }
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = wc * 16 + (nt >> 1) * 8 + g * 2 + (nt & 1);
+                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(img + row * 1024 + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             float fs[8], fq[8];            // LayerNorm folding (producer) / rank norms: per-lane partial (sum, sum of squares) of the 8 rows
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int jj = (hs & 1) * 8 + j;
-                const int row = wid * 16 + jj;
-                const int64_t orow = row_of(hs, j);
-                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * 1024 + ((lane ^ (row & 7)) << 4));
-                const f32x4 r = rr[hs & 1][j];
+                const int row = wid * 8 + j;                        // local image row; tile row 64 q + row
+                const int64_t orow = row_of(q, j);
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(img + row * 1024 + ((lane ^ (row & 7)) << 4));
+                const f32x4 r = rr[q & 1][j];
                 // row scale of slot j: lane j of the set holds it (one register per set instead of eight)
                 const float sc = (EPI == PV_EPI_BIAS_RES_F32 && p.row_scale)
-                                     ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc[hs & 1]), j)) : 1.0f;
+                                     ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc[q & 1]), j)) : 1.0f;
                 f32x4 o;
                 if (EPI == PV_EPI_BIAS_F32) {
                     const float qs = ncol < p.qcols ? p.qscale : 1.0f;
@@ -979,7 +985,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     o = (f32x4){fmaf(sc, v[0], tr * r[0]), fmaf(sc, v[1], tr * r[1]), fmaf(sc, v[2], tr * r[2]), fmaf(sc, v[3], tr * r[3])};
                 }
                 else o = (f32x4){r[0] + v[0], r[1] + v[1], r[2] + v[2], r[3] + v[3]};
-                const bool ok = m0 + ps * 128 + row < p.M && col_ok;
+                const bool ok = m0 + q * 64 + row < p.M && col_ok;
                 if (ok) {
                     if (EPI == PV_EPI_GELU_GRAD_BF16) {
                         const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
@@ -989,22 +995,22 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol) = o;
                 }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out)      // (workgroup-uniform) token norms for the next block's ranking
-                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the half-step
+                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the pass
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
                     if (ok)
                         *reinterpret_cast<u32x2*>(p.x16_out + orow * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
-                    // this lane's share of the row's (sum, sum of squares); the 64-lane reduction of the 8 rows follows the half-step
+                    // this lane's share of the row's (sum, sum of squares); the 64-lane reduction of the 8 rows follows the pass
                     fs[j] = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
                     fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
                 }
             }
-            // the rows of half-step hs + 2 into the slot set just consumed: requested before the NEXT half-step's stores, so the wait for
-            // them (two half-steps from now) has only this half-step's stores in front of it, long since drained
-            if (hs + 2 < 4) fetch(hs + 2);
+            // the rows of pass q + 2 into the slot set just consumed: requested before the NEXT pass's stores, so the wait for them (two
+            // passes from now) has only this pass's stores in front of it, long since drained
+            if (q + 2 < 4) fetch(q + 2);
             {
                 // 8 rows x 64 lanes -> 8 totals in 10 cross-lane steps per quantity (halving the rows a lane carries at every exchange)
                 // instead of 8 full wave reductions; lanes 8r .. 8r+7 end up with row r's totals
-                const int r_ = (lane >> 3) & 7, mrow = m0 + ps * 128 + wid * 16 + (hs & 1) * 8 + r_;
+                const int r_ = (lane >> 3) & 7, mrow = m0 + q * 64 + wid * 8 + r_;
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out && !p.x16_out) {
                     const float tq = pv_reduce8_rows(fq, lane);
                     if ((lane & 7) == 0 && mrow < p.M) p.rowsq_out[(int64_t)(n0 / G2_BN) * p.M + mrow] = tq;
@@ -1020,13 +1026,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         if (EPI == PV_EPI_GELU_GRAD_BF16 && p.colsum_partial) {      // (workgroup-uniform) combine the 8 waves through LDS: [8][256] floats
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // the last image has been consumed by every wave
-            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + wid * 1024 + lane * 16) = csum;
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + G2_BUF + wid * 1024 + lane * 16) = csum;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < 256 && n0 + tid < p.N) {
                 float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) t += *reinterpret_cast<const __attribute__((address_space(3))) float*>(cimg + w * 1024 + tid * 4);
+                for (int w = 0; w < 8; ++w) t += *reinterpret_cast<const __attribute__((address_space(3))) float*>(cimg + G2_BUF + w * 1024 + tid * 4);
                 p.colsum_partial[(int64_t)(m0 / G2_BM) * p.N + n0 + tid] = t;
             }
         }

@@ -13,8 +13,10 @@ lib.pv_gemm_bf16.argtypes = [C.POINTER(GemmArgs), C.c_void_p]; lib.pv_debug_set_
 dev = "cuda:0"; M = int(os.environ.get("M", 403456))
 g = torch.Generator(device=dev).manual_seed(0)
 SL = 16          # stamp slots per workgroup
-for name, N, K, epi, fold in [("qkv", 2304, 768, 0, False), ("qkv_fold", 2304, 768, 0, True), ("out", 768, 768, 2, False), ("fc1", 3072, 768, 1, False),
-                              ("fc1_fold", 3072, 768, 1, True), ("fc2", 768, 3072, 2, False)]:
+SHAPES = {"vit_b_16": [("qkv", 2304, 768, 0, False), ("qkv_fold", 2304, 768, 0, True), ("out", 768, 768, 2, False), ("fc1", 3072, 768, 1, False),
+                       ("fc1_fold", 3072, 768, 1, True), ("fc2", 768, 3072, 2, False)],
+          "vit_small": [("qkv", 1152, 384, 0, False), ("fc1", 1536, 384, 1, False)]}      # (M=100864; its residual GEMMs run the full-row kernel)
+for name, N, K, epi, fold in SHAPES[os.environ.get("MODEL", "vit_b_16")]:
     a = torch.randn(M, K, generator=g, device=dev).to(torch.float16)
     w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.float16)
     bias = torch.randn(N, generator=g, device=dev)
@@ -22,7 +24,7 @@ for name, N, K, epi, fold in [("qkv", 2304, 768, 0, False), ("qkv_fold", 2304, 7
     c1 = w.float().sum(1).contiguous()
     out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.float16, device=dev)
     res = torch.randn(M, N, generator=g, device=dev) if epi == 2 else None
-    nblk = ((M + 255) // 256) * (N // 256)
+    nblk = ((M + 255) // 256) * ((N + 255) // 256)
     dbg = torch.zeros(nblk * SL, dtype=torch.int64, device=dev)
     lib.pv_debug_set_stamp_buffer(dbg.data_ptr())
     args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
