@@ -14,6 +14,12 @@
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 // 1: the software-pipelined 16-bit epilogue of the 256^2 kernel (round 3); 0: round 2's one-pass form, kept for A/B builds (scripts/gemm_epi_ab.py)
+// prefetching persistent launch: 0 = no prefetch (plain persistent loop), 1 = prefetch retired before the first store, 2 = prefetch retired
+// by a counted wait at the end of the epilogue, 3 (shipped) = 2 for the 16-bit epilogues and 1 for the fp32 / gelu' ones - whose first stores
+// wait for the residual rows anyway (profiles/r03_gemm_pf_ab.json: out-proj 0.812 ms with 1, 0.855 with 2, 0.840 one tile per workgroup)
+#ifndef PV_PF_MODE
+#define PV_PF_MODE 3
+#endif
 #ifndef PV_EPI_PIPE
 #define PV_EPI_PIPE 1
 #endif
@@ -422,11 +428,30 @@ constexpr int G2_BUF = 4 * G2_HALF;          // 64 KiB per K-tile buffer
 constexpr int G2_LDS = 2 * G2_BUF;           // 128 KiB
 
 // one 256 x 256 output tile at (m0, n0): prologue, pipelined K loop, transposed epilogue.  Uses smem[0, G2_LDS) (+ the GELU table).
-template <int EPI>
-__device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, const int m0, const int n0) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+// PF = the prefetching persistent launch (pv_gemm256_pf_kernel, round 3): `first` = this workgroup's first tile (its K-tile 0 is staged
+// here); otherwise K-tile 0 is ALREADY in buffer 0, staged by the previous tile's epilogue, which - when `has_next` - stages the first
+// K-tile of tile (nm0, nn0) in turn.  PF = false: the tile is self-contained (one tile per workgroup, the rows kernel).
+template <int EPI, bool PF = false>
+__device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, const int m0, const int n0, const bool first = true,
+                                                const bool has_next = false, const int nm0 = 0, const int nn0 = 0, const int wid_pf = 0) {
+    int tid_ = threadIdx.x;
+    // PF: the thread index is REBUILT per tile from the wave index (an SGPR of the persistent loop) and a volatile v_mbcnt pair, so that no
+    // VGPR lives across tiles and nothing derived from the thread index (staging offsets, fragment bases) is hoisted out of the loop and
+    // kept live through the epilogue, whose register budget is full.  (hipcc spilled 53 VGPRs without this, and a scratch reload is a
+    // vector-memory operation: the s_waitcnt vmcnt(0) in front of its use also waits for every LDS-DMA and store in flight.)
+    if (PF) {
+        int l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+        tid_ = wid_pf * 64 + l_;
+    }
+    int tid = tid_, lane = tid & 63;       // (PF: rebuilt once more at the start of the epilogue)
+    const int wid = PF ? wid_pf : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    // PF: the tile's 256 bias values travel through LDS (1 KiB behind the table and the fold constants), staged with K-tile 0: a register load at
+    // the start of a tile would put an s_waitcnt vmcnt(0) - the previous tile's stores included - in front of the first MFMA
+    constexpr int PFM = PV_PF_MODE != 3 ? PV_PF_MODE
+                      : (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? 2 : 1;
+    constexpr int PF_BIAS_BASE = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0) + 4096;
     PV_STAMP(14);
 #ifdef PV_STAMPS
     if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 13] = rt_; }
@@ -463,6 +488,30 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         pv_glds16<PV_GEMM_W_AUX>(src + ow[h][0], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF);
         pv_glds16<PV_GEMM_W_AUX>(src + ow[h][1], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF + 8192);
     };
+    // PF: K-tile 0 (all four half-tile slots of buffer 0) of ANOTHER tile - the next one of this workgroup's list
+    auto stage_next_tile0 = [&](int tm0, int tn0) __attribute__((always_inline)) {
+        const char* const na = reinterpret_cast<const char*>(p.A + (int64_t)tm0 * p.lda);
+        const char* const nw = reinterpret_cast<const char*>(p.W + (int64_t)tn0 * p.ldw);
+        int l_;                 // its own lane index: nothing here may depend on a value carried (= spilled) across the K loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+        const int srow = wid * 8 + (l_ >> 3), schunk = (l_ & 7) ^ ((l_ >> 3) & 7);
+        if (p.bias && wid < 4) {          // (wave-uniform) the next tile's 256 bias values, one float per lane of waves 0 - 3
+            const int c_ = tn0 + wid * 64 + l_ < p.N ? tn0 + wid * 64 + l_ : p.N - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + c_),
+                                             (__attribute__((address_space(3))) void*)(smem + PF_BIAS_BASE + wid * 256), 4, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int ra = h * 128 + j * 64 + srow; ra = tm0 + ra < p.M ? ra : p.M - 1 - tm0;
+                const int q = j * 64 + srow;
+                int rw = h * 128 + (q & ~31) + (((q & 15) >> 2) << 3) + (((q >> 4) & 1) << 2) + (q & 3);
+                rw = tn0 + rw < p.N ? rw : p.N - 1 - tn0;
+                pv_glds16<PV_GEMM_A_AUX>(na + (uint32_t)(ra * (int)p.lda + schunk * 8) * 2u, lds_piece + h * G2_HALF + j * 8192);
+                pv_glds16<PV_GEMM_W_AUX>(nw + (uint32_t)(rw * (int)p.ldw + schunk * 8) * 2u, lds_piece + (2 + h) * G2_HALF + j * 8192);
+            }
+    };
 
     // ---- fragment read addresses: one LDS-address-space base per (buffer, k-step), every read = base + immediate ----
     typedef __attribute__((address_space(3))) const char lds_cc;
@@ -482,14 +531,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         }
 
     // accumulators start from the bias: lane (g = lane>>4) owns columns en0 + (nt>>1)*32 + g*8 + (nt&1)*4 + 0..3 of tile nt
-    const int en0 = n0 + wc * 64 + ((lane >> 4) << 3);
+    int en0 = n0 + wc * 64 + ((lane >> 4) << 3);
     f32x4 acc[4][8];   // [nt][mt]
+    if (!PF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && en0 + (i >> 1) * 32 + (i & 1) * 4 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + en0 + (i >> 1) * 32 + (i & 1) * 4);
+        for (int i = 0; i < 4; ++i) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && en0 + (i >> 1) * 32 + (i & 1) * 4 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + en0 + (i >> 1) * 32 + (i & 1) * 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = b4;
+            for (int j = 0; j < 8; ++j) acc[i][j] = b4;
+        }
     }
     bf16x8 af[2][4][2];   // [m half][mt][ks]
     bf16x8 bfr[2][2];     // [nt][ks] of the CURRENT n half (n0 lives P1-P2, n1 lives P3-P4: one register set)
@@ -554,15 +605,22 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 
     // ---- prologue: tile 0 complete + A halves of tile 1 in flight ------------------------------------------------
     const int nk = p.K / G2_BK;        // even, >= 2 (checked on the host)
+    if (PF) __builtin_assume(nk >= 4);   // (the launcher keeps K < 256 off the persistent kernel: the main loop runs at least once, no bypass edge)
     PV_STAMP(0);
 #ifdef PV_STAMPS
     if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 6] = rt_; }
 #endif
-    stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0);
+    const bool own_tile0 = !PF || !PFM || first;          // (workgroup-uniform)
+    if (PF && (first || !PFM) && p.bias && wid < 4) {       // (wave-uniform) this tile's bias values: OLDER than K-tile 0, so the wait for that covers them
+        const int c_ = n0 + wid * 64 + lane < p.N ? n0 + wid * 64 + lane : p.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + c_),
+                                         (__attribute__((address_space(3))) void*)(smem + PF_BIAS_BASE + wid * 256), 4, 0, 0);
+    }
+    if (own_tile0) { stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0); }
     stage_a(1, 0, 1); stage_a(1, 1, 1);
     constexpr bool HAS_TAB = EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16;
     constexpr int NTAB = HAS_TAB ? (EPI == PV_EPI_GELU_GRAD_BF16 ? 4 : 2) : 0;
-    if (HAS_TAB) {
+    if (HAS_TAB && own_tile0) {
         // GELU table (16 KiB replicated cubic; 32 KiB linear table for gelu') into the LDS above the staging buffers.  Issued AFTER the
         // first K tiles (round 3; round 2 issued it first, so the K loop could not start before the table had landed: fc1's prologue took
         // 4.0 k cycles against QKV's 2.4 k): the wait below leaves it in flight, and the first counted wait of the K loop - which leaves
@@ -585,17 +643,28 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((tid < 256 ? p.fold_c1 : p.fold_c2) + c_),
                                          (__attribute__((address_space(3))) void*)(smem + FOLD_BASE + 2048 + wid * 256), 4, 0, 0);
     }
-    // tile 0 has landed for this thread; the A halves of tile 1 (4 operations), the table and the fold constants stay in flight
-    {
+    // tile 0 has landed for this thread; the A halves of tile 1 (4 operations), the table and the fold constants stay in flight.
+    // (PF, not the first tile: K-tile 0 landed during the previous epilogue - every wave drained its share before its first store - and the
+    //  barrier at the tile boundary has been passed: nothing to wait for; what was just issued is covered by the K loop's first counted wait.)
+    if (own_tile0) {
         const int inflight = 4 + NTAB + (fold_dma ? 2 : 0);      // workgroup-uniform; the immediate must be literal
         if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (inflight == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (inflight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PV_STAMP(1);
+    if (PF) {          // accumulators start from the bias: the same values as the register loads of the one-tile kernel, read from the LDS copy
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) char*)smem + PF_BIAS_BASE + (wc * 64 + ((lane >> 4) << 3) + (i >> 1) * 32 + (i & 1) * 4) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = b4;
+        }
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier interval behind group 0
 
     int kt = 0;
@@ -616,7 +685,17 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     // whole contiguous row segment: one wave-instruction = 1 KiB of one (fp32) or two (bf16) output rows ------------
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
+    if (PF) {                  // fresh lane index for the epilogue: no thread-index arithmetic is carried through the K loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        tid = wid * 64 + lane;
+        en0 = n0 + wc * 64 + ((lane >> 4) << 3);
+    }
     const int g = lane >> 4, i16 = lane & 15;
+    // PF: the next tile's first K-tile goes into buffer 0 NOW - the epilogue images live in buffer 1 only - so that its 64 KiB travel under
+    // this epilogue's arithmetic instead of in front of the next K loop.  It is the OLDEST vector-memory operation of the epilogue: the
+    // s_waitcnt vmcnt(0) in front of the first store retires it without waiting for any store.
+    const bool pf_next = PF && PFM && has_next;
+    if (pf_next) stage_next_tile0(nm0, nn0);
     if (PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)) {
         // Round 3: the 16-bit epilogue as a software pipeline (in-kernel stamps of round 2's form, scripts/stamp_gemm.py: fc1 + folded
         // LayerNorm spent 18.9 k ticks here against 27.7 k in its K loop).  What was wrong, from the stamps and the ISA:
@@ -764,6 +843,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             if (vn + 1 < NU) issue(vn + 1);
             wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
             finish(vn);
+            if (PFM == 1 && vn == 4 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 has landed (before any store)
             if (vq > 0) store_row(vq - 1, vn & 3);                  // one 1-KiB store of the previous pass per unit
             if ((vn & 3) == 3) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's image writes (and the gathers issued before them)
@@ -962,6 +1042,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (PFM == 1 && q == 0 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 (and this tile's first rows) before any store
             float fs[8], fq[8];            // LayerNorm folding (producer) / rank norms: per-lane partial (sum, sum of squares) of the 8 rows
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1037,6 +1118,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             }
         }
     }
+    if (PFM == 2 && pf_next) {
+        // the next tile's K-tile 0 is older than every store of this epilogue: a COUNTED wait that leaves the stores in flight retires it.
+        // A full tile issues at least 16 (16-bit outputs: 2 rows per instruction) / 32 (fp32 and gelu' epilogues: 1 row) stores per wave
+        // after the prefetch; a ragged tile may skip some, so it drains.
+        const bool full = m0 + G2_BM <= p.M && n0 + G2_BN <= p.N;
+        constexpr bool B16 = EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+        if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (B16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    }
     PV_STAMP(3);
 #ifdef PV_STAMPS
     if (threadIdx.x == 0 && p.dbg) {          // slot 5: which CU ran this workgroup; slot 6/7: constant-rate (100 MHz) wall clock at start / end
@@ -1080,6 +1171,44 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
     const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
     const int tnl = rem / gsz, tm = grp * p.gm + (rem - tnl * gsz);
     pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, (ch * p.gc + tnl) * G2_BN);
+}
+
+// Prefetching persistent launch (round 3).  One workgroup per CU walks its XCD-contiguous share of the tile list; the epilogue of tile t
+// stages K-tile 0 of tile t+1 (pv_gemm256_tile<EPI, true>), so a tile no longer pays kernel entry (0.7 k cycles), the wait for its first 64
+// KiB (2.6 - 3.2 k cycles at batch 2048; 5 - 8 k when few rounds of tiles keep all CUs' prologues in step, vit_small) nor the 1.0 - 1.4 us
+// the dispatcher leaves between two workgroups of a CU.  The plain persistent loop (measured above pv_gemm256_kernel) lost because the
+// next tile's first wait sat behind the previous tile's stores in the in-order vmcnt queue; here the prefetch is issued BEFORE any store
+// of the epilogue and retired in front of the first one.  A tile's arithmetic is untouched: outputs are bit-identical.
+template <int EPI>
+__global__ __launch_bounds__(512) void pv_gemm256_pf_kernel(const GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;       // gridDim.x is a multiple of 8
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int nfull = p.tiles_n / p.gc;
+    auto decode = [&](int tile, int& m0, int& n0) {       // chunk-major list: chunk c = column tiles [c*gc, c*gc + cw); groups of gm row panels, n slow
+        const int ch = min(tile / (p.gc * p.tiles_m), nfull);
+        const int r = tile - ch * p.gc * p.tiles_m;
+        const int cw = ch < nfull ? p.gc : p.tiles_n - nfull * p.gc;
+        const int grp = r / (p.gm * cw), rem = r - grp * (p.gm * cw);
+        const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
+        const int tnl = rem / gsz, tm = grp * p.gm + (rem - tnl * gsz);
+        m0 = tm * G2_BM; n0 = (ch * p.gc + tnl) * G2_BN;
+    };
+    const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int m0 = 0, n0 = 0, nm0 = 0, nn0 = 0;
+    if (j < cnt) decode(start + j, m0, n0);
+    for (int i = j; i < cnt; i += per) {
+        const bool has_next = i + per < cnt;
+        if (has_next) decode(start + i + per, nm0, nn0);
+        pv_gemm256_tile<EPI, true>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of the epilogue have returned ...
+        __builtin_amdgcn_s_barrier();                          // ... and every wave's: the next tile may overwrite buffer 1; its K-tile 0 is in buffer 0
+        __builtin_amdgcn_sched_barrier(0);
+        m0 = nm0; n0 = nn0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1391,6 +1520,28 @@ __global__ __launch_bounds__(512) void pv_gemm256_rows_kernel(const GemmDev p) {
     else pv_fused_ln_rows<16>(p, m0);
 }
 
+// prefetching persistent 256^2 launches: PV_GEMM_PF=0 or pv_debug_set_gemm_pf(0) restores one tile per workgroup (A/B, scripts/gemm_epi_ab.py)
+#ifndef PV_GEMM_PF_DEFAULT
+#define PV_GEMM_PF_DEFAULT 1
+#endif
+static int g_pv_pf = -1;
+extern "C" void pv_debug_set_gemm_pf(int on) { g_pv_pf = on; }
+static bool pv_gemm_pf_enabled() {
+    static const int env = [] { const char* e = getenv("PV_GEMM_PF"); return e ? atoi(e) : PV_GEMM_PF_DEFAULT; }();
+    return g_pv_pf >= 0 ? g_pv_pf != 0 : env != 0;
+}
+static int pv_cu_count() {              // per device (the current one = the stream's: peekvit_amd.ops refuses otherwise)
+    static int cached[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 0;
+    if (cached[d] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0;
+        cached[d] = n > 0 ? n : -1;
+    }
+    return cached[d] > 0 ? cached[d] : 0;
+}
+
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
@@ -1398,9 +1549,26 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
                                   : (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)
                                         ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0)                   // + 16 KiB replicated cubic GELU table
                         + ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) ? 4096 : 0);         // + 4 KiB folded-LayerNorm constants
+    // (persistent launch: + 1 KiB of bias values behind the table and the fold slot; the gelu' epilogue has neither bias nor room)
+    constexpr int lds_pf = EPI == PV_EPI_GELU_GRAD_BF16 ? lds
+                         : G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0) + 4096 + 1024;
+    // the prefetching persistent launch: every epilogue but the one-pass forms (bf16x3's SPLIT; -DPV_EPI_PIPE=0 builds) keeps buffer 0 free
+    // (not the training pair epilogue either: in the persistent loop hipcc 7.2 spills its store addresses, and every scratch reload drains vmcnt)
+    constexpr bool PF_OK = EPI != PV_EPI_BIAS_GELU_SPLIT_BF16 && EPI != PV_EPI_BIAS_GELU_PAIR_BF16 && (PV_EPI_PIPE || (EPI != PV_EPI_BIAS_BF16 && EPI != PV_EPI_BIAS_GELU_BF16 && EPI != PV_EPI_BIAS_GELU_PAIR_BF16));
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (PF_OK) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_pf_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pf);
     }
+#ifndef PV_STAMPS
+    if (PF_OK) {
+        const int cus = pv_cu_count();
+        if (pv_gemm_pf_enabled() && p.ksplit <= 1 && p.K >= 4 * G2_BK && (int64_t)p.tiles_m * p.tiles_n >= 2 * (int64_t)cus && cus >= 8 &&
+            !(EPI == PV_EPI_GELU_GRAD_BF16 && p.bias)) {
+            PV_LAUNCH(pv_gemm256_pf_kernel<EPI>, dim3((unsigned)(cus & ~7)), dim3(512), lds_pf, stream, p);
+            return pv_check_launch();
+        }
+    }
+#endif
     PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(512), lds, stream, p);
     return pv_check_launch();
 }

@@ -30,6 +30,9 @@ def variant_paths():
     from peekvit_amd import _build
     return {"r2": os.path.join(_build.HERE, "libpeekvit_hip_r2f16.so"),
             "nopipe": os.path.join(_build.HERE, "libpeekvit_hip_nopipef16.so"),
+            "pfm0": os.path.join(_build.HERE, "libpeekvit_hip_pfm0f16.so"),      # -DPV_PF_MODE=0: persistent, no prefetch
+            "pfm1": os.path.join(_build.HERE, "libpeekvit_hip_pfm1f16.so"),      # -DPV_PF_MODE=1: prefetch retired before the first store
+            "nopf": _build.LIB_F16,            # the shipped library with pv_debug_set_gemm_pf(0): one tile per workgroup
             "cur": _build.LIB_F16}
 
 
@@ -37,6 +40,8 @@ def build():
     from peekvit_amd import _build
     _build.build()
     _build.build_variant("nopipef16", ["-DPV_OPERAND_F16", "-DPV_EPI_PIPE=0"])
+    _build.build_variant("pfm0f16", ["-DPV_OPERAND_F16", "-DPV_PF_MODE=0"])
+    _build.build_variant("pfm1f16", ["-DPV_OPERAND_F16", "-DPV_PF_MODE=1"])
     # round 2's kernels from history, compiled outside the tree (only the .so comes back)
     tmp = "/tmp/pv_r2_src"
     os.makedirs(os.path.join(tmp, "peekvit_amd", "csrc"), exist_ok=True)
@@ -83,6 +88,9 @@ def main():
         lib.pv_gemm_bf16.restype = C.c_int
         lib.pv_gemm_bf16.argtypes = [C.c_void_p, C.c_void_p]
         libs[tag] = lib
+    only = [t for t in os.environ.get("AB_VARIANTS", "").split(",") if t]
+    if only:
+        libs = {t: l for t, l in libs.items() if t in only}
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=dev).manual_seed(0)
     M = a.M
@@ -90,6 +98,9 @@ def main():
     shapes = [("qkv", 2304, 768, PV_EPI_BIAS_BF16, False), ("qkv_fold", 2304, 768, PV_EPI_BIAS_BF16, True),
               ("fc1", 3072, 768, PV_EPI_BIAS_GELU_BF16, False), ("fc1_fold", 3072, 768, PV_EPI_BIAS_GELU_BF16, True),
               ("out", 768, 768, PV_EPI_BIAS_RES_F32, False), ("fc2", 768, 3072, PV_EPI_BIAS_RES_F32, False)]
+    keep = [t for t in os.environ.get("AB_SHAPES", "").split(",") if t]
+    if keep:
+        shapes = [sh for sh in shapes if sh[0] in keep]
     result = {"M": M, "rounds": a.rounds, "iters": a.iters, "shapes": {}}
     for name, N, K, epi, fold in shapes:
         x = torch.randn(M, K, generator=g, device=dev)
@@ -123,6 +134,8 @@ def main():
         gargs = {t: args(outs[t], t) for t in libs}
 
         def run(t, n):
+            if hasattr(libs[t], "pv_debug_set_gemm_pf") and t != "r2" and t != "nopipe":
+                libs[t].pv_debug_set_gemm_pf(0 if t == "nopf" else 1)
             for _ in range(n):
                 rc = libs[t].pv_gemm_bf16(C.byref(gargs[t]), stream)
                 assert rc == 0, (t, name, rc)
@@ -148,6 +161,11 @@ def main():
             got = outs[t][rows].double()
             errs[t] = float((got - ref).norm() / ref.norm())
         same = bool(torch.equal(outs["cur"], outs["nopipe"])) if "cur" in outs and "nopipe" in outs else None
+        if "cur" in outs and "nopf" in outs:
+            eq = bool(torch.equal(outs["cur"], outs["nopf"]))
+            if resid is not None:
+                eq = eq and bool(torch.equal(x16["cur"], x16["nopf"])) and bool(torch.equal(rstat["cur"], rstat["nopf"]))
+            print(f"{name:9s} cur == nopf bitwise (all outputs): {eq}", flush=True)
         if resid is not None and "r2" in outs:           # the fp32 epilogue was restructured too: same bits as round 2's
             print(f"{name:9s} cur == r2 bitwise: out {bool(torch.equal(outs['cur'], outs['r2']))}, x16 copy {bool(torch.equal(x16['cur'], x16['r2']))}, "
                   f"row statistics max rel diff {float(((rstat['cur'] - rstat['r2']).abs() / rstat['r2'].abs().clamp_min(1e-6)).max()):.1e}", flush=True)
