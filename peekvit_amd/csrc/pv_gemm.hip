@@ -1553,8 +1553,7 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     constexpr int lds_pf = EPI == PV_EPI_GELU_GRAD_BF16 ? lds
                          : G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0) + 4096 + 1024;
     // the prefetching persistent launch: every epilogue but the one-pass forms (bf16x3's SPLIT; -DPV_EPI_PIPE=0 builds) keeps buffer 0 free
-    // (not the training pair epilogue either: in the persistent loop hipcc 7.2 spills its store addresses, and every scratch reload drains vmcnt)
-    constexpr bool PF_OK = EPI != PV_EPI_BIAS_GELU_SPLIT_BF16 && EPI != PV_EPI_BIAS_GELU_PAIR_BF16 && (PV_EPI_PIPE || (EPI != PV_EPI_BIAS_BF16 && EPI != PV_EPI_BIAS_GELU_BF16 && EPI != PV_EPI_BIAS_GELU_PAIR_BF16));
+    constexpr bool PF_OK = EPI != PV_EPI_BIAS_GELU_SPLIT_BF16 && (PV_EPI_PIPE || (EPI != PV_EPI_BIAS_BF16 && EPI != PV_EPI_BIAS_GELU_BF16 && EPI != PV_EPI_BIAS_GELU_PAIR_BF16));
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (PF_OK) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_pf_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pf);

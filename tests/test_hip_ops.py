@@ -131,6 +131,70 @@ def test_gemm_patch_embed_epilogue_big_kernel(ops):
     assert torch.all(got[:, :off] == 7.0) and torch.all(got[:, off + Np:] == 7.0)
 
 
+@pytest.mark.parametrize("M,N,K", [(41 * 256 + 37, 13 * 256 - 128, 256), (64 * 256, 9 * 256, 768), (43 * 256 + 200, 3 * 256 * 5 - 128, 384)])
+def test_gemm_persistent_launch_is_bit_identical(ops, M, N, K):
+    """Shapes with >= 2 x CUs tiles run the prefetching persistent launch (pv_gemm256_pf_kernel: the next tile's first K-tile and bias are
+    staged under the epilogue).  A tile's arithmetic is the one-tile kernel's: every epilogue must reproduce it bit for bit, ragged bottom
+    row tile and ragged last column tile included; pv_debug_set_gemm_pf(0) = one tile per workgroup."""
+    from peekvit_amd import _lib
+    from peekvit_amd._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_BIAS_POS_F32,
+                                  PV_EPI_BIAS_RES_F32, PV_EPI_GELU_GRAD_BF16)
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    A = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device=DEV) * 0.1
+    res = torch.randn(M, N, generator=g, device=DEV)
+    pre = torch.randn(M, N, generator=g, device=DEV).to(torch.bfloat16)
+    rs = torch.rand(M, generator=g, device=DEV) + 0.5
+    stat = torch.stack([torch.randn(M, generator=g, device=DEV) * 0.05, 1.0 + 0.1 * torch.rand(M, generator=g, device=DEV)], 1).contiguous()
+    c1 = W.float().sum(1).contiguous()
+    rpi = 197
+    B = (M + rpi - 2) // (rpi - 1)
+    pos = torch.randn(rpi, N, generator=g, device=DEV) * 0.02
+
+    def run_all():
+        r = {}
+        o16 = lambda: torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        o32 = lambda: torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        r["bias"] = ops.gemm(A, W, bias, o16(), PV_EPI_BIAS_BF16, qcols=(N // 3) // 8 * 8, qscale=0.125)
+        r["bias_fold"] = ops.gemm(A, W, None, o16(), PV_EPI_BIAS_BF16, fold=(stat, c1, bias))
+        r["gelu"] = ops.gemm(A, W, bias, o16(), PV_EPI_BIAS_GELU_BF16)
+        r["gelu_fold"] = ops.gemm(A, W, None, o16(), PV_EPI_BIAS_GELU_BF16, fold=(stat, c1, bias))
+        pair = torch.full((M, 2 * N), float("nan"), dtype=torch.bfloat16, device=DEV)      # training fc1: [gelu(h) | h]
+        r["pair"] = ops.gemm(A, W, bias, pair, PV_EPI_BIAS_GELU_PAIR_BF16)
+        r["f32"] = ops.gemm(A, W, bias, o32(), PV_EPI_BIAS_F32)
+        r["res"] = ops.gemm(A, W, bias, o32(), PV_EPI_BIAS_RES_F32, res=res, row_scale=rs)
+        x16, part = o16(), torch.full(((N + 255) // 256, M, 2), float("nan"), device=DEV)
+        r["res_fold"] = ops.gemm(A, W, bias, o32(), PV_EPI_BIAS_RES_F32, res=res, x16_out=x16, rowstat_out=part)
+        r["res_fold_x16"], r["res_fold_stat"] = x16, part
+        sq = torch.full(((N + 255) // 256, M), float("nan"), device=DEV)
+        r["res_rowsq"] = ops.gemm(A, W, bias, o32(), PV_EPI_BIAS_RES_F32, res=res, rowsq_out=sq)
+        r["rowsq"] = sq
+        cs = torch.zeros(N, device=DEV)
+        r["gelu_grad"] = ops.gemm(A, W, None, o16(), PV_EPI_GELU_GRAD_BF16, res=pre, colsum_out=cs)
+        r["gelu_grad_colsum"] = cs
+        outp = torch.full((B * rpi, N), 7.0, device=DEV)
+        Mp = B * (rpi - 1)
+        if Mp <= M:
+            r["pos"] = ops.gemm(A[:Mp], W, bias, outp, PV_EPI_BIAS_POS_F32, pos=pos, rows_per_img_in=rpi - 1, rows_per_img_out=rpi, row_off=1)
+        torch.cuda.synchronize()
+        return r
+
+    lib.pv_debug_set_gemm_pf(0)
+    try:
+        one = run_all()
+        lib.pv_debug_set_gemm_pf(1)
+        pf = run_all()
+        again = run_all()
+    finally:
+        lib.pv_debug_set_gemm_pf(-1)
+    for k in one:
+        assert not torch.isnan(one[k].float()).any(), k
+        assert torch.equal(one[k], pf[k]), k
+        assert torch.equal(pf[k], again[k]), k
+
+
 def test_gemm_kernels_agree_bitwise(ops):
     """An output element is rounded identically by the 128^2 and 256^2 kernels (batch invariance relies on it)."""
     import os, subprocess, sys
