@@ -14,11 +14,11 @@
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 // 1: the software-pipelined 16-bit epilogue of the 256^2 kernel (round 3); 0: round 2's one-pass form, kept for A/B builds (scripts/gemm_epi_ab.py)
-// prefetching persistent launch: 0 = no prefetch (plain persistent loop), 1 = prefetch retired before the first store, 2 = prefetch retired
-// by a counted wait at the end of the epilogue, 3 (shipped) = 2 for the 16-bit epilogues and 1 for the fp32 / gelu' ones - whose first stores
-// wait for the residual rows anyway (profiles/r03_gemm_pf_ab.json: out-proj 0.812 ms with 1, 0.855 with 2, 0.840 one tile per workgroup)
+// prefetching persistent launch: 0 = no prefetch (plain persistent loop), 1 = the whole prefetch issued at the start of the epilogue and
+// retired before the first store, 2 (shipped) = prefetch issued in pieces under the first pass of the epilogue (16-bit) / behind the first
+// residual rows (fp32) and retired by a counted wait at the end of the epilogue
 #ifndef PV_PF_MODE
-#define PV_PF_MODE 3
+#define PV_PF_MODE 2
 #endif
 #ifndef PV_EPI_PIPE
 #define PV_EPI_PIPE 1
@@ -159,7 +159,7 @@ extern "C" void pv_debug_set_stamp_buffer(void* p) { g_pv_dbg = (unsigned long l
         unsigned long long t_;                                                                       \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                                           \
-        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 16 + (i)] = t_;                    \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[pv_stamp_slot * 16 + (i)] = t_;                         \
     } while (0)
 #else
 #define PV_STAMP(i)
@@ -433,7 +433,7 @@ constexpr int G2_LDS = 2 * G2_BUF;           // 128 KiB
 // K-tile of tile (nm0, nn0) in turn.  PF = false: the tile is self-contained (one tile per workgroup, the rows kernel).
 template <int EPI, bool PF = false>
 __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, const int m0, const int n0, const bool first = true,
-                                                const bool has_next = false, const int nm0 = 0, const int nn0 = 0, const int wid_pf = 0) {
+                                                const bool has_next = false, const int nm0 = 0, const int nn0 = 0, const int wid_pf = 0, const int slot_pf = 0) {
     int tid_ = threadIdx.x;
     // PF: the thread index is REBUILT per tile from the wave index (an SGPR of the persistent loop) and a volatile v_mbcnt pair, so that no
     // VGPR lives across tiles and nothing derived from the thread index (staging offsets, fragment bases) is hoisted out of the loop and
@@ -447,14 +447,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     int tid = tid_, lane = tid & 63;       // (PF: rebuilt once more at the start of the epilogue)
     const int wid = PF ? wid_pf : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+#ifdef PV_STAMPS
+    const size_t pv_stamp_slot = PF ? (size_t)slot_pf : (size_t)blockIdx.x;      // stamps per TILE: the persistent launch passes the tile's list position
+#endif
     // PF: the tile's 256 bias values travel through LDS (1 KiB behind the table and the fold constants), staged with K-tile 0: a register load at
     // the start of a tile would put an s_waitcnt vmcnt(0) - the previous tile's stores included - in front of the first MFMA
-    constexpr int PFM = PV_PF_MODE != 3 ? PV_PF_MODE
-                      : (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? 2 : 1;
+    constexpr int PFM = PV_PF_MODE;
     constexpr int PF_BIAS_BASE = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0) + 4096;
     PV_STAMP(14);
 #ifdef PV_STAMPS
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 13] = rt_; }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 13] = rt_; }
 #endif
 
     // ---- LDS-DMA sources: per half-tile two 1-KiB pieces per wave (rows j*64 + wid*8 + lane/8), swizzled chunk ----
@@ -488,29 +490,31 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         pv_glds16<PV_GEMM_W_AUX>(src + ow[h][0], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF);
         pv_glds16<PV_GEMM_W_AUX>(src + ow[h][1], lds_piece + buf * G2_BUF + (2 + h) * G2_HALF + 8192);
     };
-    // PF: K-tile 0 (all four half-tile slots of buffer 0) of ANOTHER tile - the next one of this workgroup's list
-    auto stage_next_tile0 = [&](int tm0, int tn0) __attribute__((always_inline)) {
-        const char* const na = reinterpret_cast<const char*>(p.A + (int64_t)tm0 * p.lda);
-        const char* const nw = reinterpret_cast<const char*>(p.W + (int64_t)tn0 * p.ldw);
-        int l_;                 // its own lane index: nothing here may depend on a value carried (= spilled) across the K loop
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
-        const int srow = wid * 8 + (l_ >> 3), schunk = (l_ & 7) ^ ((l_ >> 3) & 7);
-        if (p.bias && wid < 4) {          // (wave-uniform) the next tile's 256 bias values, one float per lane of waves 0 - 3
-            const int c_ = tn0 + wid * 64 + l_ < p.N ? tn0 + wid * 64 + l_ : p.N - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + c_),
-                                             (__attribute__((address_space(3))) void*)(smem + PF_BIAS_BASE + wid * 256), 4, 0, 0);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                int ra = h * 128 + j * 64 + srow; ra = tm0 + ra < p.M ? ra : p.M - 1 - tm0;
-                const int q = j * 64 + srow;
-                int rw = h * 128 + (q & ~31) + (((q & 15) >> 2) << 3) + (((q >> 4) & 1) << 2) + (q & 3);
-                rw = tn0 + rw < p.N ? rw : p.N - 1 - tn0;
-                pv_glds16<PV_GEMM_A_AUX>(na + (uint32_t)(ra * (int)p.lda + schunk * 8) * 2u, lds_piece + h * G2_HALF + j * 8192);
-                pv_glds16<PV_GEMM_W_AUX>(nw + (uint32_t)(rw * (int)p.ldw + schunk * 8) * 2u, lds_piece + (2 + h) * G2_HALF + j * 8192);
+    // PF: K-tile 0 (all four half-tile slots of buffer 0) of ANOTHER tile - the next one of this workgroup's list - in eight 1-KiB-per-wave
+    // pieces (0-3: A half h = pc >> 1, part j = pc & 1; 4-7: W likewise) + piece 8 = the tile's 256 bias values (one float per lane of waves
+    // 0 - 3).  Nothing here may depend on a value carried (= spilled) across the K loop: the epilogue rebuilds `lane` before the first piece.
+    auto stage_next_piece = [&](int tm0, int tn0, int pc) __attribute__((always_inline)) {
+        if (pc == 8) {
+            if (p.bias && wid < 4) {          // (wave-uniform)
+                const int c_ = tn0 + wid * 64 + lane < p.N ? tn0 + wid * 64 + lane : p.N - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + c_),
+                                                 (__attribute__((address_space(3))) void*)(smem + PF_BIAS_BASE + wid * 256), 4, 0, 0);
             }
+            return;
+        }
+        const int h = (pc >> 1) & 1, jj = pc & 1;
+        const int sr = wid * 8 + (lane >> 3), sc = (lane & 7) ^ ((lane >> 3) & 7);
+        if (pc < 4) {
+            const char* const na = reinterpret_cast<const char*>(p.A + (int64_t)tm0 * p.lda);
+            int ra = h * 128 + jj * 64 + sr; ra = tm0 + ra < p.M ? ra : p.M - 1 - tm0;
+            pv_glds16<PV_GEMM_A_AUX>(na + (uint32_t)(ra * (int)p.lda + sc * 8) * 2u, lds_piece + h * G2_HALF + jj * 8192);
+        } else {
+            const char* const nw = reinterpret_cast<const char*>(p.W + (int64_t)tn0 * p.ldw);
+            const int q = jj * 64 + sr;
+            int rw = h * 128 + (q & ~31) + (((q & 15) >> 2) << 3) + (((q >> 4) & 1) << 2) + (q & 3);
+            rw = tn0 + rw < p.N ? rw : p.N - 1 - tn0;
+            pv_glds16<PV_GEMM_W_AUX>(nw + (uint32_t)(rw * (int)p.ldw + sc * 8) * 2u, lds_piece + (2 + h) * G2_HALF + jj * 8192);
+        }
     };
 
     // ---- fragment read addresses: one LDS-address-space base per (buffer, k-step), every read = base + immediate ----
@@ -608,7 +612,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     if (PF) __builtin_assume(nk >= 4);   // (the launcher keeps K < 256 off the persistent kernel: the main loop runs at least once, no bypass edge)
     PV_STAMP(0);
 #ifdef PV_STAMPS
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 6] = rt_; }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 6] = rt_; }
 #endif
     const bool own_tile0 = !PF || !PFM || first;          // (workgroup-uniform)
     if (PF && (first || !PFM) && p.bias && wid < 4) {       // (wave-uniform) this tile's bias values: OLDER than K-tile 0, so the wait for that covers them
@@ -695,7 +699,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     // this epilogue's arithmetic instead of in front of the next K loop.  It is the OLDEST vector-memory operation of the epilogue: the
     // s_waitcnt vmcnt(0) in front of the first store retires it without waiting for any store.
     const bool pf_next = PF && PFM && has_next;
-    if (pf_next) stage_next_tile0(nm0, nn0);
+    if (PFM == 1 && pf_next) {
+#pragma unroll
+        for (int pc = 0; pc < 9; ++pc) stage_next_piece(nm0, nn0, pc);
+    }
     if (PV_EPI_PIPE && (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)) {
         // Round 3: the 16-bit epilogue as a software pipeline (in-kernel stamps of round 2's form, scripts/stamp_gemm.py: fc1 + folded
         // LayerNorm spent 18.9 k ticks here against 27.7 k in its K loop).  What was wrong, from the stamps and the ISA:
@@ -841,6 +848,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         for (int vn = 0; vn < NU; ++vn) {
             const int vq = vn >> 2;
             if (vn + 1 < NU) issue(vn + 1);
+            if (PFM == 2 && vn < 4 && pf_next) {
+                // the next tile's first K-tile, two pieces per unit of the first pass: the memory path is idle until the first store (unit 4),
+                // and a burst of all 64 KiB at the start of the epilogue held every wave at the ISSUE of its loads for ~1 k cycles (stamps)
+                if (vn == 0) stage_next_piece(nm0, nn0, 8);
+                stage_next_piece(nm0, nn0, 2 * vn);
+                stage_next_piece(nm0, nn0, 2 * vn + 1);
+            }
             wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
             finish(vn);
             if (PFM == 1 && vn == 4 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 has landed (before any store)
@@ -1026,6 +1040,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         };
         fetch(0);
         fetch(1);
+        if (PFM == 2 && pf_next) {          // behind the rows the first passes wait for, in front of every store
+#pragma unroll
+            for (int pc = 0; pc < 9; ++pc) stage_next_piece(nm0, nn0, pc);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q > 0) __builtin_amdgcn_s_barrier();      // the previous pass's image has been consumed by every wave
@@ -1134,11 +1152,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.dbg[(size_t)blockIdx.x * 16 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        p.dbg[pv_stamp_slot * 16 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PV_STAMP(4);
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[(size_t)blockIdx.x * 16 + 7] = rt_; }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 7] = rt_; }
 #endif
 }
 
@@ -1203,7 +1221,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_pf_kernel(const GemmDev p) {
     for (int i = j; i < cnt; i += per) {
         const bool has_next = i + per < cnt;
         if (has_next) decode(start + i + per, nm0, nn0);
-        pv_gemm256_tile<EPI, true>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid);
+        pv_gemm256_tile<EPI, true>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid, start + i);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of the epilogue have returned ...
         __builtin_amdgcn_s_barrier();                          // ... and every wave's: the next tile may overwrite buffer 1; its K-tile 0 is in buffer 0
         __builtin_amdgcn_sched_barrier(0);
@@ -1558,7 +1576,6 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (PF_OK) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm256_pf_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pf);
     }
-#ifndef PV_STAMPS
     if (PF_OK) {
         const int cus = pv_cu_count();
         if (pv_gemm_pf_enabled() && p.ksplit <= 1 && p.K >= 4 * G2_BK && (int64_t)p.tiles_m * p.tiles_n >= 2 * (int64_t)cus && cus >= 8 &&
@@ -1567,7 +1584,6 @@ static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
             return pv_check_launch();
         }
     }
-#endif
     PV_LAUNCH(pv_gemm256_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1))), dim3(512), lds, stream, p);
     return pv_check_launch();
 }
