@@ -40,6 +40,10 @@ class GraphedForward:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     self.model(self.static_in)
+            # what gets captured: the guarded fp16 forward (its first node zeroes the flag word, the replayer reads it) - unless mode "auto"
+            # has already sent this model to the fallback mode (parameter bounds, or three trips in a row during warm-up): that capture
+            # neither zeroes nor writes the word, so the replayer must not read it (a stale bit would send every replay to eager)
+            self._guarded = engine._mode() == "auto" and not engine.guard_state(self.model).unsafe
             with torch.cuda.graph(self.graph, stream=side):
                 self.static_out = self.model(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
@@ -52,6 +56,6 @@ class GraphedForward:
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         self.static_in.copy_(x)
         self.graph.replay()
-        if engine._PRECISION == "auto" and int(self._flag.item()) != 0:      # the fp16 range guard tripped inside the replay
+        if self._guarded and int(self._flag.item()) != 0:      # a guard tripped inside the replay: this batch again, eagerly, in a mode that keeps the contract
             return self.model(self.static_in)
         return self.static_out

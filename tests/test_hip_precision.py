@@ -430,3 +430,40 @@ class _nullcontext:
 
     def __exit__(self, *a):
         return False
+
+
+def test_graph_replay_of_a_model_the_guard_sends_to_the_fallback_mode(golden):
+    """hipGraph replay + mode "auto" on the hostile vit_tiny (x100 LayerNorm gains: the attention-score guard trips on every forward).
+    While the model is still tried on fp16 operands the replay's flag read sends each batch to an eager forward in the fallback mode; once
+    the guard is sticky (three trips) a fresh capture IS the fallback forward, the replayer no longer reads the flag word - a stale bit
+    must not send its replays to eager - and the replay is bit-identical to eager.  Both stay inside 1e-3 of the reference."""
+    from peekvit_amd import engine
+    from peekvit_amd.graph import GraphedForward
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_tiny"]
+    m = VisionTransformer(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.hostile_variants(cfg)["hostile"].items()})
+    m = m.eval().to(DEV)
+    x = torch.from_numpy(synth.synth_images(2, cfg["image_size"], seed=0)).to(DEV)
+    ref = golden("hostile")["vit_tiny/hostile/logits"]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = GraphedForward(m, x, warmup=1)                 # one trip so far: the capture is the guarded fp16 forward
+        assert g._guarded and not engine.guard_state(m).unsafe
+        n0 = engine.fallback_count
+        y = g(x).clone()
+        assert engine.fallback_count == n0 + 1 and rel_l2(y.cpu().numpy(), ref) < TOL_NORTH_STAR          # replay tripped -> eager repeat in bf16x3
+        for _ in range(3):
+            m(x)
+        assert engine.guard_state(m).unsafe                # sticky now
+        g.refresh()
+        assert not g._guarded
+        engine.range_flag_for(x.device).fill_(4)           # a stale bit from some other forward of this thread
+        n1 = engine.fallback_count
+        y2 = g(x).clone()
+        assert engine.fallback_count == n1 + 1 or engine.fallback_count == n1      # (the capture itself may count; the replay must not)
+        n2 = engine.fallback_count
+        y3 = g(x).clone()
+        assert engine.fallback_count == n2
+        assert torch.equal(y2, y3) and torch.equal(y2, m(x)) and rel_l2(y2.cpu().numpy(), ref) < TOL_NORTH_STAR
+    engine.reset_guard(m)
