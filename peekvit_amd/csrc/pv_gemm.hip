@@ -14,6 +14,17 @@
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 // 1: the software-pipelined 16-bit epilogue of the 256^2 kernel (round 3); 0: round 2's one-pass form, kept for A/B builds (scripts/gemm_epi_ab.py)
+// cache policy of the 256^2 epilogues' output stores: non-temporal (bit 0 = the 16-bit outputs, bit 1 = the fp32 residual stream).  The
+// outputs are 0.6 - 2.5 GB per launch and nothing of them is re-read from L2, while the operands ARE (each A panel by up to 12 column tiles):
+// with default stores they push the panels out.  Round 3, same box, libraries swapped between runs of bench.py (scripts/lib_ab.sh): forward
+// 74.5 -> 73.2 ms; per shape (scripts/gemm_epi_ab.py) QKV + fold -2 %, fc1 + fold -1 %, fc2 -0.6 %.  The same idea measured and NOT adopted:
+// non-temporal LOADS of the residual rows (-0.8 % = slower), non-temporal stores of the attention output (-1.5 %), nt on attention's K / V
+// LDS-DMA (+-0).  0 restores default stores (A/B).
+#ifndef PV_STORE_NT
+#define PV_STORE_NT 3
+#endif
+#define PV_STORE16(ptr, val) do { if (PV_STORE_NT & 1) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
+#define PV_STORE32(ptr, val) do { if (PV_STORE_NT & 2) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 // prefetching persistent launch: 0 = no prefetch (plain persistent loop), 1 = the whole prefetch issued at the start of the epilogue and
 // retired before the first store, 2 (shipped) = prefetch issued in pieces under the first pass of the epilogue (16-bit) / behind the first
 // residual rows (fp32) and retired by a counted wait at the end of the epilogue
@@ -841,7 +852,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // virtual pass vq: image region vq & 3, plane vq >> 2
             const int row = rb_row0 + 32 * (vq & 3) + 2 * j;
             uint16_t* o = orow[j] + (vq & 3) * pass_stride + ((PAIR2 && vq < 4) ? p.N : 0);
-            if (m0 + row < p.M && ocol_ok) *reinterpret_cast<u32x4*>(o) = rb[j];
+            if (m0 + row < p.M && ocol_ok) PV_STORE16(reinterpret_cast<u32x4*>(o), rb[j]);
         };
         issue(0);
 #pragma unroll
@@ -1091,13 +1102,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + ncol) = pk;
                         csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
                     } else
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol) = o;
+                        PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol), o);
                 }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out)      // (workgroup-uniform) token norms for the next block's ranking
                     fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the pass
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
                     if (ok)
-                        *reinterpret_cast<u32x2*>(p.x16_out + orow * (int64_t)p.N + ncol) = (u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)};
+                        PV_STORE16(reinterpret_cast<u32x2*>(p.x16_out + orow * (int64_t)p.N + ncol), ((u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)}));
                     // this lane's share of the row's (sum, sum of squares); the 64-lane reduction of the 8 rows follows the pass
                     fs[j] = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
                     fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
@@ -1760,7 +1771,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int idx = lane + 64 * c;
-                    if (idx < nvec) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4) = r.v[c];
+                    if (idx < nvec) PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4), ((f32x4){r.v[c].x, r.v[c].y, r.v[c].z, r.v[c].w}));
                 }
             }
             if (p.ln_out) {                                // (workgroup-uniform)
@@ -1774,7 +1785,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                         const int idx = lane + 64 * c;
                         if (idx < nvec) {
                             u32x2 pk = {pv_pack_bf16x2(r.v[c].x * lsc[j], r.v[c].y * lsc[j]), pv_pack_bf16x2(r.v[c].z * lsc[j], r.v[c].w * lsc[j])};
-                            o[idx] = pk;
+                            PV_STORE16(o + idx, pk);
                         }
                     }
                 }

@@ -32,6 +32,8 @@ def variant_paths():
             "nopipe": os.path.join(_build.HERE, "libpeekvit_hip_nopipef16.so"),
             "pfm0": os.path.join(_build.HERE, "libpeekvit_hip_pfm0f16.so"),      # -DPV_PF_MODE=0: persistent, no prefetch
             "pfm1": os.path.join(_build.HERE, "libpeekvit_hip_pfm1f16.so"),      # -DPV_PF_MODE=1: prefetch retired before the first store
+            "nt1": os.path.join(_build.HERE, "libpeekvit_hip_nt1f16.so"),        # -DPV_STORE_NT=1: non-temporal 16-bit output stores
+            "nt3": os.path.join(_build.HERE, "libpeekvit_hip_nt3f16.so"),        # -DPV_STORE_NT=3: + the fp32 residual stream
             "nopf": _build.LIB_F16,            # the shipped library with pv_debug_set_gemm_pf(0): one tile per workgroup
             "cur": _build.LIB_F16}
 
