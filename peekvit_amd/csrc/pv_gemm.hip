@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 if (ok) {
                     if (EPI == PV_EPI_GELU_GRAD_BF16) {
                         const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + ncol) = pk;
+                        PV_STORE16(reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + ncol), pk);
                         csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
                     } else
                         PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol), o);
