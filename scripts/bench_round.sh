@@ -10,7 +10,7 @@ python3 bench.py --rank-budget 0.5 --no-cpu-baseline > $o/${tag}_bench_rankvit.j
 python3 bench.py --rank-budget 0.5 --train --no-cpu-baseline > $o/${tag}_bench_train_rankvit.json 2>> $o/${tag}_bench.err &&
 python3 bench.py --model vit_small --batch 512 --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_bench_vit_small.json 2>> $o/${tag}_bench.err &&
 python3 bench.py --model vit_small --batch 512 --steps 20 --warmup 5 --train --no-cpu-baseline > $o/${tag}_bench_train_vit_small.json 2>> $o/${tag}_bench.err &&
-python3 bench.py --model vit_tiny --batch 32 --steps 50 --warmup 10 --no-cpu-baseline > $o/${tag}_bench_vit_tiny.json 2>> $o/${tag}_bench.err
+python3 bench.py --model vit_tiny --batch 32 --steps 200 --warmup 100 --no-cpu-baseline > $o/${tag}_bench_vit_tiny.json 2>> $o/${tag}_bench.err
 rc=$?
 for f in $o/${tag}_bench_*.json; do python3 -c "
 import json,sys
