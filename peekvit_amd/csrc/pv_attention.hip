@@ -693,79 +693,109 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     }
     __syncthreads();
 
-    // =============================== pass 2: per 16-key tile ===============================
-    for (int kt = wid; kt < nqt; kt += NW) {
-        const int k0 = kt << 4;
-        bf16x8 kf[KS], vf[KS];
+    // =============================== pass 2: per unit of KPW 16-key tiles ===============================
+    // Round 3: a wave owns TWO key tiles when that turns two rounds into one (9 <= NKT <= 16 with 8 waves: 13 tiles = 7 units; it was 8 + 5
+    // tiles = two rounds at 81 %).  Both passes are paced by LDS reads (r2 analysis in DESIGN.md section 9), and everything a unit reads per
+    // q-tile pair - the Q and dO fragments for S / dP, their transposed fragments for dK / dV, the row statistics - is read ONCE for both key
+    // tiles: the MFMAs double per LDS byte.  Arithmetic per element is unchanged (same products, same accumulation order over the q tiles).
+#ifndef PV_ABW_KPW
+#define PV_ABW_KPW ((NW == 8 && NKT >= 9 && NKT <= 16) ? 2 : 1)
+#endif
+    constexpr int KPW = PV_ABW_KPW;
+    for (int ku = wid; ku * KPW < nqt; ku += NW) {
+        bf16x8 kf[KPW][KS], vf[KPW][KS];
+        bool key_ok[KPW];
+        int k0[KPW];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag(Ks, kt, ks); vf[ks] = frag(Vs, kt, ks); }
-        const bool key_ok = k0 + i16 < S;
-        f32x4 dv[NDT], dk[NDT];
+        for (int t = 0; t < KPW; ++t) {
+            const int kt = ku * KPW + t, ktc = kt < NKT ? kt : NKT - 1;       // a unit's second tile may lie past the last one: no valid key
+            k0[t] = kt << 4;
+            key_ok[t] = kt < nqt && k0[t] + i16 < S;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
-        // probabilities / dS of one (q tile, key tile) pair from the saved row statistics: p[r], ds[r] for query qt*16 + 4g + r
-        auto pds = [&](int qt, u32x2& pw, u32x2& dw) __attribute__((always_inline)) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
+            for (int ks = 0; ks < KS; ++ks) { kf[t][ks] = frag(Ks, ktc, ks); vf[t][ks] = frag(Vs, ktc, ks); }
+        }
+        f32x4 dv[KPW][NDT], dk[KPW][NDT];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s = PV_MFMA_16x16x32(frag(Qs, qt, ks), kf[ks], s, 0, 0, 0);
-                c = PV_MFMA_16x16x32(frag(Os, qt, ks), vf[ks], c, 0, 0, 0);
-            }
+        for (int t = 0; t < KPW; ++t)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[t][dt] = dv[t][dt]; }
+        // probabilities / dS of one q tile against the unit's key tiles from the saved row statistics: p[r], ds[r] for query qt*16 + 4g + r
+        auto pds = [&](int qt, u32x2 (&pw)[KPW], u32x2 (&dw)[KPW]) __attribute__((always_inline)) {
+            bf16x8 qq_[KS], oo_[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qq_[ks] = frag(Qs, qt, ks); oo_[ks] = frag(Os, qt, ks); }
             const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * g);
             const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-            float p[4], ds[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = key_ok ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, mm[r])) : 0.f;
-                ds[r] = p[r] * (c[r] - dd[r]);
+            for (int t = 0; t < KPW; ++t) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = PV_MFMA_16x16x32(qq_[ks], kf[t][ks], s, 0, 0, 0);
+                    c = PV_MFMA_16x16x32(oo_[ks], vf[t][ks], c, 0, 0, 0);
+                }
+                float p[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = key_ok[t] ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, mm[r])) : 0.f;
+                    ds[r] = p[r] * (c[r] - dd[r]);
+                }
+                pw[t] = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
+                dw[t] = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
             }
-            pw = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
-            dw = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
         };
         // q tiles in pairs on the K = 32 MFMA (same slot order on both operands as in pass 1), an odd last tile on the K = 16 form
-        // three pairs per iteration at S = 193..208 (two iterations): the LDS reads of the next pair are issued under the MFMAs of this one
-        // (2.28 -> 2.13 ms at ViT-B/16, batch 2048); shorter sequences spill with it (NKT = 7: 0.93 -> 2.07 ms) and keep the rolled loop
+        // one key tile per wave: three pairs per iteration at S = 193..208 (two iterations): the LDS reads of the next pair are issued under the
+        // MFMAs of this one (2.28 -> 2.13 ms at ViT-B/16, batch 2048); shorter sequences spill with it (NKT = 7: 0.93 -> 2.07 ms) and keep the rolled loop
 #ifndef PV_ABW_P2_UNROLL
-#define PV_ABW_P2_UNROLL (NKT == 13 ? 3 : 1)
+#define PV_ABW_P2_UNROLL (KPW == 1 ? (NKT == 13 ? 3 : 1) : 1)
 #endif
 #pragma unroll PV_ABW_P2_UNROLL
         for (int tt = 0; tt < NKT / 2; ++tt) {
-            u32x2 p0, d0, p1, d1;
+            u32x2 p0[KPW], d0[KPW], p1[KPW], d1[KPW];
             pds(2 * tt, p0, d0);
             pds(2 * tt + 1, p1, d1);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[0], p0[1], p1[0], p1[1]});
-            const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 const s16x8 oo = __builtin_shufflevector(tfrag(Os, 2 * tt, dt), tfrag(Os, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
                 const s16x8 qq = __builtin_shufflevector(tfrag(Qs, 2 * tt, dt), tfrag(Qs, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
-                dv[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, oo), pf, dv[dt], 0, 0, 0);
-                dk[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, qq), dsf, dk[dt], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < KPW; ++t) {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[t][0], p0[t][1], p1[t][0], p1[t][1]});
+                    const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[t][0], d0[t][1], d1[t][0], d1[t][1]});
+                    dv[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, oo), pf, dv[t][dt], 0, 0, 0);
+                    dk[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, qq), dsf, dk[t][dt], 0, 0, 0);
+                }
             }
         }
         if (NKT & 1) {
-            u32x2 pw, dw;
+            u32x2 pw[KPW], dw[KPW];
             pds(NKT - 1, pw, dw);
-            const s16x4 pf = __builtin_bit_cast(s16x4, pw), dsf = __builtin_bit_cast(s16x4, dw);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                dv[dt] = PV_MFMA_16x16x16(tfrag(Os, NKT - 1, dt), pf, dv[dt], 0, 0, 0);
-                dk[dt] = PV_MFMA_16x16x16(tfrag(Qs, NKT - 1, dt), dsf, dk[dt], 0, 0, 0);
-            }
-        }
-        if (key_ok) {             // d*[dt][r] = dL/d{k,v}[k0+i16][dt*16 + 4g + r]
-            uint16_t* op = gb + (int64_t)(k0 + i16) * ld + 4 * g;
+                const s16x4 oo = tfrag(Os, NKT - 1, dt), qq = tfrag(Qs, NKT - 1, dt);
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const u32x2 kv = {pv_pack_bf16x2(dk[dt][0], dk[dt][1]), pv_pack_bf16x2(dk[dt][2], dk[dt][3])};
-                const u32x2 vv = {pv_pack_bf16x2(dv[dt][0], dv[dt][1]), pv_pack_bf16x2(dv[dt][2], dv[dt][3])};
-                *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
-                *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;
-                ck[dt] += (f32x4){pv_unpack_lo(kv[0]), pv_unpack_hi(kv[0]), pv_unpack_lo(kv[1]), pv_unpack_hi(kv[1])};
-                cv[dt] += (f32x4){pv_unpack_lo(vv[0]), pv_unpack_hi(vv[0]), pv_unpack_lo(vv[1]), pv_unpack_hi(vv[1])};
+                for (int t = 0; t < KPW; ++t) {
+                    dv[t][dt] = PV_MFMA_16x16x16(oo, __builtin_bit_cast(s16x4, pw[t]), dv[t][dt], 0, 0, 0);
+                    dk[t][dt] = PV_MFMA_16x16x16(qq, __builtin_bit_cast(s16x4, dw[t]), dk[t][dt], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int t = 0; t < KPW; ++t)
+            if (key_ok[t]) {             // d*[dt][r] = dL/d{k,v}[k0+i16][dt*16 + 4g + r]
+                uint16_t* op = gb + (int64_t)(k0[t] + i16) * ld + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const u32x2 kv = {pv_pack_bf16x2(dk[t][dt][0], dk[t][dt][1]), pv_pack_bf16x2(dk[t][dt][2], dk[t][dt][3])};
+                    const u32x2 vv = {pv_pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pv_pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
+                    *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
+                    *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;
+                    ck[dt] += (f32x4){pv_unpack_lo(kv[0]), pv_unpack_hi(kv[0]), pv_unpack_lo(kv[1]), pv_unpack_hi(kv[1])};
+                    cv[dt] += (f32x4){pv_unpack_lo(vv[0]), pv_unpack_hi(vv[0]), pv_unpack_lo(vv[1]), pv_unpack_hi(vv[1])};
+                }
+            }
     }
     if (dbp) {        // (workgroup-uniform) sum over the 16 rows a lane group holds, then over the waves through LDS
         __syncthreads();                                  // every wave has left pass 2: the Q image is free

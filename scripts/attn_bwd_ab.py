@@ -3,7 +3,9 @@
 import ctypes as C, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = {"rolled": ["-DPV_ABW_P2_UNROLL=1"], "u2": ["-DPV_ABW_P2_UNROLL=(NKT==13?2:1)"]}      # the pass-2 loop rolled (round 1) / two pairs per trip
+# round 3: "shipped" = two key tiles per wave in pass 2 (rolled q-pair loop); kpw1 = round 2's one key tile per wave with three q-tile pairs per trip;
+# kpw2u2 / kpw2u3 = two key tiles with two / three pairs per trip
+VARIANTS = {"kpw1": ["-DPV_ABW_KPW=1"], "kpw2u2": ["-DPV_ABW_P2_UNROLL=2"], "kpw2u3": ["-DPV_ABW_P2_UNROLL=3"]}
 from peekvit_amd import _build
 if "--build" in sys.argv:
     _build.build()
