@@ -1,0 +1,254 @@
+// Diagnostic (not part of the library): the K loop of a 256 x 256 x 64 tile with 128 x 128 WAVE tiles - 4 waves per workgroup, one per SIMD,
+// 64 accumulator quads (256 registers) per wave, a third fewer LDS fragment reads per MFMA than the shipped 8-wave kernel (128 x 64 wave tiles).
+// VERDICT r2 item 1 names this variant; DESIGN.md section 10.4(a) priced it at about +3 % from the empirical roofline.  This program MEASURES its
+// K loop in isolation (s_memtime stamps around the loop, the same clock scripts/stamp_gemm.py reads for the shipped kernel) on the QKV shape of
+// ViT-B/16 at batch 2048, with the shipped kernel's staging (LDS-DMA, XOR-swizzled 16-byte chunks), tile raster and MFMA (16x16x32 f16).
+//   schedule per K-tile t (one wave, no partner wave to hide behind - the software pipeline is inside the wave):
+//     [16 ds_read_b128: fragments of k-step 1 of tile t]  interleaved with  [64 MFMA on the k-step-0 fragments]
+//     s_waitcnt lgkmcnt(0), vmcnt(0) (tile t+1 landed, issued a whole K-tile ago), s_barrier
+//     [16 LDS-DMA: tile t+2 into the buffer tile t just left] + [16 ds_read_b128: k-step 0 of tile t+1]  interleaved with  [64 MFMA on k-step 1]
+//   hipcc --offload-arch=gfx950 -O3 scripts/gemm_w4_proto.hip -o scripts/bin/gemm_w4_proto && scripts/bin/gemm_w4_proto
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifndef PROTO_FULLWAIT
+#define PROTO_FULLWAIT 0
+#endif
+#ifndef PROTO_STEP
+#define PROTO_STEP 3          // one fragment read (and one LDS-DMA) per PROTO_STEP MFMAs
+#endif
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_A = BM * BK * 2, BUF = 2 * TILE_A, LDS_BYTES = 2 * BUF;      // 32 KiB A + 32 KiB W per buffer, two buffers = 128 KiB
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm_w4(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M, int N, int K,
+                                               unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, i16 = lane & 15;
+    // the shipped raster for 9 column tiles: every XCD walks a contiguous eighth of a list of groups of 8 row panels, n slow inside a group
+    const int tiles_n = N / BN, tiles_m = M / BM, ntiles = tiles_m * tiles_n;
+    const int tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int grp = tile / (8 * tiles_n), rem = tile - grp * 8 * tiles_n;
+    const int m0 = (grp * 8 + (rem & 7)) * BM, n0 = (rem >> 3) * BN;
+    (void)tiles_m;
+    // staging: 64 pieces of 1 KiB per K-tile (8 rows x 128 bytes; 16-byte chunk c of row r lands at chunk c ^ (r & 7)), 16 per wave:
+    // wave w stages A rows [w*64, w*64+64) (pieces 0-7) and W rows [w*64, w*64+64) (pieces 8-15)
+    const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
+    const char* a_src = reinterpret_cast<const char*>(A + (int64_t)(m0 + wid * 64 + srow) * K) + schunk * 16;
+    const char* w_src = reinterpret_cast<const char*>(W + (int64_t)(n0 + wid * 64 + srow) * K) + schunk * 16;
+    const int64_t piece_stride = (int64_t)8 * K * 2;
+    char* const lds_a = smem + wid * 64 * 128;                 // + buf * BUF + piece * 1024
+    char* const lds_w = smem + TILE_A + wid * 64 * 128;
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(a_src + i * piece_stride + kt * (BK * 2), lds_a + buf * BUF + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(w_src + i * piece_stride + kt * (BK * 2), lds_w + buf * BUF + i * 1024);
+    };
+    // fragment reads: lane (g, i16) of tile row block T reads row T*16 + i16, 16-byte chunk (ks*4 + g) ^ (i16 & 7)
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    lds_cc* a_rd[2][2];
+    lds_cc* b_rd[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ((ks * 4 + g) ^ (i16 & 7)) << 4;
+            a_rd[b][ks] = (lds_cc*)smem + b * BUF + (wr * 128 + i16) * 128 + sw;
+            b_rd[b][ks] = (lds_cc*)smem + b * BUF + TILE_A + (wc * 128 + i16) * 128 + sw;
+            asm volatile("" : "+v"(a_rd[b][ks]));
+            asm volatile("" : "+v"(b_rd[b][ks]));
+        }
+    f32x4 acc[8][8];       // [nt][mt]; 256 registers: they live in AGPRs and are accumulated IN PLACE by inline-asm MFMAs ("+a") - with the builtin
+                           // hipcc 7.2 gives every MFMA a destination different from its accumulator input and shuffles the quads through VGPRs
+                           // (818 v_accvgpr moves and 71 s_nops in the loop)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 af[2][8], bf[2][8];      // [k-step][tile]
+    const int nk = K / BK;
+#define MFMA_(ACC, WF, AF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(WF), "v"(AF))
+#define DSR_(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+    // fragment i of a k-step (i = 0..15): 0-7 -> A tile i, 8-15 -> W tile i - 8.  MFMA q (0..63): W tile n = q >> 3, A tile m = q & 7 - the first
+    // eight need fragments 0..8, every further eight one more: LDS returns in order, so counted lgkmcnt waits let the last reads land under MFMAs
+#define RD1(SET, BUFI, KS, I)                                                                       \
+    do { if ((I) >= 8) DSR_(bf[SET][(I) - 8], b_rd[BUFI][KS], ((I) - 8) * 2048);                    \
+         else DSR_(af[SET][(I)], a_rd[BUFI][KS], (I) * 2048); } while (0)
+#define MM1(SET, Q) MFMA_(acc[(Q) >> 3][(Q) & 7], bf[SET][(Q) >> 3], af[SET][(Q) & 7])
+#define LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+    // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-step-0 fragments in registers
+    stage(0, 0);
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) RD1(0, 0, 0, i);
+    // One K-tile.  Reads / LDS-DMA are issued one per THREE MFMAs (all 16 inside the first 48), so the last of them has 16 MFMAs to land under.
+    auto ktile = [&](auto bufc, auto stc, int kt) __attribute__((always_inline)) {
+        constexpr int B = decltype(bufc)::value;
+        constexpr bool STAGE = decltype(stc)::value;
+        // (1) k-step-1 fragments of this tile under the MFMAs of k-step 0, whose own fragments (issued during the previous block) are
+        //     waited for group by group: before group n (8 MFMAs) at most (7 - n) of them + the (3n' ...) reads issued here may be outstanding
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            if ((q & 7) == 0) {
+                // reads of this block issued before MFMA q: ceil(q / 3) (capped at 16); fragments of k-step 0 still allowed in flight: 7 - q/8
+                constexpr int dummy = 0; (void)dummy;
+                const int issued = (q + PROTO_STEP - 1) / PROTO_STEP < 16 ? (q + PROTO_STEP - 1) / PROTO_STEP : 16;
+                const int allow = (7 - (q >> 3)) + issued;
+                switch (PROTO_FULLWAIT ? 0 : allow) {          // (q is a compile-time constant after unrolling: one case survives)
+                    case 0: LGKM(0); break; case 1: LGKM(1); break; case 2: LGKM(2); break; case 3: LGKM(3); break; case 4: LGKM(4); break;
+                    case 5: LGKM(5); break; case 6: LGKM(6); break; case 7: LGKM(7); break; case 8: LGKM(8); break; case 9: LGKM(9); break;
+                    case 10: LGKM(10); break; case 11: LGKM(11); break; case 12: LGKM(12); break; case 13: LGKM(13); break; case 14: LGKM(14); break;
+                    default: LGKM(15); break;
+                }
+            }
+            if (q % PROTO_STEP == 0 && q / PROTO_STEP < 16) RD1(1, B, 1, q / PROTO_STEP);
+            MM1(0, q);
+        }
+        // (2) every wave has its fragments of tile kt; tile kt + 1 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // (3) tile kt + 2 into the buffer just left + k-step-0 fragments of tile kt + 1 under the MFMAs of k-step 1
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            if (q % PROTO_STEP == 0 && q / PROTO_STEP < 16) {
+                const int i = q / PROTO_STEP;
+                if (STAGE) {
+                    if (i < 8) glds16(a_src + i * piece_stride + (kt + 2) * (BK * 2), lds_a + B * BUF + i * 1024);
+                    else glds16(w_src + (i - 8) * piece_stride + (kt + 2) * (BK * 2), lds_w + B * BUF + (i - 8) * 1024);
+                }
+                RD1(0, B ^ 1, 0, i);
+            }
+            MM1(1, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {
+        ktile(B0{}, T{}, kt);
+        ktile(B1{}, T{}, kt + 1);
+    }
+    // tiles nk-4 .. nk-1 (nk even, >= 4): the last two stage nothing
+    ktile(B0{}, T{}, kt);
+    ktile(B1{}, T{}, kt + 1);
+    ktile(B0{}, F{}, kt + 2);
+    {
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            if ((q & 7) == 0) LGKM(0);          // (tail: not worth counting)
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) RD1(1, 1, 1, i);
+            }
+            MM1(0, q);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 64; ++q) MM1(1, q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the MFMAs are inline asm: hipcc does not know that the accumulators were just written by the matrix pipe and inserts no wait states in
+    // front of the v_accvgpr_read of the epilogue (the last accumulator quad came back without its final product) - spell them out
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+#pragma unroll
+    for (int n_ = 0; n_ < 8; ++n_)      // (the accumulators pass THROUGH the wait states: hipcc had hoisted the epilogue's reads in between the last MFMAs)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[n_][0]), "+a"(acc[n_][1]), "+a"(acc[n_][2]), "+a"(acc[n_][3]), "+a"(acc[n_][4]), "+a"(acc[n_][5]),
+                     "+a"(acc[n_][6]), "+a"(acc[n_][7]));
+    if (tid == 0 && stamps) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = t1; }
+    // plain per-lane epilogue (outside the stamped region): lane holds C[m0 + wr*128 + mt*16 + i16][n0 + wc*128 + nt*16 + 4g .. +4]
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const f32x4 v = acc[nt][mt];
+            f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<f16x4*>(C + (int64_t)(m0 + wr * 128 + mt * 16 + i16) * N + n0 + wc * 128 + nt * 16 + 4 * g) = o;
+        }
+}
+
+__global__ void fill(_Float16* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = (_Float16)(((int)(h & 0xffff) - 32768) * (scale / 32768.0f));
+    }
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 403456, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
+    if (M % 2048 || N % 256 || K % 128) { printf("M %% 2048, N %% 256, K %% 128 must be 0\n"); return 1; }
+    _Float16 *A, *W, *C;
+    unsigned long long* st;
+    const int nblk = (M / BM) * (N / BN);
+    CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&W, (size_t)N * K * 2)); CHECK(hipMalloc(&C, (size_t)M * N * 2));
+    CHECK(hipMalloc(&st, (size_t)nblk * 16));
+    fill<<<2048, 256>>>(A, (size_t)M * K, 1u, 1.0f);
+    fill<<<2048, 256>>>(W, (size_t)N * K, 2u, 0.05f);
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int r = 0; r < 12; ++r) {
+        CHECK(hipEventRecord(e0));
+        gemm_w4<<<nblk, 256, LDS_BYTES>>>(A, W, C, M, N, K, st);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 2) ms.push_back(t);
+    }
+    CHECK(hipGetLastError());
+    std::sort(ms.begin(), ms.end());
+    std::vector<unsigned long long> hs((size_t)nblk * 2);
+    CHECK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> kl;
+    for (int b = 0; b < nblk; ++b) kl.push_back((double)(hs[2 * b + 1] - hs[2 * b]));
+    std::sort(kl.begin(), kl.end());
+    // correctness: 16 rows x all columns against a host fp32 dot product of the same fp16 values
+    std::vector<_Float16> hw((size_t)N * K), ha(K), hc(N);
+    CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
+    double num = 0, den = 0;
+    int nbad = 0;
+    for (int s = 0; s < 16; ++s) {
+        const int64_t row = ((int64_t)s * 7919 * 257 + 131) % M;
+        CHECK(hipMemcpy(ha.data(), A + row * K, (size_t)K * 2, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(hc.data(), C + row * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            double acc = 0;
+            for (int k = 0; k < K; ++k) acc += (double)(float)ha[k] * (double)(float)hw[(size_t)n * K + k];
+            num += (acc - (double)(float)hc[n]) * (acc - (double)(float)hc[n]);
+            den += acc * acc;
+            if (getenv("PROTO_DEBUG") && std::fabs(acc - (double)(float)hc[n]) > 0.02 * std::fabs(acc) + 0.02 && nbad++ < 40)
+                printf("  bad: row %lld (%% 256 = %lld) col %d (%% 256 = %d): got %.4f want %.4f\n", (long long)row, (long long)(row % 256), n, n % 256, (float)hc[n], acc);
+        }
+    }
+    const double med = ms[ms.size() / 2];
+    printf("{\"kernel\": \"256x256x64 tile, 4 waves x (128 x 128) wave tiles, plain per-lane epilogue\", \"M\": %d, \"N\": %d, \"K\": %d, \"ms_median\": %.4f, "
+           "\"tflops_whole_kernel\": %.1f, \"kloop_ticks_median\": %.0f, \"kloop_ticks_per_ktile\": %.1f, \"kloop_ticks_p10\": %.0f, \"kloop_ticks_p90\": %.0f, "
+           "\"rel_l2_vs_host_fp32\": %.3e}\n",
+           M, N, K, med, 2.0 * M * N * K / med / 1e9, kl[kl.size() / 2], kl[kl.size() / 2] / (K / BK), kl[kl.size() / 10], kl[kl.size() * 9 / 10], std::sqrt(num / den));
+    return 0;
+}
