@@ -353,6 +353,12 @@ def test_vit_384_long_sequence_forward():
         got = m(x)
         ref = m._composite_head(m.encoder(m._composite_tokens(x)))
     assert rel_l2(got.cpu(), ref.cpu()) < 1.2e-2
+    # ... and against the CPU ORACLE (the reference's arithmetic, pinned by the golden vectors) at the contract's tolerance (round 3: the
+    # module's own stock-op composite is pinned to the reference at micro size only)
+    cfg = dict(image_size=384, patch_size=16, num_layers=2, num_heads=2, hidden_dim=128, mlp_dim=256, num_classes=10)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = O.vit_forward(x.cpu(), sd, cfg, "fp32")
+    assert rel_l2(got.cpu(), want) < TOL_CONTRACT
 
 
 def test_forward_leaves_the_module_tree_untouched():
@@ -680,6 +686,9 @@ def test_rankvit_budget_zero_keeps_the_class_token_only():
     finally:
         del os.environ["PEEKVIT_AMD_BACKEND"]
     assert rel_l2(y.cpu(), ref.cpu()) < 5e-3
+    # ... and against the CPU ORACLE (rankvit.py:74 with budget 0 in the reference's arithmetic) at the contract's tolerance (round 3)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    assert rel_l2(y.cpu(), O.vit_forward(x.cpu(), sd, cfg, "fp32", rankvit_layers=[1, 2], budget=0.0)) < TOL_CONTRACT
     m.train()
     torch.nn.functional.cross_entropy(m(x), torch.arange(3, device=DEV)).backward()
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
@@ -719,3 +728,7 @@ def test_patch_size_whose_columns_are_not_a_multiple_of_64():
         finally:
             del os.environ["PEEKVIT_AMD_BACKEND"]
     assert rel_l2(y.cpu(), ref.cpu()) < 2e-3
+    # ... and against the CPU ORACLE at the contract's tolerance (round 3)
+    cfg = dict(image_size=224, patch_size=14, num_layers=2, num_heads=4, hidden_dim=256, mlp_dim=1024, num_classes=50)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    assert rel_l2(y.cpu(), O.vit_forward(x.cpu(), sd, cfg, "fp32")) < TOL_CONTRACT
