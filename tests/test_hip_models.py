@@ -732,3 +732,55 @@ def test_patch_size_whose_columns_are_not_a_multiple_of_64():
     cfg = dict(image_size=224, patch_size=14, num_layers=2, num_heads=4, hidden_dim=256, mlp_dim=1024, num_classes=50)
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     assert rel_l2(y.cpu(), O.vit_forward(x.cpu(), sd, cfg, "fp32")) < TOL_CONTRACT
+
+
+# ---- round 3: the matrix of arithmetic-variant switches, each pinned to the oracle ---------------------------------------------------------
+# Every module-level switch of peekvit_amd.engine that selects a DIFFERENT sequence of kernels for the same logits (and the persistent GEMM
+# launch of the library) against the CPU oracle at the contract's tolerance, on two widths: 384 (full-row GEMM with the fused LayerNorm) and
+# 768 (LayerNorm folded into the GEMM epilogues), at a batch where the 256-row kernels, the folds and the class-row last block all engage.
+_VARIANT_CFGS = {
+    "w384": dict(image_size=224, patch_size=16, num_layers=2, num_heads=6, hidden_dim=384, mlp_dim=1536, num_classes=100),
+    "w768": dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072, num_classes=100),
+}
+_VARIANTS = [("default", None, None), ("no LayerNorm folding", "_FOLD_LN", False), ("no full-row GEMM", "_FULLROW_LN", False),
+             ("row-block fused LayerNorm", "_FUSE_LN", True), ("no split-K", "_SMALL_M_SPLITK", False), ("last block on all rows", "_LAST_BLOCK_ROWS", False),
+             ("two streams", "_STREAMS", 2), ("large batch: persistent GEMM launch", "BIG", None), ("large batch, one tile per workgroup", "PF", 0)]
+_variant_ref = {}
+
+
+@pytest.mark.parametrize("width", list(_VARIANT_CFGS))
+@pytest.mark.parametrize("label,flag,value", _VARIANTS)
+def test_every_arithmetic_variant_switch_meets_the_contract(monkeypatch, width, label, flag, value):
+    from peekvit_amd import _lib, engine
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = _VARIANT_CFGS[width]
+    # the stream split needs >= 256 images (engine._STREAMS_MIN_BATCH); the persistent GEMM launch needs >= 512 tiles (so does its "off" switch)
+    B = 16 if flag not in ("_STREAMS", "PF", "BIG") else 512 if width == "w384" else 256
+    m = VisionTransformer(**cfg)
+    synth.load_synth_weights(m, cfg, "vit", seed=0)
+    m = m.eval().to(DEV)
+    x = torch.from_numpy(synth.synth_images(B, cfg["image_size"], seed=3)).to(DEV)
+    key = (width, B)
+    if key not in _variant_ref:                     # the oracle on the first 16 images (a forward is per-image: any batch's first rows must agree)
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        _variant_ref[key] = O.vit_forward(x[:16].cpu(), sd, cfg, "fp32")
+    lib16 = _lib.load("f16")
+    if flag == "PF":
+        lib16.pv_debug_set_gemm_pf(value)
+    elif flag is not None and flag != "BIG":
+        monkeypatch.setattr(engine, flag, value)
+    try:
+        n0 = ops_launches()
+        with torch.no_grad():
+            y = m(x)
+        assert ops_launches() > n0
+    finally:
+        if flag == "PF":
+            lib16.pv_debug_set_gemm_pf(-1)
+    err = rel_l2(y[:16].cpu(), _variant_ref[key])
+    assert err < TOL_CONTRACT, (width, label, err)
+
+
+def ops_launches():
+    from peekvit_amd import ops
+    return ops.launch_count
