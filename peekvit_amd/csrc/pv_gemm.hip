@@ -706,9 +706,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         en0 = n0 + wc * 64 + ((lane >> 4) << 3);
     }
     const int g = lane >> 4, i16 = lane & 15;
-    // PF: the next tile's first K-tile goes into buffer 0 NOW - the epilogue images live in buffer 1 only - so that its 64 KiB travel under
-    // this epilogue's arithmetic instead of in front of the next K loop.  It is the OLDEST vector-memory operation of the epilogue: the
-    // s_waitcnt vmcnt(0) in front of the first store retires it without waiting for any store.
+    // PF: the next tile's first K-tile goes into buffer 0 during this epilogue - its images live in buffer 1 only - so that the 64 KiB travel
+    // under the epilogue's arithmetic instead of in front of the next K loop.  It is OLDER than every store of the epilogue, so a wait that
+    // leaves the stores in flight retires it: mode 1 issues it here and waits (vmcnt(0)) in front of the first store; mode 2 (shipped) issues
+    // it in pieces below and waits with a count at the end of the epilogue.
     const bool pf_next = PF && PFM && has_next;
     if (PFM == 1 && pf_next) {
 #pragma unroll
@@ -1207,7 +1208,10 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
 // KiB (2.6 - 3.2 k cycles at batch 2048; 5 - 8 k when few rounds of tiles keep all CUs' prologues in step, vit_small) nor the 1.0 - 1.4 us
 // the dispatcher leaves between two workgroups of a CU.  The plain persistent loop (measured above pv_gemm256_kernel) lost because the
 // next tile's first wait sat behind the previous tile's stores in the in-order vmcnt queue; here the prefetch is issued BEFORE any store
-// of the epilogue and retired in front of the first one.  A tile's arithmetic is untouched: outputs are bit-identical.
+// of the epilogue (in pieces under its first pass / behind its first residual rows) and retired by a COUNTED wait at its end that leaves
+// the stores in flight (PV_PF_MODE 2; mode 1 = all of it at the epilogue's start, retired in front of the first store).  A tile's
+// arithmetic is untouched: outputs are bit-identical.  Per-tile stamps of both launches: profiles/r03_gemm_stamps_*.txt; what had to be
+// true before it was faster than one tile per workgroup (no VGPR spill, bias through LDS, no K < 256 bypass edge): DESIGN.md section 14.
 template <int EPI>
 __global__ __launch_bounds__(512) void pv_gemm256_pf_kernel(const GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
