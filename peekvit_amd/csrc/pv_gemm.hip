@@ -132,6 +132,7 @@ struct GemmDev {
     int rpi, rpo, row_off, qcols;
     float qscale;
     int tiles_m, tiles_n;
+    int fr_full, fr_half;      // full-row kernel, split remainder: fr_full 128-row tiles (a multiple of 8) + fr_half 64-row tiles; 0, 0 = tiles_m plain tiles
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
     int gc;                    // column tiles per raster chunk (256^2 kernel): the tile list is chunk-major, so an XCD keeps the
                                // same gc weight tiles while it streams the activation row panels of its share of the rows
@@ -1640,7 +1641,24 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    const int m0 = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
+    // Split remainder (round 3): 788 tiles of 128 rows on 256 CUs are 3.08 rounds - a quarter of the last one idle in every XCD.  With
+    // fr_full > 0 the launch is whole rounds of 128-row tiles plus ONE round of 64-row tiles over the remaining rows; every XCD (workgroup id
+    // & 7) takes an equal share of both lists, full tiles first.  A 64-row tile is this same code with wave group 1 (rows 64 - 127) idle:
+    // no A staging and no MFMAs for it, one epilogue pass - per row the arithmetic is unchanged.
+    int m0_;
+    bool half = false;
+    if (p.fr_full > 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, fper = p.fr_full >> 3, q = p.fr_half >> 3, r = p.fr_half & 7;
+        if (j < fper) m0_ = (x * fper + j) * BM;
+        else {
+            const int hj = j - fper;
+            if (hj >= q + (x < r ? 1 : 0)) return;          // (whole workgroup: before any barrier)
+            m0_ = p.fr_full * BM + ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + hj) * 64;
+            half = true;
+        }
+    } else m0_ = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
+    const int m0 = m0_;
+    const bool skip_mm = half && wm == 1;              // (wave-uniform)
     const int g = lane >> 4, i16 = lane & 15;
 
     // accumulators start from the bias (ordinary loads, consumed before any LDS-DMA is issued)
@@ -1673,7 +1691,8 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     auto stage = [&](int buf, int kt) {
         char* l = smem + buf * BUF + wid * 1024;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pv_glds16(ga[j] + kt * BK, l + j * 8192);
+        for (int j = 0; j < 2; ++j)
+            if (j == 0 || !half) pv_glds16(ga[j] + kt * BK, l + j * 8192);          // (workgroup-uniform: every wave issues the same number of pieces)
 #pragma unroll
         for (int j = 0; j < NT; ++j) pv_glds16(gw[j] + kt * BK, l + A_BYTES + j * 8192);
     };
@@ -1693,6 +1712,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         __builtin_amdgcn_s_barrier();                      // tile kt has landed for every wave; buffer cur ^ 1 is no longer read
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if (skip_mm) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[4], wf[NT];
@@ -1717,6 +1737,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     if (p.ln_out) pv_ln_load_affine<NCH>(ln_g, ln_b, p.ln_gamma, p.ln_beta, nvec, lane);
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
+        if (ps == 1 && half) break;                        // (workgroup-uniform) a 64-row tile has no second pass
         // this wave's 8 rows of the pass: their residual segments first (NCH x 16 B per lane and row, whole contiguous rows)
         f32x4 rr[8][NCH];
         float sc[8], lsc[8];
@@ -1798,6 +1819,13 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     }
 }
 
+static int g_pv_frsplit = -1;
+extern "C" void pv_debug_set_fullrow_split(int on) { g_pv_frsplit = on; }
+static bool pv_fullrow_split_enabled() {
+    static const int env = [] { const char* e = getenv("PV_FULLROW_SPLIT"); return e ? atoi(e) : 1; }();
+    return g_pv_frsplit >= 0 ? g_pv_frsplit != 0 : env != 0;
+}
+
 template <int NT>
 static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
@@ -1805,7 +1833,21 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH(pv_gemm_fullrow_kernel<NT>, dim3((unsigned)p.tiles_m), dim3(512), lds, stream, p);
+    // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
+    // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
+    GemmDev q = p;
+    q.fr_full = 0; q.fr_half = 0;
+    unsigned grid = (unsigned)p.tiles_m;
+    const int cus = pv_cu_count() & ~7;
+    if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
+        const int full = p.tiles_m / cus * cus;
+        const int64_t rem = p.M - (int64_t)full * 128;
+        if (rem > 0 && rem <= (int64_t)cus * 64) {
+            q.fr_full = full; q.fr_half = (int)((rem + 63) / 64);
+            grid = 8u * (unsigned)(full / 8 + (q.fr_half + 7) / 8);
+        }
+    }
+    PV_LAUNCH(pv_gemm_fullrow_kernel<NT>, dim3(grid), dim3(512), lds, stream, q);
     return pv_check_launch();
 }
 

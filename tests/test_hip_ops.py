@@ -217,7 +217,11 @@ def test_gemm_kernels_agree_bitwise(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2048 + 77, 768, 768), (1000, 768, 3072), (520, 1024, 256),
-                                   (3000, 384, 384), (1001, 384, 1536), (2100, 256, 768), (700, 512, 512), (128 * 97 + 5, 384, 64), (50, 512, 1536)])
+                                   (3000, 384, 384), (1001, 384, 1536), (2100, 256, 768), (700, 512, 512), (128 * 97 + 5, 384, 64), (50, 512, 1536),
+                                   # more than one round of 128-row tiles on 256 CUs with a remainder of at most half a round: the split remainder
+                                   # (whole rounds of 128-row tiles + one round of 64-row tiles, ragged last tile) of the full-row kernel; and
+                                   # a remainder beyond half a round (plain 128-row tiles)
+                                   (256 * 128 + 5003, 384, 384), (2 * 256 * 128 + 64 * 256 - 1, 256, 128), (256 * 128 + 20000, 512, 128)])
 def test_gemm_fused_layernorm_bit_identical_to_separate_kernels(ops, M, N, K):
     """GEMM with fused LayerNorm (full-row tile for N = 256 / 384 / 512, row-block kernel otherwise) == plain GEMM followed by
     pv_layernorm_bf16, bit for bit (with and without row scale); N = 384 ... also cover the full-row kernel WITHOUT LayerNorm against the
