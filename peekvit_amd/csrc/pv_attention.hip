@@ -35,9 +35,14 @@ extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbo
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
+// Probabilities are packed as p * 2^PV_P_SHIFT in the fp16 build (the fp16 MFMA flushes subnormal operands; the factor cancels in O / l).
+// Round 4: 2^10 instead of round 3's 2^14 - p <= 1 leaves SIX bits of fp16 headroom instead of two (an exponent computed against a
+// maximum that is off by up to 4 score units still packs a finite value; round 3's carried-maximum experiment turned exactly such
+// values into inf and then NaN rows), and everything down to p = 6e-8 stays a normal number: at most 197 x 6e-8 = 1.2e-5 of a row's
+// mass can flush, two orders below the contract.  The streaming kernel (S > 416, wide heads) now applies the same scale.
 #ifndef PV_P_SHIFT
 #ifdef PV_OPERAND_F16
-#define PV_P_SHIFT 14.0f
+#define PV_P_SHIFT 10.0f
 #else
 #define PV_P_SHIFT 0.0f
 #endif
@@ -186,9 +191,9 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         pv_score_guard(m, flag);
         // p = exp(s - m) = exp2(s*log2e - m*log2e): one FMA + v_exp per score.
-        // (+ PV_P_SHIFT: the probabilities are packed as p * 2^14.  The fp16 MFMA path flushes subnormal operands, and with scores spread
+        // (+ PV_P_SHIFT: the probabilities are packed as p * 2^10.  The fp16 MFMA path flushes subnormal operands, and with scores spread
         //  over ~17 units more than half of a row's p = exp(s - m) lie below fp16's smallest normal 6.1e-5 - up to 0.7 % of a row's mass;
-        //  scaled, everything down to 3.7e-9 stays normal, and the factor cancels in O / l.  Free: it rides in the FMA's addend.)
+        //  scaled, everything down to 6e-8 stays normal, and the factor cancels in O / l.  Free: it rides in the FMA's addend.)
         // Measured and NOT kept (round 3, scripts/attn_ab.py, profiles/r03_attention_ab.json): the exp argument as a packed FMA and the
         // row sum as one more MFMA tile (P^T times a tile of ones) take 30 % of the wave's VALU instructions away and not one percent of
         // the kernel's time - it is not VALU-bound, whatever the 54 % VALU issue utilisation suggests.
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256) void pv_attn_stream_kernel(const uint16_t* __r
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
         const float mn = fmaxf(m, bm);             // finite from the first block on (key 0 is never masked)
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
-        const float nm = -mn * LOG2E;
+        const float nm = -mn * LOG2E + PV_P_SHIFT;      // p * 2^PV_P_SHIFT (fp16 build): o and l carry the same factor, it cancels in o / l
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)

@@ -199,6 +199,17 @@ __device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __rest
 
 // normalise in place: v <- (v - mean) * rstd * gamma + beta   (lanes beyond nvec keep zeros).  gamma / beta already in registers
 // (the lane's NCH float4 of each): ONE arithmetic for the standalone kernel and the GEMM-fused passes.
+// A scalar fp32 add the compiler cannot fold into a packed (v_pk_add_f32) tree.  Round 4: v_pk_*_f32 whose LOW result reads the HIGH register
+// of a source pair (an op_sel bit set - what hipcc emits for a horizontal add of a packed pair, or to broadcast a value that sits in an
+// odd register) returned wrong low results in lanes 48-63 about 1e-5 of the time on gfx950 while vector-memory loads were returning into
+// VGPRs (scripts/dbg/gelu_glitch.py); the sums below run under exactly such loads in the GEMM-fused LayerNorm
+// epilogues.  Same operation, same rounding as `a + b`.
+__device__ __forceinline__ float pv_add_s(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int NCH>
 __device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
     // every operation rounded on its own: which multiply-adds hipcc contracts into FMAs depends on the code this is inlined into, and the
@@ -206,14 +217,14 @@ __device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&g
 #pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
+    for (int j = 0; j < NCH; ++j) s += pv_add_s(r.v[j].x + r.v[j].y, r.v[j].z + r.v[j].w);
     const float mean = pv_wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (lane + 64 * j < nvec) {
             float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+            q += pv_add_s(a * a + b * b, c * c + d * d);
         }
     }
     const float rstd = 1.0f / sqrtf(pv_wave_sum(q) / (float)D + eps);

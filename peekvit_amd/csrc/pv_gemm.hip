@@ -84,9 +84,44 @@ __device__ __forceinline__ void pv_gelu_bits2(float x0, float x1, uint32_t& b0, 
 #ifndef PV_GELU_GLOBAL_MODE
 #define PV_GELU_GLOBAL_MODE 1
 #endif
-__device__ __forceinline__ float pv_gelu_poly_g(float x, const f32x4 c) {
+__device__ __forceinline__ float pv_gelu_poly_g(float x, f32x4 c) {
 #if PV_GELU_GLOBAL_MODE == 0
     return pv_gelu_poly(x, c);
+#elif PV_GELU_GLOBAL_MODE == 2      // diagnostic (round 4): the packed form, 4+ idle cycles between the wait for the entry and its first read
+    asm volatile("s_nop 3" : "+v"(c));
+    return pv_gelu_poly(x, c);
+#elif PV_GELU_GLOBAL_MODE == 3      // diagnostic: the packed FMA writes FRESH registers (early-clobber), never the load's destination registers
+    pv_f32x2_t r;
+    const pv_f32x2_t c02 = {c[0], c[1]}, c13 = {c[2], c[3]}, xx = {x, x};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(c13), "v"(xx), "v"(c02));
+    return pv_fma_s(x, pv_mul_s(x, r[1]), r[0]);
+#elif PV_GELU_GLOBAL_MODE == 4      // diagnostic: packed FMA as shipped, its CONSUMERS as compiler-visible C (no inline asm behind the packed result)
+    const pv_f32x2_t c02 = {c[0], c[1]}, c13 = {c[2], c[3]}, xx = {x, x};
+    const pv_f32x2_t r = __builtin_elementwise_fma(c13, xx, c02);
+    return fmaf(x, x * r[1], r[0]);
+#elif PV_GELU_GLOBAL_MODE == 6      // diagnostic: packed asm, FRESH destination, x broadcast by op_sel_hi (the modifier hipcc's form carries)
+    pv_f32x2_t r;
+    const pv_f32x2_t c02 = {c[0], c[1]}, c13 = {c[2], c[3]}, xx = {x, 0.0f};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(c13), "v"(xx), "v"(c02));
+    return pv_fma_s(x, pv_mul_s(x, r[1]), r[0]);
+#elif PV_GELU_GLOBAL_MODE == 9      // diagnostic: packed asm, FRESH destination, x taken from the HIGH register of its pair for BOTH results (op_sel:[0,1,0])
+    pv_f32x2_t r;
+    const pv_f32x2_t c02 = {c[0], c[1]}, c13 = {c[2], c[3]}, xx = {0.0f, x};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(r) : "v"(c13), "v"(xx), "v"(c02));
+    return pv_fma_s(x, pv_mul_s(x, r[1]), r[0]);
+#elif PV_GELU_GLOBAL_MODE == 7      // diagnostic: packed asm, no op_sel, destination = the ADDEND's registers (in place over c0 | c2, as hipcc's form)
+    pv_f32x2_t c02 = {c[0], c[1]};
+    const pv_f32x2_t c13 = {c[2], c[3]}, xx = {x, x};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c02) : "v"(c13), "v"(xx));
+    return pv_fma_s(x, pv_mul_s(x, c02[1]), c02[0]);
+#elif PV_GELU_GLOBAL_MODE == 8      // diagnostic: packed asm, no op_sel, destination = the MULTIPLICAND's registers (over c1 | c3)
+    pv_f32x2_t c13 = {c[2], c[3]};
+    const pv_f32x2_t c02 = {c[0], c[1]}, xx = {x, x};
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(c13) : "v"(xx), "v"(c02));
+    return pv_fma_s(x, pv_mul_s(x, c13[1]), c13[0]);
+#elif PV_GELU_GLOBAL_MODE == 5      // diagnostic: scalar FMAs as INLINE ASM (an asm statement is the first reader of the loaded registers)
+    const float r0 = pv_fma_s(c[2], x, c[0]), r1 = pv_fma_s(c[3], x, c[1]);
+    return pv_fma_s(x, pv_mul_s(x, r1), r0);
 #else
     const float r0 = fmaf(c[2], x, c[0]), r1 = fmaf(c[3], x, c[1]);
     return pv_fma_s(x, pv_mul_s(x, r1), r0);
@@ -1788,8 +1823,10 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                 const int idx = lane + 64 * c;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (idx < nvec) v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((idx ^ (row & 7)) << 4));
-                r.v[c] = idx < nvec ? make_float4(fmaf(sc[j], v[0], rr[j][c][0]), fmaf(sc[j], v[1], rr[j][c][1]), fmaf(sc[j], v[2], rr[j][c][2]),
-                                                  fmaf(sc[j], v[3], rr[j][c][3]))
+                // (scalar FMAs by inline asm: packed, hipcc broadcasts a row scale that sits in an odd register with an op_sel bit - the
+                //  form that misreads lanes 48-63 while this pass's residual rows are still returning, pv_common.h pv_add_s)
+                r.v[c] = idx < nvec ? make_float4(pv_fma_s(sc[j], v[0], rr[j][c][0]), pv_fma_s(sc[j], v[1], rr[j][c][1]), pv_fma_s(sc[j], v[2], rr[j][c][2]),
+                                                  pv_fma_s(sc[j], v[3], rr[j][c][3]))
                                     : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
             }
             if (m < p.M) {
@@ -1809,7 +1846,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                     for (int c = 0; c < NCH; ++c) {
                         const int idx = lane + 64 * c;
                         if (idx < nvec) {
-                            u32x2 pk = {pv_pack_bf16x2(r.v[c].x * lsc[j], r.v[c].y * lsc[j]), pv_pack_bf16x2(r.v[c].z * lsc[j], r.v[c].w * lsc[j])};
+                            u32x2 pk = {pv_pack_bf16x2(pv_mul_s(r.v[c].x, lsc[j]), pv_mul_s(r.v[c].y, lsc[j])), pv_pack_bf16x2(pv_mul_s(r.v[c].z, lsc[j]), pv_mul_s(r.v[c].w, lsc[j]))};
                             PV_STORE16(o + idx, pk);
                         }
                     }

@@ -43,9 +43,10 @@ class GraphedForward:
             # what gets captured: the guarded fp16 forward (its first node zeroes the flag word, the replayer reads it) - unless mode "auto"
             # has already sent this model to the fallback mode (parameter bounds, or three trips in a row during warm-up): that capture
             # neither zeroes nor writes the word, so the replayer must not read it (a stale bit would send every replay to eager)
-            self._guarded = engine._mode() == "auto" and not engine.guard_state(self.model).unsafe
+            # (or the warm-up forwards' self-check measured this model / budget / batch size outside the contract on fp16 operands)
             with torch.cuda.graph(self.graph, stream=side):
                 self.static_out = self.model(self.static_in)
+            self._guarded = engine._mode() == "auto" and engine.last_forward_guarded()
         torch.cuda.current_stream().wait_stream(side)
 
     def refresh(self):

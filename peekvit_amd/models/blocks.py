@@ -90,10 +90,10 @@ class NoiseBlock(nn.Module):
             raise ValueError("std is not supported anymore. Please use snr instead.")
 
     def forward_snr(self, x):
-        if self.snr_db == 0:
-            return x + 0
-        power = x.pow(2).mean(dim=-1, keepdim=True) / (10 ** (self.snr_db / 10))
-        return x + torch.randn_like(x) * power.sqrt()
+        # snr 0 means "no noise" in the reference, and it still DRAWS the noise and multiplies it by 0 (models/blocks.py:124-129): the
+        # generator advances exactly as there, so a seeded noise sweep stays sample-for-sample comparable after a 0.0 entry
+        std = (x.pow(2).mean(dim=-1, keepdim=True) / (10 ** (self.snr_db / 10))).sqrt() if self.snr_db != 0 else 0
+        return x + torch.randn_like(x) * std
 
     def forward_std(self, x):
         return x + torch.randn_like(x) * self.std

@@ -120,8 +120,8 @@ class RankVisionTransformer(_ViTBase):
                 tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            return engine.run_guarded(self, x, lambda: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, x), _pos_added=True,
-                                                                                                   _rows=self.num_class_tokens)))
+            body = lambda xs: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
+            return engine.run_guarded(self, x, lambda: body(x), probe=body, probe_key=repr(getattr(self, "current_budget", None)))
         return self._composite_head(self.encoder(self._composite_tokens(x)))
 
     def set_budget(self, budget: float):

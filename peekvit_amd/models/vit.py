@@ -209,7 +209,7 @@ class VisionTransformer(_ViTBase):
                 tokens = self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            return engine.run_guarded(self, x, lambda: engine.forward_split(x, self._hip_forward))
+            return engine.run_guarded(self, x, lambda: engine.forward_split(x, self._hip_forward), probe=self._hip_forward)
         return self._composite_head(self.encoder(self._composite_tokens(x)))
 
     def _hip_forward(self, x: torch.Tensor):

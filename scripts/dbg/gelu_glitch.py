@@ -23,6 +23,13 @@ for tag in sys.argv[1:]:
         ga = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), M=M, N=N, K=K, lda=K, ldw=K, ldo=N, epilogue=PV_EPI_BIAS_GELU_BF16)
         assert lib.pv_gemm_bf16(C.byref(ga), st) == 0
         err = (out.double() - ref).abs()
-        bad = int((err > 0.02 * ref.abs() + 1e-3).sum())
+        badm = err > 0.02 * ref.abs() + 1e-3
+        bad = int(badm.sum())
         bad_runs += bad > 0; bad_total += bad
+        if bad:
+            cols = torch.cat([cols, badm.nonzero()[:, 1].cpu()]) if "cols" in dir() else badm.nonzero()[:, 1].cpu()
     print(f"variant '{tag}': runs with glitches {bad_runs}/40, wrong elements {bad_total}", flush=True)
+    if bad_total:
+        # which of a lane's four consecutive columns (c & 3: the two pv_gelu_lut2 pairs are (0, 1) and (2, 3)) and which 16-lane group (c >> 2 & 3)
+        print("   wrong elements by (column & 3):", torch.bincount(cols & 3, minlength=4).tolist(), " by lane group ((column >> 2) & 3):", torch.bincount((cols >> 2) & 3, minlength=4).tolist(), flush=True)
+        del cols

@@ -111,7 +111,12 @@ def test_noise_block_matches_the_reference_semantics():
     want = x + torch.randn_like(x) * torch.sqrt((x ** 2).mean(-1, keepdim=True) / 10 ** (20.0 / 10))
     assert torch.equal(got, want)
     nb.set_value(0)
+    torch.manual_seed(9)
     assert torch.equal(nb(x), x)
+    after = torch.get_rng_state()
+    torch.manual_seed(9)
+    torch.randn_like(x)                   # snr 0 adds nothing but still DRAWS (reference blocks.py:127): a seeded sweep stays comparable after it
+    assert torch.equal(after, torch.get_rng_state())
     snr = 10 * torch.log10((x ** 2).mean() / ((got - x) ** 2).mean())
     assert abs(float(snr) - 20.0) < 1.5                                              # the realised SNR is the requested one
     td = NoiseBlock("token_drop", prob=0.3)

@@ -193,26 +193,40 @@ def test_residualvit_parity(golden, tag, name, gb):
     cfg, m = _model("res", name, **extra)
     x = _x(cfg)
     sd = synth.synth_state_dict(dict(cfg, **extra), "residualvit")
+    from peekvit_amd import engine
     for b in (0.2, 0.5, 1.0):
         m.set_budget(b)
+        t0, f0 = engine.selfcheck_trips, engine.fallback_count
         with torch.no_grad():
             logits = m(x.to(DEV)).cpu().numpy()
+        # mode "auto" measures every new (parameters, budget, batch size) against its split-operand arithmetic on the first forward
+        # (engine.run_guarded, "contract self-check"); a trip means THIS forward already came from the bf16x3 mode
+        tripped = engine.selfcheck_trips > t0
+        assert engine.fallback_count - f0 == (1 if tripped else 0)
         masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
+        assert masks.shape[1] == x.shape[0]                                       # the probe's slice never overwrites what the blocks remember
         thr = torch.stack([blk.residual_gate.threshold.cpu() for blk in m.encoder.layers])      # left behind like ResidualGate.forward does (utils.py:131)
         assert thr.shape == (cfg["num_layers"], x.shape[0], 1, 1) and bool(((thr > 0) & (thr < 1)).all())
         tr = {}
-        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, _op(), trace=tr).numpy()
-        assert rel_l2(logits, same) < TOL_SAME
+        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "fp32" if tripped else _op(), trace=tr).numpy()
+        assert rel_l2(logits, same) < (1e-4 if tripped else TOL_SAME)
         assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
         if "thresholds" in tr:
             assert np.abs(thr.view(cfg["num_layers"], -1).numpy() - torch.stack(tr["thresholds"]).view(cfg["num_layers"], -1).numpy()).max() < 5e-3
         assert np.abs(masks[0] - g[f"{tag}_b{b}_masks"][0]).max() < 1e-5      # first block sees fp32-identical input
         assert np.abs(masks - g[f"{tag}_b{b}_masks"]).max() < 2e-3            # every block's mask vs the REAL reference's
         if np.linalg.norm(g[f"{tag}_b{b}_logits"]) > 0:
-            # the contract tolerance, on every case but ONE, whose observed value is committed instead of a blanket allowance
-            # (profiles/r03_parity_observed.json): the 2-layer, 18-token toy with the reference's gate bias of 10 at budget 0.2 - no
-            # averaging over tokens / width behind its soft masks - measures 1.07e-3 with fp16 operands (bf16x3: 6e-6)
-            assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < (1.25e-3 if (tag, b) == ("vit_micro", 0.2) else TOL_CONTRACT)
+            # the contract tolerance on EVERY case.  Round 3 allowed 1.25e-3 on one of them: the 2-layer, 18-token, width-128 toy with the
+            # reference's gate bias of 10 at budget 0.2 measures 1.07e-3 on plain fp16 operands with no guard bit raised (the CPU oracle with
+            # the same rounding points: 1.2e-3 - thirteen rounding sites of 1 - 4.6e-4 each on a model too small to average them out; its
+            # masks are 0.05 .. 0.44, nowhere near the gate threshold).  The self-check sees exactly that and answers from bf16x3.
+            assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_CONTRACT
+            if (tag, b) == ("vit_micro", 0.2):
+                assert tripped and rel_l2(logits, g[f"{tag}_b{b}_logits"]) < 1e-4
+        with torch.no_grad():                                                    # the verdict is kept: no second probe, same arithmetic again
+            c0 = engine.selfcheck_count
+            again = m(x.to(DEV)).cpu().numpy()
+        assert engine.selfcheck_count == c0 and np.array_equal(again, logits)
 
 
 def test_error_contract_matches_reference():
@@ -335,10 +349,15 @@ def test_uint8_nhwc_input_is_bit_identical_to_normalised_fp32_nchw():
     raw = torch.randint(0, 256, (3, cfg["image_size"], cfg["image_size"], 3), generator=gen, dtype=torch.uint8)
     mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
     x = (raw.permute(0, 3, 1, 2).float().div(255.0) - mean) / std          # torchvision ToTensor + Normalize
-    with torch.no_grad():
+    from peekvit_amd import engine
+    with torch.no_grad(), engine.precision("f16"):                        # the same arithmetic on both inputs: bit-identical
         a = m(x.contiguous().to(DEV)).cpu()
         b = m(raw.to(DEV)).cpu()
     assert torch.equal(a, b)
+    with torch.no_grad():                                                  # mode "auto" (whatever its self-check decides for these noise images)
+        a = m(x.contiguous().to(DEV)).cpu()
+        b = m(raw.to(DEV)).cpu()
+    assert rel_l2(b.numpy(), a.numpy()) < 1e-5
 
 
 def test_vit_384_long_sequence_forward():
@@ -468,6 +487,8 @@ def test_rank_norms_come_from_the_fc2_epilogue(monkeypatch):
     m.set_budget(0.5)
     # 224 images: even the fc2 before layer 9 (224 x 50 rows x 3 column tiles = 132 tiles) runs on the 256-row tile kernel
     x = torch.randn(224, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        m(x)                                       # (the first forward of a new batch size also runs mode auto's self-check probe: keep it out of the kernel table)
     with torch.no_grad(), ops.KernelTimer() as kt:
         fused = m(x)
     torch.cuda.synchronize()

@@ -457,3 +457,45 @@ def test_attention_at_the_headline_batch_is_finite_deterministic_and_close_to_fp
     q, k, v = (qkv[idx].double().view(3, S, 3, H, dh).permute(2, 0, 3, 1, 4)[i] for i in range(3))
     ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(3, S, H * dh)
     assert rel_l2(first[idx].double().cpu(), ref.cpu()) < 4e-4
+
+
+def test_attention_streaming_kernel_fp16_keeps_small_probabilities(ops):
+    """Round 3 ADVICE: the LDS-resident kernel packs its probabilities as p * 2^k in the fp16 build (the fp16 MFMA flushes subnormal
+    operands: up to 0.7 % of a row's mass vanished from P.V while still counted in l), the streaming kernel (S > 416, wide heads) did
+    not.  Both do now (2^10): fp16 operands, scores spread over ~17 units, S = 577 and a 128-wide head (both streamed) against fp64, at the
+    bound the resident kernel is held to at the headline batch."""
+    from peekvit_amd import engine
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for (B, S, H, dh) in [(2, 577, 4, 64), (1, 300, 2, 128)]:
+        with engine.precision("f16"):
+            qkv = torch.randn(B, S, 3 * H * dh, generator=g, device=DEV)
+            qkv[..., :H * dh] *= 2.2 * dh ** -0.5          # scores ~ N(0, 2.2^2): row spread ~ 17 units
+            qkv = qkv.to(torch.float16)
+            out = torch.full((B, S, H * dh), float("nan"), dtype=torch.float16, device=DEV)
+            ops.attention(qkv, out, B, S, H, dh)
+        q, k, v = (qkv.double().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+        ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(B, S, H * dh)
+        assert bool(torch.isfinite(out).all())
+        assert rel_l2(out.double().cpu(), ref.cpu()) < 4e-4
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(2560, 3072 + 64, 768, 128), (16384, 3072, 768, 256), (2560, 3072, 768, 256)])
+def test_gemm_gelu_is_elementwise_exact_on_both_tile_kernels(ops, M, N, K, tile):
+    """Round 3 ADVICE / round 4 finding: the GELU epilogue ELEMENT BY ELEMENT against fp64 gelu(A W^T + b) at the fc1 shape, three launches
+    each - a norm cannot see a polynomial that is wrong for one value in 1e5 (the 128^2 kernel's packed form with an op_sel bit was:
+    DESIGN.md section 14, tests/test_isa_audit.py).  N = 3136 takes the 128^2 kernel (table gathered from global memory), the others
+    the 256^2 kernel (table in LDS; 16384 rows = the prefetching persistent launch).  16-bit operands are exact in the reference, so what
+    is left is fp32 accumulation order, the table's 8e-7 and the 16-bit output rounding (2^-9 relative)."""
+    from peekvit_amd._lib import PV_EPI_BIAS_GELU_BF16
+    assert ops.gemm_tile_rows(M, N, K, PV_EPI_BIAS_GELU_BF16) == tile
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    w = ((torch.rand(N, K, generator=g, device=DEV) * 2 - 1) / math.sqrt(K) * 3).to(torch.bfloat16)      # pre-activations ~ N(0, 3): every table interval
+    bias = (torch.rand(N, generator=g, device=DEV) * 2 - 1) * 0.1
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double())
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, w, bias, out, PV_EPI_BIAS_GELU_BF16)
+        err = (out.double() - ref).abs()
+        bad = err > 0.006 * ref.abs() + 2e-5
+        assert int(bad.sum()) == 0, f"{int(bad.sum())} of {M * N} elements off: worst {float(err.max()):.3e}"

@@ -467,3 +467,55 @@ def test_graph_replay_of_a_model_the_guard_sends_to_the_fallback_mode(golden):
         assert engine.fallback_count == n2
         assert torch.equal(y2, y3) and torch.equal(y2, m(x)) and rel_l2(y2.cpu().numpy(), ref) < TOL_NORTH_STAR
     engine.reset_guard(m)
+
+
+def test_contract_self_check_of_mode_auto(monkeypatch):
+    """Round 4: the first model-level forward of every (parameters, budget setting, batch size) also runs its first images in the bf16x3 mode
+    and compares (engine.run_guarded): a model / input on which plain fp16 operand rounding adds up to more than the limit is answered from
+    bf16x3 - measured, not inferred from a flag bit.  Mechanics: one probe per key; a verdict "x3" makes that key's forwards bitwise the
+    bf16x3 mode's and counts as a fallback; what the blocks remember (masks) stays the whole batch's; IMAGES = 0 switches it off."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_tiny")
+    x = torch.from_numpy(synth.synth_images(12, cfg["image_size"], seed=3)).to(DEV)
+    c0, t0, f0 = engine.selfcheck_count, engine.selfcheck_trips, engine.fallback_count
+    with torch.no_grad():
+        a = m(x)
+        assert engine.selfcheck_count == c0 + 1 and engine.selfcheck_last[1] == min(12, engine.SELFCHECK_IMAGES)
+        assert 1e-5 < engine.selfcheck_last[0] < engine.SELFCHECK_LIMIT and engine.selfcheck_trips == t0        # fp16 operands: ~5e-4 on this model
+        b = m(x)
+        assert engine.selfcheck_count == c0 + 1 and torch.equal(a, b)                                          # the verdict is kept
+        m(x[:5])
+        assert engine.selfcheck_count == c0 + 2                                                                # another batch size: another key
+        with engine.precision("f16"):
+            raw = m(x)
+        assert torch.equal(raw, a)                                                                             # the probe changed nothing in the forward proper
+    # an impossible limit: the same model is now measured outside it, and answered from the split-operand arithmetic
+    monkeypatch.setattr(engine, "SELFCHECK_LIMIT", 1e-6)
+    engine.reset_guard(m)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = m(x)
+        with engine.precision("bf16x3"):
+            ref = m(x)
+        assert engine.selfcheck_trips == t0 + 1 and engine.fallback_count == f0 + 1 and torch.equal(c, ref) and not torch.equal(c, a)
+        d = m(x)
+        assert engine.fallback_count == f0 + 2 and engine.selfcheck_count == c0 + 3 and torch.equal(d, ref)    # straight to the fallback: no probe, no fp16 attempt
+        assert not engine.guard_state(m).unsafe                                                                # the verdict is per key, not sticky for the module
+    monkeypatch.setattr(engine, "SELFCHECK_IMAGES", 0)
+    engine.reset_guard(m)
+    with torch.no_grad():
+        e = m(x)
+    assert engine.selfcheck_count == c0 + 3 and torch.equal(e, a)
+    # somebody watches the forward (a module hook): no probe - it would fire the hook a second time, on a slice of the batch
+    monkeypatch.setattr(engine, "SELFCHECK_IMAGES", 8)
+    monkeypatch.setattr(engine, "SELFCHECK_LIMIT", 9e-4)
+    engine.reset_guard(m)
+    seen = []
+    h = m.encoder.layers[1].register_forward_hook(lambda mod, i, o: seen.append(o.shape[0]))
+    with torch.no_grad():
+        f = m(x)
+    h.remove()
+    assert seen == [12] and engine.selfcheck_count == c0 + 3 and torch.equal(f, a)
+    with torch.no_grad():
+        m(x)
+    assert engine.selfcheck_count == c0 + 4                   # the first unobserved forward is measured
