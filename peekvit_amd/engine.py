@@ -1004,6 +1004,14 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
     K = Cin * P * P
     dev = img.device
 
+    if u8 and _mode() == "bf16x3":
+        # the split-operand mode exists to be 1e-5-accurate: the fused uint8 gather emits ONE 16-bit value per pixel (fine for fp16 / bf16
+        # operands, 4e-3 / 5e-4 of rounding for this mode) - so here the image is normalised to fp32 first, as ToTensor + Normalize would
+        mean, std = getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD)
+        mt = torch.tensor(mean, dtype=torch.float32, device=img.device).view(1, -1, 1, 1)
+        st = torch.tensor(std, dtype=torch.float32, device=img.device).view(1, -1, 1, 1)
+        img = ((img.permute(0, 3, 1, 2).float().div(255.0) - mt) / st).contiguous()
+        u8 = False
     x3 = _mode() == "bf16x3" and not u8
     cols = workspace.get("cols", (B * Np, 3 * K if x3 else K), _lib.operand_dtype(), dev)
     if x3:
