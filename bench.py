@@ -37,6 +37,37 @@ HBM_PEAK_GBS = 8000.0               # HBM3E spec, same guide
 # measured on this box (scripts/mfma_peak.hip, profiles/r01_mfma_peak.txt): register-only MFMA loop with data-like operand toggling;
 # reported next to the nominal peak, never used for `frac`
 MFMA_BF16_SUSTAINED_MEASURED_TFLOPS = 2003.0
+HBM_ACHIEVABLE_GBS = 6290.0         # measured float4 copy, same guide ("HBM3E peak BW": 6.29 TB/s = 79 % of spec); the ridge below uses it
+RIDGE_FLOP_PER_BYTE = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_ACHIEVABLE_GBS * 1e9)      # 397: a GEMM below it is HBM-bound by its ALGORITHMIC bytes
+
+
+def gemm_members(kt, name, steps, cfg):
+    """Per-member roofline of the GEMM family (one C-ABI entry point, four roofline cases): each member against the bound its algorithmic
+    intensity puts it under - MFMA for the in-projection and fc1, HBM for the out-projection and fc2, whose fp32 residual in + out and
+    16-bit copy make them move more bytes than 2.5 PFLOP/s could feed."""
+    D, Mh = cfg["hidden_dim"], cfg["mlp_dim"]
+    from peekvit_amd._lib import PV_EPI_BIAS_POS_F32
+    names = {(3 * D, D): "qkv in-projection", (2 * D, D): "k|v in-projection of the last block (class-token rows only)",
+             (D, D): "attention out-projection (+ fp32 residual, 16-bit copy, row statistics)",
+             (Mh, D): "fc1 + GELU", (D, Mh): "fc2 (+ fp32 residual, 16-bit copy, row statistics)"}
+    out = []
+    for (N, K, epi), d in sorted(kt.members(name).items(), key=lambda kv: -kv[1]["ms"]):
+        if d["ms"] / steps < 0.1:          # (the last block's class-row GEMMs: 2048 rows, tens of microseconds)
+            continue
+        sec = d["ms"] * 1e-3
+        inten = d["flops"] / d["bytes"]
+        bound = "mfma" if inten >= RIDGE_FLOP_PER_BYTE else "hbm"
+        m = {"member": "patch embedding (+ bias, positional embedding)" if epi == PV_EPI_BIAS_POS_F32 else names.get((N, K), f"N={N} K={K}"), "N": N, "K": K, "epilogue": epi,
+             "launches_per_step": d["launches"] // steps, "avg_launch_ms": round(d["ms"] / d["launches"], 4), "ms_per_step": round(d["ms"] / steps, 3),
+             "algorithmic_flop_per_byte": round(inten, 1), "bound": bound,
+             "tflops": round(d["flops"] / sec / 1e12, 1), "algo_gbs": round(d["bytes"] / sec / 1e9, 1)}
+        if bound == "mfma":
+            m.update(achieved=m["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(m["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4))
+        else:
+            m.update(achieved=m["algo_gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(m["algo_gbs"] / HBM_PEAK_GBS, 4),
+                     frac_of_achievable_hbm=round(m["algo_gbs"] / HBM_ACHIEVABLE_GBS, 4))
+        out.append(m)
+    return out
 
 
 def parse():
@@ -54,6 +85,8 @@ def parse():
                     help="--train: stop the step after loss.backward() (+ all-reduce).  Default: the reference's whole step (train/train.py:112-121) "
                          "- zero_grad, forward, cross-entropy, backward, [all-reduce], clip_grad_norm_(1.0), Adam(1e-3).step()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: skip the extra_configs (BASELINE configs 2, 4 and config 3's training "
+                                                             "step, timed after the headline in the same process) and the reference-loop value")
     ap.add_argument("--cpu-batch", type=int, default=64, help="images of the CPU-oracle sample (64: large enough that the GPU path scored "
                                                                 "against it takes the same kernels / LayerNorm folding as the timed batch)")
     ap.add_argument("--cpu-iters", type=int, default=4)
@@ -100,6 +133,120 @@ def cpu_baseline(cfg, batch, iters, gpu_model=None, dev=None):
                 err[mode] = float(f"{((got - ref).norm() / ref.norm()).item():.3e}")
         out["gpu_logits_rel_l2_vs_oracle"] = err       # tolerance of BASELINE.json: 1e-3
     return out
+
+
+def oracle_error(model, cfg, dev, images, train=False, rank=None):
+    """Relative L2 of the GPU path's logits against the CPU oracle's fp32 logits (= the reference's arithmetic) on a small seeded batch."""
+    from oracle import vit_oracle as O
+    from peekvit_amd import synth
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg).items()}
+    x = torch.randn(images, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ref = O.vit_forward(x, sd, cfg, "fp32", **({"rankvit_layers": rank[0], "budget": rank[1]} if rank else {}))
+    with (torch.enable_grad() if train else torch.no_grad()):
+        got = model(x.to(dev)).detach().float().cpu()
+    return float(f"{((got - ref).norm() / ref.norm()).item():.3e}")
+
+
+def extra_config(kind, dev, steps, warmup):
+    """One more BASELINE.json configuration, timed in THIS process after the headline (same barrier + synchronize bracket around exactly
+    `steps` steps), so that the driver's one invocation also times configs 2, 4 and the training step of config 3."""
+    from peekvit_amd import engine, ops, synth
+    from peekvit_amd.models.rankvit import RankVisionTransformer
+    from peekvit_amd.models.vit import VisionTransformer
+    name, batch, train, rank = {"vit_small_fwd": ("vit_small", 512, False, None), "rankvit_b16_fwd": ("vit_b_16", 2048, False, ([3, 6, 9], 0.5)),
+                                "vit_b_16_train_step": ("vit_b_16", 2048, True, None)}[kind]
+    cfg = synth.MODEL_CONFIGS[name]
+    seqs = None
+    if rank:
+        import math
+        model = RankVisionTransformer(**cfg, rankvit_layers=rank[0])
+        model.set_budget(rank[1])
+        S, seqs = synth.seq_length(cfg), []
+        for i in range(cfg["num_layers"]):
+            if i in rank[0]:
+                S = 1 + math.ceil((S - 1) * rank[1])
+            seqs.append(S)
+    else:
+        model = VisionTransformer(**cfg)
+    synth.load_synth_weights(model, cfg)
+    model = (model.train() if train else model.eval()).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    x = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], generator=gen, device=dev).to(torch.bfloat16).to(torch.float32)
+    if train:
+        y = torch.randint(0, cfg["num_classes"], (batch,), generator=gen, device=dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+
+        def step():
+            for p in params:
+                p.grad = None
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
+            opt.step()
+    else:
+        def step():
+            model(x)
+    f0 = engine.fallback_count
+    err = oracle_error(model, cfg, dev, 16 if rank else 64, train, rank)        # before the optimizer moves the weights
+    engine.selfcheck_last = None
+    with (torch.enable_grad() if train else torch.no_grad()):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        with ops.KernelTimer() as kt:
+            step()
+            torch.cuda.synchronize(dev)
+    ks = kt.summary()
+    flops_exec = sum(v["flops"] for v in ks.values()) / batch
+    value = batch * steps / dt
+    out = {"config": kind, "workload": (f"{name} train step (fwd, cross-entropy, bwd, clip 1.0, Adam)" if train else
+                                        f"rank{name} layers={rank[0]} budget={rank[1]} forward" if rank else f"{name} forward") + f", batch {batch}, {cfg['image_size']}x{cfg['image_size']}",
+           "value": round(value, 1), "unit": "images/sec", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "dtype": "bf16" if train else ("bf16x3" if engine.fallback_count > f0 else "f16"),
+           "gflop_per_image": round(synth.fwd_flops_per_image(cfg, seqs) * (3 if train else 1) / 1e9, 3), "gflop_per_image_executed": round(flops_exec / 1e9, 3),
+           "model_mfma_roofline_frac": round(value * flops_exec / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+           ("train_forward_logits_rel_l2_vs_oracle" if train else "logits_rel_l2_vs_oracle"): err,
+           "logits_sample_images": 16 if rank else 64,
+           "top_kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:4]}}
+    if not train and engine.selfcheck_last is not None:
+        sc = engine.selfcheck_last
+        out["self_check"] = {"fp16_vs_bf16x3_logits_rel_l2": float(f"{sc[0]:.3e}"), "images_compared": sc[1] - sc[2], "limit": engine.SELFCHECK_LIMIT}
+        if rank:
+            out["self_check"]["rank_tie_flips"] = {"images": sc[2], "of": sc[1], "note": "probe images in which a ranked layer kept a different token SET than the "
+                                                   "split-operand arithmetic did (a near-tie at the keep boundary resolved by 16-bit noise in the norms): their logits move "
+                                                   "by percents and they are excluded from the comparison above; PEEKVIT_AMD_RANK_STRICT=1 sends the model to bf16x3 instead"}
+    if train:
+        out["logits_note"] = "training runs bf16 operands (fp16 gradients would need loss scaling): its forward is outside the 1e-3 inference contract by design; gradients are asserted at 3e-2 (README)"
+    del model, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def reference_loop(model, cfg, batch, steps, dev):
+    """images/sec as the REFERENCE defines it (validate/test.py:113-124): wall clock around the evaluation loop, host batches moved with a
+    synchronous .to(device), argmax + metric update per batch - here `steps` batches from one pinned host batch.  Never `value`."""
+    host = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(7)).pin_memory()
+    labels = torch.randint(0, cfg["num_classes"], (batch,), generator=torch.Generator().manual_seed(8)).pin_memory()
+    correct = torch.zeros((), dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            model(host.to(dev))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b, l = host.to(dev), labels.to(dev)
+            correct += (torch.argmax(model(b), 1) == l).sum()
+        _ = int(correct.item())
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+            "definition": "validate/test.py:113-124: wall clock of the loop incl. a synchronous host-to-device copy of every fp32 batch (pinned, "
+                          f"{host.numel() * 4 / 1e9:.2f} GB) and the argmax / accuracy update"}
 
 
 def self_launch(args) -> int:
@@ -269,33 +416,49 @@ def main():
         roof["launches_per_step"] = d["launches"] // args.steps
         roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)
         roof["algorithmic_per_launch"] = round((d["flops"] if d["flops"] > 0 else d["bytes"]) / d["launches"] / (1e12 if d["flops"] > 0 else 1e9), 4)
-        # HBM/fabric bytes per launch of this kernel from the committed PMC passes of this same command (separate FETCH_SIZE /
-        # WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r01_kernel_summary.json
+        if dom.startswith("pv_gemm_bf16"):
+            # The GEMM entry point is four roofline cases.  `roofline` itself = the member the step spends most time in, against ITS bound;
+            # `members` = all of them; `family` = every GEMM launch lumped against the MFMA peak (what rounds 1-3 reported as `frac`).
+            members = gemm_members(kt, dom, args.steps, cfg)
+            top = members[0]
+            family = dict(roof)
+            roof = {"kernel": f"{dom} [{top['member']}: N={top['N']} K={top['K']}]", "bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"],
+                    "unit": top["unit"], "frac": top["frac"], "traffic": None, "launches_per_step": top["launches_per_step"], "avg_launch_ms": top["avg_launch_ms"],
+                    "algorithmic_per_launch": round((top["tflops"] if top["bound"] == "mfma" else top["algo_gbs"]) * top["avg_launch_ms"] * 1e-3, 4),
+                    "algorithmic_flop_per_byte": top["algorithmic_flop_per_byte"], "ridge_flop_per_byte": round(RIDGE_FLOP_PER_BYTE, 1),
+                    "members": members, "family": family}
+        # HBM/fabric bytes per launch from the committed PMC passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+        # doubled per MI355X_MICROARCH.md "HBM"): profiles/rNN_kernel_summary.json, keyed by the rocprof kernel name - the 256^2 kernel's template
+        # argument is the epilogue, so the in-projection (<0>) and fc1 (<1>) have their own rows, the two residual GEMMs share <2>
         try:
-            prof = next(f for f in ("r03_kernel_summary.json", "r02_kernel_summary.json", "r01_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
-            roof["traffic_source"] = "profiles/" + prof
+            prof = next(f for f in ("r04_kernel_summary.json", "r03_kernel_summary.json", "r02_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             summ = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
-            fam = [v for k, v in summ.items() if k.startswith(dom.replace("_bf16", "").replace("pv_", "pv_")) and "hbm_read_MB" in v]
-            if dom == "pv_gemm_bf16":
+            if dom.startswith("pv_gemm_bf16") and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train:
+                for m in roof["members"]:
+                    row = summ.get(f"pv_gemm256_pf<{m['epilogue']}>")
+                    if row and "hbm_read_MB" in row:
+                        m["traffic"] = round((row["hbm_read_MB"] + row["hbm_write_MB"]) * 1e6)
+                        m["traffic_note"] = "bytes/launch, PMC FETCH_SIZE x2 + WRITE_SIZE" + (" (kernel name shared by out-proj and fc2: their launch-weighted mean)" if m["epilogue"] == 2 else "")
+                roof["traffic"] = roof["members"][0].get("traffic")
+                roof["traffic_source"] = "profiles/" + prof
+                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE) of the dominant member's kernel"
                 fam = [v for k, v in summ.items() if k.startswith("pv_gemm") and "hbm_read_MB" in v]
-            if fam and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train:
                 n = sum(v["launches"] for v in fam)
-                roof["traffic"] = round(sum((v["hbm_read_MB"] + v["hbm_write_MB"]) * 1e6 * v["launches"] for v in fam) / n)
-                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted mean over the GEMM variants)"
-        except (OSError, KeyError, ValueError, StopIteration):
+                roof["family"]["traffic"] = round(sum((v["hbm_read_MB"] + v["hbm_write_MB"]) * 1e6 * v["launches"] for v in fam) / n)
+        except (OSError, KeyError, ValueError, StopIteration, ZeroDivisionError):
             pass
         flops_exec = sum(v["flops"] for v in ks.values()) / (args.steps * args.batch)
         # the EMPIRICAL roofline (scripts/power_roofline.hip, profiles/r02_power_roofline.json): what a dependency-free loop with a 256^2 GEMM tile's
         # LDS / L2 operand traffic sustains on this part at the dominant kernel's HBM bytes per FLOP - `peak` above stays the nominal 2.5 PFLOP/s
         try:
-            if roof["bound"] == "mfma" and d["bytes"] > 0:
+            if d["flops"] > 0 and d["bytes"] > 0:
                 pr_ = json.load(open(os.path.join(ROOT, "profiles", "r02_power_roofline.json")))
                 pts = sorted((r["bytes_per_kflop_hbm"], r["tflops"]) for r in pr_["synthetic"] if r["lds_per_16mfma"] == 6 and r["l2_per_16mfma"] == 2)
                 bpk = d["bytes"] / d["flops"] * 1e3
                 lo = max((q for q in pts if q[0] <= bpk), default=pts[0]); hi = min((q for q in pts if q[0] >= bpk), default=pts[-1])
                 emp = lo[1] if hi[0] == lo[0] else lo[1] + (hi[1] - lo[1]) * (bpk - lo[0]) / (hi[0] - lo[0])
-                roof["empirical"] = {"algorithmic_hbm_bytes_per_kflop": round(bpk, 3), "sustained_by_dependency_free_mix_tflops": round(emp, 1),
-                                     "frac": round(roof["achieved"] / emp, 4), "source": "profiles/r02_power_roofline.json"}
+                (roof.get("family") or roof)["empirical"] = {"algorithmic_hbm_bytes_per_kflop": round(bpk, 3), "sustained_by_dependency_free_mix_tflops": round(emp, 1),
+                                                             "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / emp, 4), "source": "profiles/r02_power_roofline.json"}
         except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
             pass
         kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
@@ -319,13 +482,21 @@ def main():
                        "operands": {"f16": "IEEE fp16 operands, fp32 accumulate (same MFMA rate as bf16), range-guarded" if args.precision == "auto"
                                     else "IEEE fp16 operands, fp32 accumulate", "bf16": "bf16 operands, fp32 accumulate",
                                     "bf16x3": "split bf16 hi+lo operands (3 products), fp32 accumulate"}[dtype],
-                       "range_guard_fallbacks": fallbacks},
+                       "range_guard_fallbacks": fallbacks,
+                       "self_check": (None if args.train or engine.selfcheck_last is None else
+                                      {"fp16_vs_bf16x3_logits_rel_l2": float(f"{engine.selfcheck_last[0]:.3e}"), "images": engine.selfcheck_last[1],
+                                       "limit": engine.SELFCHECK_LIMIT, "note": "mode auto's own measurement on the first forward of this batch size (engine.run_guarded)"})},
             # MFMA FLOPs the kernels really executed per second (their own algorithmic counts) over the dense bf16 peak - NOT the
             # reference formula's FLOPs, of which the last block skips the rows nobody reads
             "model_mfma_roofline_frac": round(value / world * flops_exec / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roof,
             "kernels": kernels,
         }
+        if args.train and world == 1 and not args.no_cpu_baseline and args.rank_budget is None:
+            # the forward of the TRAINING arithmetic (bf16 operands) against the fp32 oracle, next to `dtype`: outside the 1e-3 inference contract by
+            # design (fp16 gradients would need loss scaling); gradients are asserted at 3e-2 against the reference's (tests/test_hip_backward.py)
+            line["train_forward_logits_rel_l2_vs_oracle"] = oracle_error(infer_model, cfg, dev, args.cpu_batch, train=True)
+            line["train_forward_logits_note"] = "weights after the timed optimizer steps; contract of the inference path: 1e-3; training tolerance (gradients): 3e-2"
         if args.train and dist:
             line["grad_allreduce"] = {"buckets_per_step": n_buckets, "launched_during_backward_total": reducer.launched_before_finish,
                                       "bucket_bytes": reducer.bucket_bytes}
@@ -370,6 +541,16 @@ def main():
                     # the reported operand type is the one that is supposed to meet BASELINE.json's contract: refuse to report otherwise
                     print(json.dumps(line), file=sys.stderr, flush=True)
                     raise SystemExit(f"bench.py: dtype {dtype} logits are {err:.2e} from the CPU oracle, outside the 1e-3 contract: no result line")
+        if world == 1 and not args.no_extra and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train \
+                and args.precision == "auto":
+            # (c) the reference's own images/sec definition as a second value; (b) BASELINE configs 2, 4 and config 3's training step in the same
+            # invocation: the driver's one `bench.py --gpus 1` then times them too.  `value` above is untouched by these.
+            line["reference_loop"] = reference_loop(infer_model, cfg, args.batch, args.steps, dev)
+            del x, out
+            infer_model.to("cpu")
+            torch.cuda.empty_cache()
+            line["extra_configs"] = [extra_config(k, dev, args.steps if k != "vit_b_16_train_step" else max(5, args.steps // 2), min(args.warmup, 3) + 2)
+                                     for k in ("vit_small_fwd", "rankvit_b16_fwd", "vit_b_16_train_step")]
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

@@ -478,7 +478,9 @@ constexpr int G2_LDS = 2 * G2_BUF;           // 128 KiB
 // PF = the prefetching persistent launch (pv_gemm256_pf_kernel, round 3): `first` = this workgroup's first tile (its K-tile 0 is staged
 // here); otherwise K-tile 0 is ALREADY in buffer 0, staged by the previous tile's epilogue, which - when `has_next` - stages the first
 // K-tile of tile (nm0, nn0) in turn.  PF = false: the tile is self-contained (one tile per workgroup, the rows kernel).
-template <int EPI, bool PF = false>
+// FULL (round 4): the tile lies entirely inside the matrix (every tile but the last row / column tile) - the row / column clamps of the
+// staging addresses and the bounds guards of the epilogue's stores compile away.  The kernels pick the instantiation per tile.
+template <int EPI, bool PF = false, bool FULL = false>
 __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, const int m0, const int n0, const bool first = true,
                                                 const bool has_next = false, const int nm0 = 0, const int nn0 = 0, const int wid_pf = 0, const int slot_pf = 0) {
     int tid_ = threadIdx.x;
@@ -517,12 +519,12 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int ra = h * 128 + j * 64 + srow; ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            int ra = h * 128 + j * 64 + srow; ra = (FULL || m0 + ra < p.M) ? ra : p.M - 1 - m0;
             // LDS row q of every aligned 32-row block holds W row perm(q) = ((q&15)>>2)*8 + (q>>4)*4 + (q&3): with the
             // MFMA C layout (row = 4*(lane>>4)+reg) a lane then owns 8 CONSECUTIVE output columns per tile pair.
             const int q = j * 64 + srow;
             int rw = h * 128 + (q & ~31) + (((q & 15) >> 2) << 3) + (((q >> 4) & 1) << 2) + (q & 3);
-            rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+            rw = (FULL || n0 + rw < p.N) ? rw : p.N - 1 - n0;
             oa[h][j] = (uint32_t)(ra * (int)p.lda + schunk * 8) * 2u;
             ow[h][j] = (uint32_t)(rw * (int)p.ldw + schunk * 8) * 2u;
         }
@@ -800,7 +802,6 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         }
         PV_STAMP(8);
         const uint32_t tabc = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16) - 0x40000000u;
-        uint16_t* const ob = reinterpret_cast<uint16_t*>(p.out) + n0 + (lane & 31) * 8;
         const bool ocol_ok = n0 + (lane & 31) * 8 < p.N;
         const int rb_row0 = (wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5);      // + 32 q + 2 j: the rows this wave stores in pass q
         // The image of a pass: 64 rows x 512 B = 32 KiB, local row lr = (wave group) * 32 + (tile row % 32); two such regions alternate
@@ -882,44 +883,55 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             const int lrow = wr * 32 + (mt & 1) * 16 + i16, c = wc * 8 + u * 4 + g;
             *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(img + ((mt >> 1) & 1) * 32768 + lrow * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
         };
-        uint16_t* orow[4];         // output row of read-back slot j in image region 0; region q is 32 rows further
+        // Output addresses (round 4).  The stores of this epilogue leave in a fixed order (pass by pass, four 2-row stores per wave and pass), so
+        // ONE running per-lane pointer walks them: first row of the wave + (lane >> 5) rows + (lane & 31) 16-byte chunks, advanced after every
+        // store by a workgroup-uniform byte distance (2 rows, or 26 rows to the next pass; the training pair's planes are N elements apart) -
+        // one 64-bit vector add per store.  Round 3 kept four 64-bit row pointers, which the allocator (251 of 256 registers live) re-derived
+        // before every store: 7 vector instructions + a compare + an exec-mask branch per 1-KiB store, 16 % of this issue-bound epilogue's
+        // instructions.  Full tiles (template argument FULL) have no bounds guard.
+        // (a workgroup-uniform 64-bit base in scalar registers + ONE 32-bit running byte offset per lane: the tile spans < 4 MiB)
+        const uint32_t row_bytes = (uint32_t)p.ldo * 2u;
+        char* const obase = reinterpret_cast<char*>(p.out) + ((int64_t)m0 * p.ldo + n0) * 2;
+        uint32_t ooff = (uint32_t)((wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5)) * row_bytes + (uint32_t)(lane & 31) * 16u
+                        + (PAIR2 ? (uint32_t)p.N * 2u : 0u);                               // (the pair's raw plane goes first)
+        {
+            auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // virtual pass vq: image region vq & 3, plane vq >> 2
+                if (FULL || (m0 + rb_row0 + 32 * (vq & 3) + 2 * j < p.M && ocol_ok)) PV_STORE16(reinterpret_cast<u32x4*>(obase + ooff), rb[j]);
+                // to the next store in program order: (vq, j + 1), else (vq + 1, 0) - which for the pair's fifth pass is row 0 of the OTHER plane
+                if (j < 3) ooff += 2u * row_bytes;
+                else if (PAIR2 && vq == 3) ooff -= 102u * row_bytes + (uint32_t)p.N * 2u;
+                else ooff += 26u * row_bytes;
+            };
+            issue(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) orow[j] = ob + (int64_t)(m0 + rb_row0 + 2 * j) * p.ldo;
-        const int64_t pass_stride = 32 * p.ldo;
-        auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // virtual pass vq: image region vq & 3, plane vq >> 2
-            const int row = rb_row0 + 32 * (vq & 3) + 2 * j;
-            uint16_t* o = orow[j] + (vq & 3) * pass_stride + ((PAIR2 && vq < 4) ? p.N : 0);
-            if (m0 + row < p.M && ocol_ok) PV_STORE16(reinterpret_cast<u32x4*>(o), rb[j]);
-        };
-        issue(0);
+            for (int vn = 0; vn < NU; ++vn) {
+                const int vq = vn >> 2;
+                if (vn + 1 < NU) issue(vn + 1);
+                if (PFM == 2 && vn < 4 && pf_next) {
+                    // the next tile's first K-tile, two pieces per unit of the first pass: the memory path is idle until the first store (unit 4),
+                    // and a burst of all 64 KiB at the start of the epilogue held every wave at the ISSUE of its loads for ~1 k cycles (stamps)
+                    if (vn == 0) stage_next_piece(nm0, nn0, 8);
+                    stage_next_piece(nm0, nn0, 2 * vn);
+                    stage_next_piece(nm0, nn0, 2 * vn + 1);
+                }
+                wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
+                finish(vn);
+                if (PFM == 1 && vn == 4 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 has landed (before any store)
+                if (vq > 0) store_row(vq - 1, vn & 3);                  // one 1-KiB store of the previous pass per unit
+                if ((vn & 3) == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's image writes (and the gathers issued before them)
+                    if (vq < 4) { PV_STAMP(9 + vq); }
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int vn = 0; vn < NU; ++vn) {
-            const int vq = vn >> 2;
-            if (vn + 1 < NU) issue(vn + 1);
-            if (PFM == 2 && vn < 4 && pf_next) {
-                // the next tile's first K-tile, two pieces per unit of the first pass: the memory path is idle until the first store (unit 4),
-                // and a burst of all 64 KiB at the start of the epilogue held every wave at the ISSUE of its loads for ~1 k cycles (stamps)
-                if (vn == 0) stage_next_piece(nm0, nn0, 8);
-                stage_next_piece(nm0, nn0, 2 * vn);
-                stage_next_piece(nm0, nn0, 2 * vn + 1);
+                    for (int j = 0; j < 4; ++j)      // local row rb_lrow0 + 2 j of region q & 1: base + immediate
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"((vq & 1) * 32768));
+                }
             }
-            wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
-            finish(vn);
-            if (PFM == 1 && vn == 4 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 has landed (before any store)
-            if (vq > 0) store_row(vq - 1, vn & 3);                  // one 1-KiB store of the previous pass per unit
-            if ((vn & 3) == 3) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this pass's image writes (and the gathers issued before them)
-                if (vq < 4) { PV_STAMP(9 + vq); }
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
 #pragma unroll
-                for (int j = 0; j < 4; ++j)      // local row rb_lrow0 + 2 j of region q & 1: base + immediate
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(rb_addr[j]), "n"((vq & 1) * 32768));
-            }
+            for (int j = 0; j < 4; ++j) store_row(NU / 4 - 1, j);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) store_row(NU / 4 - 1, j);
         pv_range_commit(vmax, p.range_flag);
     } else
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
@@ -1053,13 +1065,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // stores, so the wait for the rows also waited for 192 KiB of stores to drain, and the CU's memory path (the bound of this
         // epilogue: 640 KiB per tile at ~28 B/clk) idled in between.  Same arithmetic per element: bit-identical outputs.
         lds_c* const img = cimg + G2_BUF;
-        const bool col_ok = n0 + lane * 4 < p.N;          // ragged last column tile (N % 256 != 0)
+        const bool col_ok = FULL || n0 + lane * 4 < p.N;  // ragged last column tile (N % 256 != 0)
         const int ncol = col_ok ? n0 + lane * 4 : 0;
         f32x4 rr[2][8];
         float rsc[2] = {1.0f, 1.0f};                       // PV_EPI_BIAS_RES_F32 row scale: lane j (< 8) holds slot j's (loaded with the rows: never after a store)
         auto row_of = [&](int q, int j) -> int64_t {       // output row of slot j of pass q (clamped at the ragged bottom edge)
             int m = m0 + q * 64 + wid * 8 + j;
-            m = m < p.M ? m : p.M - 1;
+            m = (FULL || m < p.M) ? m : p.M - 1;
             if (EPI == PV_EPI_BIAS_POS_F32) { const int img_ = m / p.rpi, pi = m - img_ * p.rpi; return (int64_t)img_ * p.rpo + p.row_off + pi; }
             return m;
         };
@@ -1067,7 +1079,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int m = m0 + q * 64 + wid * 8 + j;
-                m = m < p.M ? m : p.M - 1;
+                m = (FULL || m < p.M) ? m : p.M - 1;
                 f32x4& r = rr[q & 1][j];
                 if (EPI == PV_EPI_BIAS_F32) {
                     r = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1132,7 +1144,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     o = (f32x4){fmaf(sc, v[0], tr * r[0]), fmaf(sc, v[1], tr * r[1]), fmaf(sc, v[2], tr * r[2]), fmaf(sc, v[3], tr * r[3])};
                 }
                 else o = (f32x4){r[0] + v[0], r[1] + v[1], r[2] + v[2], r[3] + v[3]};
-                const bool ok = m0 + q * 64 + row < p.M && col_ok;
+                const bool ok = FULL || (m0 + q * 64 + row < p.M && col_ok);
                 if (ok) {
                     if (EPI == PV_EPI_GELU_GRAD_BF16) {
                         const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
@@ -1188,7 +1200,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // the next tile's K-tile 0 is older than every store of this epilogue: a COUNTED wait that leaves the stores in flight retires it.
         // A full tile issues at least 16 (16-bit outputs: 2 rows per instruction) / 32 (fp32 and gelu' epilogues: 1 row) stores per wave
         // after the prefetch; a ragged tile may skip some, so it drains.
-        const bool full = m0 + G2_BM <= p.M && n0 + G2_BN <= p.N;
+        const bool full = FULL || (m0 + G2_BM <= p.M && n0 + G2_BN <= p.N);
         constexpr bool B16 = EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
         if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (B16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1236,7 +1248,9 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
     const int grp = r / (p.gm * cw), rem = r - grp * (p.gm * cw);
     const int gsz = min(p.gm, p.tiles_m - grp * p.gm);
     const int tnl = rem / gsz, tm = grp * p.gm + (rem - tnl * gsz);
-    pv_gemm256_tile<EPI>(p, smem, tm * G2_BM, (ch * p.gc + tnl) * G2_BN);
+    const int m0 = tm * G2_BM, n0 = (ch * p.gc + tnl) * G2_BN;
+    if (m0 + G2_BM <= p.M && n0 + G2_BN <= p.N) pv_gemm256_tile<EPI, false, true>(p, smem, m0, n0);
+    else pv_gemm256_tile<EPI, false, false>(p, smem, m0, n0);
 }
 
 // Prefetching persistent launch (round 3).  One workgroup per CU walks its XCD-contiguous share of the tile list; the epilogue of tile t
@@ -1272,7 +1286,8 @@ __global__ __launch_bounds__(512) void pv_gemm256_pf_kernel(const GemmDev p) {
     for (int i = j; i < cnt; i += per) {
         const bool has_next = i + per < cnt;
         if (has_next) decode(start + i + per, nm0, nn0);
-        pv_gemm256_tile<EPI, true>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid, start + i);
+        if (m0 + G2_BM <= p.M && n0 + G2_BN <= p.N) pv_gemm256_tile<EPI, true, true>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid, start + i);
+        else pv_gemm256_tile<EPI, true, false>(p, smem, m0, n0, i == j, has_next, nm0, nn0, wid, start + i);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of the epilogue have returned ...
         __builtin_amdgcn_s_barrier();                          // ... and every wave's: the next tile may overwrite buffer 1; its K-tile 0 is in buffer 0
         __builtin_amdgcn_sched_barrier(0);

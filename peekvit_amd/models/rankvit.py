@@ -121,7 +121,11 @@ class RankVisionTransformer(_ViTBase):
                 return train_engine.pool_and_head_train(self, tokens)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             body = lambda xs: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
-            return engine.run_guarded(self, x, lambda: body(x), probe=body, probe_key=repr(getattr(self, "current_budget", None)))
+            # what a ranked layer decided for every image: its kept SET (sorted indices); mode auto's self-check compares arithmetic only where
+            # these agree with the split-operand run (engine.RANK_STRICT)
+            ranked = [blk for blk in self.encoder.layers if getattr(blk, "current_budget", 1) != 1 and hasattr(blk, "sort_and_drop")]
+            state = (lambda: [torch.sort(blk.last_keep, dim=1).values for blk in ranked if getattr(blk, "last_keep", None) is not None]) if ranked else None
+            return engine.run_guarded(self, x, lambda: body(x), probe=body, probe_key=repr(getattr(self, "current_budget", None)), probe_state=state)
         return self._composite_head(self.encoder(self._composite_tokens(x)))
 
     def set_budget(self, budget: float):

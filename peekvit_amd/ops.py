@@ -24,7 +24,7 @@ class KernelTimer:
     work of the launches."""
 
     def __init__(self):
-        self.records = []     # (name, start_event, end_event, flops, bytes)
+        self.records = []     # (name, start_event, end_event, flops, bytes, member)
 
     def __enter__(self):
         global _timer
@@ -37,8 +37,22 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for name, e0, e1, flops, nbytes in self.records:
+        for name, e0, e1, flops, nbytes, _member in self.records:
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+    def members(self, name):
+        """The launches of one kernel name split by `member` (GEMMs: (N, K, epilogue) - the in-projection, out-projection, fc1, fc2 and the
+        patch embedding are one C-ABI entry point but different roofline cases): {member: {"launches", "ms", "flops", "bytes"}}."""
+        out = {}
+        for n, e0, e1, flops, nbytes, member in self.records:
+            if n != name:
+                continue
+            d = out.setdefault(member, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
@@ -51,10 +65,10 @@ _timer: Optional[KernelTimer] = None
 
 class _timed:
     """Context manager used by every wrapper: no-op unless a KernelTimer is active."""
-    __slots__ = ("name", "flops", "nbytes", "e0", "dev")
+    __slots__ = ("name", "flops", "nbytes", "e0", "dev", "member")
 
-    def __init__(self, name, dev, flops=0.0, nbytes=0.0):
-        self.name, self.flops, self.nbytes, self.dev = name, flops, nbytes, dev
+    def __init__(self, name, dev, flops=0.0, nbytes=0.0, member=None):
+        self.name, self.flops, self.nbytes, self.dev, self.member = name, flops, nbytes, dev, member
 
     def __enter__(self):
         if _timer is not None:
@@ -65,7 +79,7 @@ class _timed:
         if _timer is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.dev))
-            _timer.records.append((self.name, self.e0, e1, self.flops, self.nbytes))
+            _timer.records.append((self.name, self.e0, e1, self.flops, self.nbytes, self.member))
 
 
 def _stream(t: torch.Tensor):
@@ -211,7 +225,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
     if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
         part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)
         args.colsum_partial = part.data_ptr()
-    with _timed("pv_gemm_bf16" + tag, a.device, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0)):
+    # algorithmic bytes: both operands once, the output once (+ the residual rows it adds, + the 16-bit copies the fused / folded LayerNorm forms emit)
+    nbytes = 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0) + (2.0 * M * N if x16_out is not None else 0.0)
+    with _timed("pv_gemm_bf16" + tag, a.device, 2.0 * M * N * K, nbytes, member=(N, K, epilogue)):
         check(_lib.load().pv_gemm_bf16(C.byref(args), _stream(a)), "pv_gemm_bf16")
     _count()
     if colsum_out is not None:
