@@ -52,7 +52,7 @@ def gemm_members(kt, name, steps, cfg):
              (Mh, D): "fc1 + GELU", (D, Mh): "fc2 (+ fp32 residual, 16-bit copy, row statistics)"}
     out = []
     for (N, K, epi), d in sorted(kt.members(name).items(), key=lambda kv: -kv[1]["ms"]):
-        if d["ms"] / steps < 0.1:          # (the last block's class-row GEMMs: 2048 rows, tens of microseconds)
+        if out and d["ms"] / steps < 0.1:  # (the last block's class-row GEMMs: 2048 rows, tens of microseconds)
             continue
         sec = d["ms"] * 1e-3
         inten = d["flops"] / d["bytes"]

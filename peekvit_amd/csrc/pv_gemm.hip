@@ -1154,13 +1154,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                         PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol), o);
                 }
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out)      // (workgroup-uniform) token norms for the next block's ranking
-                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;     // reduced over the lanes after the pass
+                    fq[j] = ok ? pv_add_s(pv_add_s(o[0] * o[0], o[1] * o[1]), pv_add_s(o[2] * o[2], o[3] * o[3])) : 0.f;     // reduced over the lanes after the pass (pv_add_s: no packed horizontal add under the row loads in flight)
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
                     if (ok)
                         PV_STORE16(reinterpret_cast<u32x2*>(p.x16_out + orow * (int64_t)p.N + ncol), ((u32x2){pv_pack_bf16x2_tracked(o[0], o[1], vmax), pv_pack_bf16x2_tracked(o[2], o[3], vmax)}));
                     // this lane's share of the row's (sum, sum of squares); the 64-lane reduction of the 8 rows follows the pass
-                    fs[j] = ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f;
-                    fq[j] = ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f;
+                    fs[j] = ok ? pv_add_s(pv_add_s(o[0], o[1]), pv_add_s(o[2], o[3])) : 0.f;
+                    fq[j] = ok ? pv_add_s(pv_add_s(o[0] * o[0], o[1] * o[1]), pv_add_s(o[2] * o[2], o[3] * o[3])) : 0.f;
                 }
             }
             // the rows of pass q + 2 into the slot set just consumed: requested before the NEXT pass's stores, so the wait for them (two

@@ -81,63 +81,108 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
 
 
 class OverlappedGradReducer:
-    """Gradient all-reduce OVERLAPPED with backward: a post-accumulate hook on every parameter files its
-    gradient into the current ~25 MB bucket; a full bucket is flattened and all-reduced asynchronously while backward keeps
-    producing the earlier layers' gradients (the HIP training path hands over one encoder block's 12 gradients at a time, last
-    block first).  `finish()` - called where the reference's loop has `clip_grad_norm_` (train/train.py:120) - flushes the last
-    bucket, waits for every collective, averages and writes the reduced values back into `p.grad`.
+    """Gradient all-reduce OVERLAPPED with backward: the parameters are assigned ONCE, in reverse order (the order
+    backward produces their gradients), to ~25 MB buckets, each a pre-allocated flat buffer whose slices ARE the parameters' `.grad`
+    (round 4; rounds 1-3 flattened every bucket with torch.cat and copied the reduced values back: two extra passes over the gradients per
+    step).  A post-accumulate hook counts a bucket's gradients in; the last one launches the bucket's asynchronous all-reduce IN PLACE while
+    backward keeps producing the earlier layers' gradients (the HIP training path hands over one encoder block's 12 gradients at a time,
+    last block first).  `finish()` - called where the reference's loop has `clip_grad_norm_` (train/train.py:120) - launches what is left,
+    waits for every collective and averages in place.
 
         reducer = OverlappedGradReducer(model.parameters())
+        reducer.zero_grad()                      # (optional) gradients accumulate straight into the bucket views
         loss.backward(); reducer.finish(); clip_grad_norm_(...); optimizer.step()
-    """
+
+    A loop that sets `p.grad = None` instead (autograd then hands the parameter a tensor of its own) still works: the hook moves that
+    gradient into its view - one copy, still no concatenation and no copy back."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes, self.average = bucket_bytes, average
-        self._bucket: List[torch.nn.Parameter] = []
-        self._size = 0
+        self._buckets = []                   # {"params", "views", "flat", "pending", "launched"}
+        self._of = {}
+        cur, size, key = [], 0, None
+        for p in reversed(self.params):
+            nbytes, k = p.numel() * p.element_size(), (p.device, p.dtype)
+            if cur and (size + nbytes > bucket_bytes or k != key):
+                self._add_bucket(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size, key = size + nbytes, k
+        if cur:
+            self._add_bucket(cur)
         self._work = []
         self.buckets_launched = 0
         self.launched_before_finish = 0      # cumulative: buckets that left from a gradient hook, i.e. while backward was still running
         self._finishing = False
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
-    def _on_grad(self, p: torch.nn.Parameter):
-        nbytes = p.grad.numel() * p.grad.element_size()
-        if self._bucket and self._size + nbytes > self.bucket_bytes:
-            self._launch()
-        self._bucket.append(p)
-        self._size += nbytes
+    def _add_bucket(self, ps):
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        b = {"params": ps, "views": views, "flat": flat, "pending": len(ps), "launched": False}
+        for i, p in enumerate(ps):
+            self._of[id(p)] = (b, i)
+        self._buckets.append(b)
 
-    def _launch(self):
-        if not self._bucket:
+    def zero_grad(self):
+        """Zero the flat buffers and make their slices the parameters' gradients (instead of `p.grad = None`)."""
+        for b in self._buckets:
+            b["flat"].zero_()
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+
+    def _on_grad(self, p: torch.nn.Parameter):
+        b, i = self._of[id(p)]
+        v = b["views"][i]
+        if p.grad.data_ptr() != v.data_ptr():          # the loop cleared p.grad: autograd gave the parameter a tensor of its own
+            v.copy_(p.grad)
+            p.grad = v
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if b["launched"]:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in self._bucket])
+        flat = b["flat"]
+        host = None
         if flat.is_cuda and td.get_backend() == "gloo":
             # rehearsal backend (several ranks sharing one GPU, tests): gloo reduces on the host; RCCL ("nccl") reduces in place on
             # the device over xGMI
-            flat = flat.cpu()
-        self._work.append((td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True), flat, self._bucket))
-        self._bucket, self._size = [], 0
+            host = flat.cpu()
+        self._work.append((td.all_reduce(host if host is not None else flat, op=td.ReduceOp.SUM, async_op=True), b, host))
+        b["launched"] = True
         self.buckets_launched += 1
         self.launched_before_finish += 0 if self._finishing else 1
 
     def finish(self) -> int:
-        """Flush, wait, average, write back.  Returns the number of buckets of this step."""
+        """Launch what has not left yet, wait, average in place.  Returns the number of buckets of this step."""
         self._finishing = True
-        self._launch()
+        for b in self._buckets:
+            if not b["launched"] and b["pending"] < len(b["params"]):      # (a bucket none of whose parameters received a gradient stays home)
+                for p, v in zip(b["params"], b["views"]):
+                    if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                        if p.grad is None:
+                            v.zero_()
+                        else:
+                            v.copy_(p.grad)
+                        p.grad = v
+                self._launch(b)
         self._finishing = False
         world = td.get_world_size()
-        for handle, flat, ps in self._work:
+        for handle, b, host in self._work:
             handle.wait()
+            if host is not None:
+                b["flat"].copy_(host)
             if self.average:
-                flat.div_(world)
-            off = 0
-            for p in ps:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad), non_blocking=False)
-                off += n
+                b["flat"].div_(world)
         n_buckets, self._work, self.buckets_launched = len(self._work), [], 0
+        for b in self._buckets:
+            b["pending"], b["launched"] = len(b["params"]), False
         return n_buckets
 
     def remove(self):

@@ -19,12 +19,13 @@ import torch
 class DevicePrefetcher:
     """Iterate `loader` with the host->device copy of batch i+1 in flight while batch i is computed.
 
-    depth: batches staged ahead (pinned ring of depth + 1 slots per tensor shape).  The yielded tensors are valid until `depth` further
-    batches have been requested (they are views of the device ring) - consume a batch before asking for the one after next, as any
-    loop of the reference's shape does."""
+    depth: batches staged ahead (pinned ring of depth + 1 + keep slots per tensor shape).  The yielded tensors are views of the device
+    ring: batch i is valid until batch i + 1 + keep is handed out - with keep = 0 (default) consume a batch inside its own iteration, as any
+    loop of the reference's shape does; keep = 1 leaves batch i intact through iteration i + 1 (the evaluation loop's deferred guard read,
+    engine.deferred_flags, may have to repeat it then)."""
 
-    def __init__(self, loader: Iterable, device, depth: int = 1):
-        self.loader, self.device, self.depth = loader, torch.device(device), max(int(depth), 1)
+    def __init__(self, loader: Iterable, device, depth: int = 1, keep: int = 0):
+        self.loader, self.device, self.depth, self.keep = loader, torch.device(device), max(int(depth), 1), max(int(keep), 0)
         if self.device.type != "cuda":
             raise ValueError("DevicePrefetcher stages batches for a GPU; iterate the loader directly on CPU")
         self.stream = torch.cuda.Stream(self.device)
@@ -64,11 +65,12 @@ class DevicePrefetcher:
         return tuple(out), ready
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, ...]]:
-        nslots = self.depth + 1
+        nslots = self.depth + 1 + self.keep
         free = [None] * nslots
         it = iter(self.loader)
         queue = []
         slot = 0
+        recent = []                                             # slots of the last `keep` batches handed out: the consumer may still read them
         cur = torch.cuda.current_stream(self.device)
         for _ in range(self.depth):
             try:
@@ -87,5 +89,7 @@ class DevicePrefetcher:
             cur.wait_event(ready)
             yield tensors
             ev = torch.cuda.Event()
-            ev.record(cur)                                      # everything the consumer launched on this batch so far
-            free[used] = ev
+            ev.record(cur)                                      # everything the consumer launched on this batch (and on the kept ones) so far
+            for s_ in [used] + recent:
+                free[s_] = ev
+            recent = ([used] + recent)[:self.keep]

@@ -44,15 +44,23 @@ def evaluate(model, loader, device, budgets: Sequence, n_images: int, prefetch: 
             n_batches = 0
             if device.type == "cuda" and prefetch:
                 from .pipeline import DevicePrefetcher
+                from .. import engine
                 hits = torch.zeros((), dtype=torch.int64, device=device)
-                for batch, labels in DevicePrefetcher(loader, device):
-                    n_batches += 1
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    out = model(batch)
-                    e1.record()
-                    events.append((e0, e1))
-                    hits += (out.argmax(1) == labels).sum()
+                prev = None
+                # the guard word of batch i is read after batch i + 1 has been launched (engine.deferred_flags): no host stall per batch
+                with engine.deferred_flags():
+                    for batch, labels in DevicePrefetcher(loader, device, keep=1):       # (batch i stays valid through iteration i + 1: resolve() may repeat it)
+                        n_batches += 1
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        out = model(batch)
+                        e1.record()
+                        events.append((e0, e1))
+                        if prev is not None:
+                            hits += (engine.resolve(prev[0]).argmax(1) == prev[1]).sum()
+                        prev = (out, labels)
+                    if prev is not None:
+                        hits += (engine.resolve(prev[0]).argmax(1) == prev[1]).sum()
                 correct = int(hits.item())                         # the one read-back of the loop
                 dev_ms = sum(a.elapsed_time(b) for a, b in events)
             else:

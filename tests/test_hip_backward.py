@@ -487,9 +487,14 @@ def test_training_step_vs_reference_golden(golden, name, batch):
     x = torch.from_numpy(synth.synth_images(batch, cfg["image_size"], seed=0)).cuda()
     y = (torch.arange(batch) % cfg["num_classes"]).cuda()
     n0 = ops.launch_count
-    loss = torch.nn.functional.cross_entropy(m(x), y)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
     loss.backward()
     assert ops.launch_count - n0 > 20 * cfg["num_layers"], "the HIP training path did not run"
+    # The forward of the TRAINING arithmetic, stated and tested (round 3 review): bf16 operands (fp16 gradients would need loss scaling), so its
+    # logits sit at the explicit "bf16" mode's distance from the reference's train-mode logits - 4e-3 .. 7e-3 measured, asserted at 1.2e-2 - and NOT
+    # inside the 1e-3 contract of the inference path; what training is held to is the gradient tolerance below (3e-2) and the loss curve.
+    assert rel_l2(logits.detach().float().cpu().numpy(), g[f"{name}/logits"]) < 1.2e-2
     assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-3 * float(g[f"{name}/loss"])      # bf16-operand training path
     named = dict(m.named_parameters())
     names = [str(n) for n in g[f"{name}/names"]]

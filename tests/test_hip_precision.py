@@ -519,3 +519,30 @@ def test_contract_self_check_of_mode_auto(monkeypatch):
     with torch.no_grad():
         m(x)
     assert engine.selfcheck_count == c0 + 4                   # the first unobserved forward is measured
+
+
+def test_deferred_flag_read_repeats_only_the_batch_that_tripped():
+    """Round 4 (round 2/3 ADVICE: one host synchronisation per forward): inside engine.deferred_flags() a model-level forward returns without
+    reading its guard word; engine.resolve(out), called after the NEXT batch has been launched, hands back `out` itself for clean batches and
+    the split-operand result for the one batch whose activations overflowed fp16 - same logits as the immediate path, batch by batch."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_tiny")
+    xs = [torch.from_numpy(synth.synth_images(4, cfg["image_size"], seed=s)).to(DEV) for s in range(4)]
+    xs[2] = xs[2] * 3.0e4                                        # this batch overflows (patch values ~ 1e5 > 65504 in the gather)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m(xs[0])                                                 # the self-check verdict for this batch size (deferral starts after it)
+        want = [m(x).clone() for x in xs]
+        n0 = engine.fallback_count
+        got, prev = [], None
+        with engine.deferred_flags():
+            for x in xs:
+                out = m(x)
+                if prev is not None:
+                    got.append(engine.resolve(prev).clone())
+                prev = out
+            got.append(engine.resolve(prev).clone())
+    assert engine.fallback_count == n0 + 1                       # exactly the overflowing batch was repeated
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert torch.isfinite(got[2]).all()
