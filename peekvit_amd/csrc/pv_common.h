@@ -210,35 +210,58 @@ __device__ __forceinline__ float pv_add_s(float a, float b) {
     return r;
 }
 
-template <int NCH>
-__device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
+// JB rows at once (round 4): the SAME per-row arithmetic, written step by step ACROSS the rows, so that the JB independent chains of
+// cross-lane reductions (two wave sums per row, each a dependent chain of four DPP adds, four v_readlane and three scalar adds) interleave
+// instead of running one after the other - the GEMM-fused LayerNorm passes are latency-bound on exactly these chains.  JB = 1 is the
+// standalone kernel's form; every row rounds identically for any JB.
+template <int NCH, int JB>
+__device__ __forceinline__ void pv_ln_rows_regs(RowRegs<NCH> (&r)[JB], const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
     // every operation rounded on its own: which multiply-adds hipcc contracts into FMAs depends on the code this is inlined into, and the
     // standalone kernel and the GEMM-fused passes must agree to the bit (tests/test_hip_ops.py found a last-bit difference at N = 512)
 #pragma clang fp contract(off)
-    float s = 0.f;
+    float s[JB], mean[JB], q[JB], rstd[JB];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) s += pv_add_s(r.v[j].x + r.v[j].y, r.v[j].z + r.v[j].w);
-    const float mean = pv_wave_sum(s) / (float)D;
-    float q = 0.f;
+    for (int b = 0; b < JB; ++b) {
+        s[b] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        if (lane + 64 * j < nvec) {
-            float a = r.v[j].x - mean, b = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
-            q += pv_add_s(a * a + b * b, c * c + d * d);
+        for (int j = 0; j < NCH; ++j) s[b] += pv_add_s(r[b].v[j].x + r[b].v[j].y, r[b].v[j].z + r[b].v[j].w);
+    }
+#pragma unroll
+    for (int b = 0; b < JB; ++b) mean[b] = pv_wave_sum(s[b]) / (float)D;
+#pragma unroll
+    for (int b = 0; b < JB; ++b) {
+        q[b] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (lane + 64 * j < nvec) {
+                float a = r[b].v[j].x - mean[b], bb = r[b].v[j].y - mean[b], c = r[b].v[j].z - mean[b], d = r[b].v[j].w - mean[b];
+                q[b] += pv_add_s(a * a + bb * bb, c * c + d * d);
+            }
         }
     }
-    const float rstd = 1.0f / sqrtf(pv_wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        int idx = lane + 64 * j;
-        if (idx < nvec) {
-            const float4 g = gm[j], b = bt[j];
-            r.v[j].x = (r.v[j].x - mean) * rstd * g.x + b.x;
-            r.v[j].y = (r.v[j].y - mean) * rstd * g.y + b.y;
-            r.v[j].z = (r.v[j].z - mean) * rstd * g.z + b.z;
-            r.v[j].w = (r.v[j].w - mean) * rstd * g.w + b.w;
+    for (int b = 0; b < JB; ++b) rstd[b] = 1.0f / sqrtf(pv_wave_sum(q[b]) / (float)D + eps);
+#pragma unroll
+    for (int b = 0; b < JB; ++b) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < nvec) {
+                const float4 g = gm[j], be = bt[j];
+                r[b].v[j].x = (r[b].v[j].x - mean[b]) * rstd[b] * g.x + be.x;
+                r[b].v[j].y = (r[b].v[j].y - mean[b]) * rstd[b] * g.y + be.y;
+                r[b].v[j].z = (r[b].v[j].z - mean[b]) * rstd[b] * g.z + be.z;
+                r[b].v[j].w = (r[b].v[j].w - mean[b]) * rstd[b] * g.w + be.w;
+            }
         }
     }
+}
+
+template <int NCH>
+__device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
+    RowRegs<NCH> one[1] = {r};
+    pv_ln_rows_regs<NCH, 1>(one, gm, bt, D, nvec, lane, eps);
+    r = one[0];
 }
 
 template <int NCH>

@@ -1677,6 +1677,11 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 //     pv_gemm_bf16 followed by pv_layernorm_bf16 (tests/test_hip_ops.py).
 // K loop: 2 buffers, LDS-DMA of tile kt+1 in flight under the MFMAs of tile kt, one barrier per K tile (the 128^2 kernel's
 // structure: these shapes have 6 - 24 K tiles per output tile and the epilogue moves 10 bytes per output element).
+// (Measured dead end, round 4: the same loop as a ring of FOUR 32-deep stages with three stages of LDS-DMA in flight behind a counted
+//  vmcnt - to take the DMA latency per K tile off the critical path (3.3 k cycles per 64 of K against the 2.3 k the global -> LDS path
+//  needs, scripts/fullrow_probe.py) - is bit-identical and 6 - 10 % SLOWER (N = 384: K = 384 97.8 -> 103.8 us, K = 1536 203.7 -> 223.5 us):
+//  a 32-deep stage has 64-byte rows, so every 1-KiB DMA piece touches 16 half cache lines instead of 8 whole ones, and the staging path
+//  is what bounds this loop.  A ring of 64-deep stages would need 192 KiB at N = 384.)
 // Epilogue: two passes of 64 rows; the wave group that owns the rows writes bias-initialised accumulators to an fp32 LDS image
 // (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 WHOLE rows: residual row from HBM, fmaf, fp32 row
 // store (N * 4 contiguous bytes), LayerNorm, 16-bit row store.
@@ -1828,41 +1833,54 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // the wave's 8 rows in two batches of four: image row + residual -> fp32 row store, then the LayerNorm of the four rows with their
+        // reduction chains interleaved (pv_ln_rows_regs; round 3 ran the rows one after the other: scripts/fullrow_probe.py put the fused
+        // LayerNorm at 27 us per launch where its extra bytes cost 12), 16-bit row stores
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = wid * 8 + j;
-            const int m = m0 + ps * 64 + row;
-            RowRegs<NCH> r;
+        for (int j0 = 0; j0 < 8; j0 += 4) {
+            RowRegs<NCH> r[4];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int idx = lane + 64 * c;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (idx < nvec) v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((idx ^ (row & 7)) << 4));
-                // (scalar FMAs by inline asm: packed, hipcc broadcasts a row scale that sits in an odd register with an op_sel bit - the
-                //  form that misreads lanes 48-63 while this pass's residual rows are still returning, pv_common.h pv_add_s)
-                r.v[c] = idx < nvec ? make_float4(pv_fma_s(sc[j], v[0], rr[j][c][0]), pv_fma_s(sc[j], v[1], rr[j][c][1]), pv_fma_s(sc[j], v[2], rr[j][c][2]),
-                                                  pv_fma_s(sc[j], v[3], rr[j][c][3]))
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
-            }
-            if (m < p.M) {
+            for (int jb = 0; jb < 4; ++jb) {
+                const int j = j0 + jb, row = wid * 8 + j;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int idx = lane + 64 * c;
-                    if (idx < nvec) PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4), ((f32x4){r.v[c].x, r.v[c].y, r.v[c].z, r.v[c].w}));
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (idx < nvec) v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((idx ^ (row & 7)) << 4));
+                    // (scalar FMAs by inline asm: packed, hipcc broadcasts a row scale that sits in an odd register with an op_sel bit - the
+                    //  form that misreads lanes 48-63 while this pass's residual rows are still returning, pv_common.h pv_add_s)
+                    r[jb].v[c] = idx < nvec ? make_float4(pv_fma_s(sc[j], v[0], rr[j][c][0]), pv_fma_s(sc[j], v[1], rr[j][c][1]), pv_fma_s(sc[j], v[2], rr[j][c][2]),
+                                                          pv_fma_s(sc[j], v[3], rr[j][c][3]))
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int m = m0 + ps * 64 + wid * 8 + j0 + jb;
+                if (m < p.M) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int idx = lane + 64 * c;
+                        if (idx < nvec) PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4), ((f32x4){r[jb].v[c].x, r[jb].v[c].y, r[jb].v[c].z, r[jb].v[c].w}));
+                    }
                 }
             }
             if (p.ln_out) {                                // (workgroup-uniform)
                 // p.N (= N), not the constant: the standalone kernel divides by a RUN-TIME D, and hipcc's division by a run-time value and by
                 // a power-of-two constant differ in the last bit (found by the bit-identity test at N = 512)
-                pv_ln_row_regs<NCH>(r, ln_g, ln_b, p.N, nvec, lane, p.ln_eps);
-                if (m < p.M) {
-                    u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * N);
+                pv_ln_rows_regs<NCH, 4>(r, ln_g, ln_b, p.N, nvec, lane, p.ln_eps);
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int idx = lane + 64 * c;
-                        if (idx < nvec) {
-                            u32x2 pk = {pv_pack_bf16x2(pv_mul_s(r.v[c].x, lsc[j]), pv_mul_s(r.v[c].y, lsc[j])), pv_pack_bf16x2(pv_mul_s(r.v[c].z, lsc[j]), pv_mul_s(r.v[c].w, lsc[j]))};
-                            PV_STORE16(o + idx, pk);
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int j = j0 + jb, m = m0 + ps * 64 + wid * 8 + j;
+                    if (m < p.M) {
+                        u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * N);
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int idx = lane + 64 * c;
+                            if (idx < nvec) {
+                                u32x2 pk = {pv_pack_bf16x2(pv_mul_s(r[jb].v[c].x, lsc[j]), pv_mul_s(r[jb].v[c].y, lsc[j])), pv_pack_bf16x2(pv_mul_s(r[jb].v[c].z, lsc[j]), pv_mul_s(r[jb].v[c].w, lsc[j]))};
+                                PV_STORE16(o + idx, pk);
+                            }
                         }
                     }
                 }
