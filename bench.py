@@ -216,20 +216,6 @@ def extra_config(kind, dev, steps, warmup):
     ks = kt.summary()
     flops_exec = sum(v["flops"] for v in ks.values()) / batch
     value = batch * steps / dt
-    graph_ms = None
-    if kind == "vit_small_fwd":
-        from peekvit_amd.graph import GraphedForward
-        with torch.no_grad():
-            gf = GraphedForward(model, x)
-            for _ in range(3):
-                gf(x)
-            torch.cuda.synchronize(dev)
-            tg = time.perf_counter()
-            for _ in range(steps):
-                gf(x)
-            torch.cuda.synchronize(dev)
-            graph_ms = (time.perf_counter() - tg) / steps * 1e3
-        del gf
     out = {"config": kind, "workload": (f"{name} train step (fwd, cross-entropy, bwd, clip 1.0, Adam)" if train else
                                         f"rank{name} layers={rank[0]} budget={rank[1]} forward" if rank else f"{name} forward" + (" on the hostile-weights fixture" if hostile else "")) + f", batch {batch}, {cfg['image_size']}x{cfg['image_size']}",
            "value": round(value, 1), "unit": "images/sec", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
@@ -244,9 +230,6 @@ def extra_config(kind, dev, steps, warmup):
         out["guard"] = {"fallback_forwards": engine.fallback_count - f0, "sticky_split_operand_mode": bool(engine.guard_state(model).unsafe),
                         "note": "the fp16 guards trip on these weights (attention scores ~1e3): mode auto answers from bf16x3 (1e-5 from the reference, tests/"
                                 "test_hip_precision.py::HOSTILE_CASES) at about a third of the fp16 rate - the price of a guard trip, next to the headline"}
-    if graph_ms is not None:
-        out["hip_graph_replay"] = {"value": round(batch / (graph_ms * 1e-3), 1), "unit": "images/sec", "ms_per_step": round(graph_ms, 3),
-                                   "note": "the same forward as ONE hipGraph replay (peekvit_amd.graph.GraphedForward, bit-identical logits): at 5 ms per step the ~60 eager launches leave gaps"}
     if not train and not hostile and engine.selfcheck_last is not None:
         sc = engine.selfcheck_last
         out["self_check"] = {"fp16_vs_bf16x3_logits_rel_l2": float(f"{sc[0]:.3e}"), "images_compared": sc[1] - sc[2], "limit": engine.SELFCHECK_LIMIT}
@@ -468,10 +451,12 @@ def main():
             summ = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
             if dom.startswith("pv_gemm_bf16") and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train:
                 for m in roof["members"]:
-                    row = summ.get(f"pv_gemm256_pf<{m['epilogue']}>")
+                    key = f"pv_gemm256_pf<{m['epilogue']}>"
+                    split = key + (" [short]" if m["K"] == cfg["hidden_dim"] else " [long]")      # (out-proj / fc2 share a kernel name: split by duration in the summary)
+                    row = summ.get(split) or summ.get(key)
                     if row and "hbm_read_MB" in row:
                         m["traffic"] = round((row["hbm_read_MB"] + row["hbm_write_MB"]) * 1e6)
-                        m["traffic_note"] = "bytes/launch, PMC FETCH_SIZE x2 + WRITE_SIZE" + (" (kernel name shared by out-proj and fc2: their launch-weighted mean)" if m["epilogue"] == 2 else "")
+                        m["traffic_note"] = "bytes/launch, PMC FETCH_SIZE x2 + WRITE_SIZE" + (" (kernel name shared by out-proj and fc2: their launch-weighted mean)" if split not in summ and m["epilogue"] == 2 else "")
                 roof["traffic"] = roof["members"][0].get("traffic")
                 roof["traffic_source"] = "profiles/" + prof
                 roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE) of the dominant member's kernel"

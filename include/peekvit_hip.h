@@ -176,7 +176,7 @@ int pv_gemm_bf16(const pv_gemm_args* args /* HOST pointer */, void* stream);
  * with an online softmax; dh in {80,96,128}: the streaming kernel for every S.
  * range_flag (ABI v7, optional): the device word of the operand-range guard; the fp16-operand build ORs 4 into it when the magnitude of
  * a query's largest score exceeds 32 - the 16-bit rounding of q and k leaves an error proportional to the score in it, and beyond that
- * the softmax no longer meets BASELINE's 1e-3 (measured sensitivity: DESIGN.md section 13).  The bf16 build ignores it. */
+ * the softmax no longer meets BASELINE's 1e-3 (measured sensitivity: DESIGN.md section 6).  The bf16 build ignores it. */
 int pv_attention_bf16(const uint16_t* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag, void* stream);
 
 /* The same attention for the FIRST nq ROWS of every image only (queries) against all S keys: the last encoder block, of whose output

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
         //  scaled, everything down to 6e-8 stays normal, and the factor cancels in O / l.  Free: it rides in the FMA's addend.)
         // Measured and NOT kept (round 3, scripts/attn_ab.py, profiles/r03_attention_ab.json): the exp argument as a packed FMA and the
         // row sum as one more MFMA tile (P^T times a tile of ones) take 30 % of the wave's VALU instructions away and not one percent of
-        // the kernel's time - it is not VALU-bound, whatever the 54 % VALU issue utilisation suggests.
+        // the kernel's time - it is not VALU-bound, whatever the 54 % VALU issue utilisation suggests (DESIGN.md sections 4 and 12).
         const float nm = -m * 1.44269504088896340736f + PV_P_SHIFT;
         float l = 0.f;
 #pragma unroll

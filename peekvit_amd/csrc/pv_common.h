@@ -73,7 +73,7 @@ __device__ __forceinline__ void pv_range_commit(float, uint32_t*) {}
 // Attention-logit guard (ABI v7, bit 4 of the same flag word).  The error the 16-bit rounding of q and k leaves in a score grows with
 // the score: delta_s ~ 2^-11 * sqrt(2) * |s| / sqrt(d_eff), and softmax turns it into a RELATIVE error of the probabilities of the
 // keys that matter.  On Gaussian q, k (S = 197, d = 64) the attention output's relative error is 3.6e-4 at max|s| = 5, 8.6e-4 at 40,
-// 1.1e-3 at 73, 1.6e-3 at 147 (fp16 operands; DESIGN.md section 13) - beyond PV_SCORE_LIMIT the fp16 path cannot promise BASELINE's
+// 1.1e-3 at 73, 1.6e-3 at 147 (fp16 operands; DESIGN.md section 6) - beyond PV_SCORE_LIMIT the fp16 path cannot promise BASELINE's
 // 1e-3, so the attention kernels of the fp16 build OR 4 into the flag when the magnitude of a row's largest score exceeds it, and the
 // caller repeats the forward in a mode that keeps q, k in fp32 (engine mode "auto" -> "bf16x3").  One v_max per query tile.
 #define PV_SCORE_LIMIT 32.0f
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pv_load_row(RowRegs<NCH>& r, const float* __rest
 // A scalar fp32 add the compiler cannot fold into a packed (v_pk_add_f32) tree.  Round 4: v_pk_*_f32 whose LOW result reads the HIGH register
 // of a source pair (an op_sel bit set - what hipcc emits for a horizontal add of a packed pair, or to broadcast a value that sits in an
 // odd register) returned wrong low results in lanes 48-63 about 1e-5 of the time on gfx950 while vector-memory loads were returning into
-// VGPRs (DESIGN.md section 14, scripts/dbg/gelu_glitch.py); the sums below run under exactly such loads in the GEMM-fused LayerNorm
+// VGPRs (DESIGN.md section 11, scripts/dbg/gelu_glitch.py); the sums below run under exactly such loads in the GEMM-fused LayerNorm
 // epilogues.  Same operation, same rounding as `a + b`.
 __device__ __forceinline__ float pv_add_s(float a, float b) {
     float r;

@@ -76,11 +76,18 @@ __device__ __forceinline__ void pv_gelu_bits2(float x0, float x1, uint32_t& b0, 
     b0 = (uint32_t)min(max(ti[0], lo), hi);
     b1 = (uint32_t)min(max(ti[1], lo), hi);
 }
-// The polynomial for an entry that has just arrived from GLOBAL memory (128^2 kernel): scalar FMAs for (r0, r1).  The packed form
-// (pv_gelu_poly's v_pk_fma_f32 on the freshly loaded register pairs, directly behind the s_waitcnt vmcnt that covers the
-// global_load_dwordx4) returned a stale dword 2 (c1 = 0) in lanes 48-63 of a wave about 3e-6 of the time on MI355X / ROCm 7.2 -
-// scripts/dbg/gelu_glitch.py: 28 of 40 launches of a 2560 x 3072 x 768 GEMM had wrong elements with -DPV_GELU_GLOBAL_MODE=0, 0 of 40
-// with the scalar form.  Same operations, same roundings as pv_gelu_poly: both kernels still round an element identically.
+// The polynomial for an entry that has just arrived from GLOBAL memory (128^2 kernel): scalar FMAs for (r0, r1).
+// Cause of round 3's "stale dword" (found in round 4): hipcc broadcasts an x that sits in an ODD register with
+//   v_pk_fma_f32 ..., op_sel:[0,1,0]        (the LOW result reads the HIGH register of the src1 pair)
+// and on gfx950 that form returns a low result computed as if the source were zero, in lanes 48-63, for ~1e-5 of the values, WHILE vector-memory
+// loads (here: the next table gathers) are returning into VGPRs.  scripts/dbg/gelu_glitch.py over the PV_GELU_GLOBAL_MODE builds below
+// (scripts/dbg/build_gelu_variants.py), 40 launches of a 2560 x 3072 x 768 GEMM each: mode 0 (hipcc's packed form) 37/40 launches wrong, every wrong
+// element computed by an op_sel:[0,1,0] instruction, all in lanes 48-63; 2 (idle cycles after the wait) 29/40; 4 (consumers as plain C) 36/40;
+// 9 (inline-asm v_pk_fma_f32 op_sel:[0,1,0], fresh registers, ALL values) 40/40; 1 / 5 (scalar FMAs), 3 / 6 / 7 / 8 (inline-asm packed FMA without
+// that bit: fresh destination, op_sel_hi broadcast, in place over the addend / the multiplicand) 0/40.  The 256^2 kernel evaluates the same packed
+// form from LDS with no register-destination load in flight and is bitwise relaunch-stable and elementwise exact (tests/test_hip_ops.py);
+// tests/test_isa_audit.py keeps the form out of every kernel that computes under such loads.
+// Same operations, same roundings as pv_gelu_poly: both kernels still round an element identically.
 #ifndef PV_GELU_GLOBAL_MODE
 #define PV_GELU_GLOBAL_MODE 1
 #endif
@@ -176,7 +183,7 @@ struct GemmDev {
     int res_scaled;            // PV_EPI_BIAS_RES_F32 with row_scale: the residual row is scaled too (ResidualViT: res = the unmasked tokens)
     int k_last;                // TN kernel: K extent of the last split-K slice (the slices need not be equal)
     float* colsum_partial;     // PV_EPI_GELU_GRAD_BF16: [tiles_m][N] column sums of the stored tile rows (bias gradient), or null
-    // LayerNorm folding (opt-in): the PRODUCER (PV_EPI_BIAS_RES_F32) also emits the 16-bit copy of its
+    // LayerNorm folding (the default for large batches): the PRODUCER (PV_EPI_BIAS_RES_F32) also emits the 16-bit copy of its
     // output rows and per-(column tile, row) partial (sum, sum of squares); the CONSUMER (PV_EPI_BIAS_BF16 / _GELU_BF16) runs on that
     // copy with W' = gamma (.) W and finishes  out = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]  before its usual epilogue.
     uint16_t* x16_out;
@@ -1261,7 +1268,7 @@ __global__ __launch_bounds__(512) void pv_gemm256_kernel(const GemmDev p_in) {
 // of the epilogue (in pieces under its first pass / behind its first residual rows) and retired by a COUNTED wait at its end that leaves
 // the stores in flight (PV_PF_MODE 2; mode 1 = all of it at the epilogue's start, retired in front of the first store).  A tile's
 // arithmetic is untouched: outputs are bit-identical.  Per-tile stamps of both launches: profiles/r03_gemm_stamps_*.txt; what had to be
-// true before it was faster than one tile per workgroup (no VGPR spill, bias through LDS, no K < 256 bypass edge): DESIGN.md section 14.
+// true before it was faster than one tile per workgroup (no VGPR spill, bias through LDS, no K < 256 bypass edge): DESIGN.md section 4.
 template <int EPI>
 __global__ __launch_bounds__(512) void pv_gemm256_pf_kernel(const GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

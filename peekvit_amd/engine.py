@@ -29,7 +29,7 @@ from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_BF16, PV_
 # Operand precision of the MFMA products:
 #   "auto"   (default) INFERENCE runs on IEEE fp16 operands (libpeekvit_hip_f16.so: same kernels, same MFMA rate, 2^-11 instead
 #            of 2^-8 operand rounding, fp32 accumulate): 5e-4 relative logits error = inside BASELINE's 1e-3 contract at the
-#            speed of bf16 - behind GUARDS for everything fp16 operands cannot carry inside that contract (DESIGN.md section 13):
+#            speed of bf16 - behind GUARDS for everything fp16 operands cannot carry inside that contract (DESIGN.md section 6):
 #            a device flag word that the kernels raise - bit 1: a data-dependent 16-bit value overflowed (|v| > 65504: QKV / GELU
 #            epilogues, patch gather, x16 copies); bit 2: a row handed to a folded LayerNorm has a mean large against its spread
 #            (pv_rowstat_finalize); bit 4: an attention score beyond 32 (the softmax amplifies the rounding of q and k) - and host
@@ -200,7 +200,7 @@ _FLAG_FOLD = 2
 # with a large mean, large attention scores); what they cannot see is a model / input on which the ordinary 2^-11 operand rounding simply
 # adds up to more than BASELINE's 1e-3 - the golden ResidualViT toy (2 layers, 18 tokens, width 128) at budget 0.2 measures 1.07e-3 with no
 # guard bit raised, and the CPU oracle with the same rounding points says 1.2e-3: thirteen rounding sites of 1 - 4.6e-4 each on a model too
-# small to average them out (DESIGN.md section 13; masks are NOT near the gate threshold there).  So the first model-level forward of every
+# small to average them out (DESIGN.md section 6; masks are NOT near the gate threshold there).  So the first model-level forward of every
 # (module parameters, budget setting, batch size, folding on/off) also runs its first few images in FALLBACK_MODE (6e-6 from the
 # reference) and compares: beyond SELFCHECK_LIMIT the verdict for that key is "x3" and every forward with it runs in FALLBACK_MODE -
 # measured, not inferred.  One small extra forward per key; nothing inside a timed steady state.  PEEKVIT_AMD_SELFCHECK_IMAGES=0 disables.
@@ -711,7 +711,7 @@ def _ln_key(ln: nn.LayerNorm):
 
 
 # LayerNorm FOLDING (default since round 2 where every token GEMM of a block runs on the 256-row tile kernel, i.e. large batches;
-# PEEKVIT_AMD_FOLD_LN=0 disables; DESIGN.md sections 10-11): no LayerNorm pass at all - the residual GEMMs also emit the 16-bit copy of
+# PEEKVIT_AMD_FOLD_LN=0 disables; DESIGN.md sections 4 and 10): no LayerNorm pass at all - the residual GEMMs also emit the 16-bit copy of
 # their rows + per-tile row statistics, and the in-proj / fc1 GEMMs run on that raw copy with gamma (.) W and correct in their
 # epilogue: rstd * (acc - mean * c1) + c2.  Same math as LayerNorm -> Linear, but the operand that is rounded to 16 bits is the raw
 # row instead of the normalised one: logits error 6.9e-4 instead of 5.8e-4 with fp16 operands on ViT-B/16 (tolerance 1e-3), and the

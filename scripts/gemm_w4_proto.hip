@@ -1,6 +1,6 @@
 // Diagnostic (not part of the library): the K loop of a 256 x 256 x 64 tile with 128 x 128 WAVE tiles - 4 waves per workgroup, one per SIMD,
 // 64 accumulator quads (256 registers) per wave, a third fewer LDS fragment reads per MFMA than the shipped 8-wave kernel (128 x 64 wave tiles).
-// VERDICT r2 item 1 names this variant; DESIGN.md section 10.4(a) priced it at about +3 % from the empirical roofline.  This program MEASURES its
+// VERDICT r2 item 1 names this variant; round 2's DESIGN.md priced it at about +3 % from the empirical roofline.  This program MEASURES its
 // K loop in isolation (s_memtime stamps around the loop, the same clock scripts/stamp_gemm.py reads for the shipped kernel) on the QKV shape of
 // ViT-B/16 at batch 2048, with the shipped kernel's staging (LDS-DMA, XOR-swizzled 16-byte chunks), tile raster and MFMA (16x16x32 f16).
 //   schedule per K-tile t (one wave, no partner wave to hide behind - the software pipeline is inside the wave):

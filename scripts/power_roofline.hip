@@ -1,5 +1,5 @@
 // Diagnostic (not part of the library): the EMPIRICAL MFMA roofline of one MI355X under its package power cap, as a function of how many
-// bytes move per FLOP.  Every token GEMM of this repo holds the package at 1400 W with the clock pulled to 1.8-2.0 GHz (DESIGN.md section 11),
+// bytes move per FLOP.  Every token GEMM of this repo holds the package at 1400 W with the clock pulled to 1.8-2.0 GHz (DESIGN.md section 10),
 // so "fraction of 2.5 PFLOP/s" says little about the kernel: the question is what ANY kernel can sustain at the same LDS / L2 / HBM traffic
 // per MFMA.  This program measures exactly that with a dependency-free loop:
 //   per trip and wave: 16 x v_mfma_f32_16x16x32_bf16 on register operands (8 independent accumulators, operands that toggle like real data)

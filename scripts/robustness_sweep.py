@@ -15,7 +15,7 @@ for name, batches in (("vit_small", (1, 7, 11, 100, 333, 1000)), ("vit_b_16", (1
             y = m.eval()(x[:B])
         assert torch.isfinite(y).all()
         # LayerNorm folding (large batches only) rounds differently from the LayerNorm-kernel path: bit-exact batch invariance holds among
-        # batches that take the same form (DESIGN.md section 10; likewise the split-K residual GEMMs of small batches), closeness across forms
+        # batches that take the same form (DESIGN.md section 4; likewise the split-K residual GEMMs of small batches), closeness across forms
         S = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
         with engine.precision(engine.inference_operand()):
             folded = (engine._fold_ok(B * S, cfg["hidden_dim"], cfg["mlp_dim"]),

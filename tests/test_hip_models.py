@@ -551,7 +551,7 @@ def test_graph_owns_its_scratch():
 
 
 def test_two_stream_forward_is_bit_identical(monkeypatch):
-    """PEEKVIT_AMD_STREAMS=2 (opt-in, DESIGN.md section 11): two half-batches on two HIP streams give the same bits."""
+    """PEEKVIT_AMD_STREAMS=2 (opt-in, DESIGN.md section 12): two half-batches on two HIP streams give the same bits."""
     from peekvit_amd import engine
     cfg, m = _model("vit", "vit_tiny")
     x = torch.randn(300, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(9)).to(DEV)

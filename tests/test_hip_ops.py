@@ -483,7 +483,7 @@ def test_attention_streaming_kernel_fp16_keeps_small_probabilities(ops):
 def test_gemm_gelu_is_elementwise_exact_on_both_tile_kernels(ops, M, N, K, tile):
     """Round 3 ADVICE / round 4 finding: the GELU epilogue ELEMENT BY ELEMENT against fp64 gelu(A W^T + b) at the fc1 shape, three launches
     each - a norm cannot see a polynomial that is wrong for one value in 1e5 (the 128^2 kernel's packed form with an op_sel bit was:
-    DESIGN.md section 14, tests/test_isa_audit.py).  2560 rows take the 128^2 kernel (table gathered from global memory; N = 3136 its
+    DESIGN.md section 11, tests/test_isa_audit.py).  2560 rows take the 128^2 kernel (table gathered from global memory; N = 3136 its
     ragged column tile), the others the 256^2 kernel (table in LDS; 16384 rows = the prefetching persistent launch, 8192 = one tile per workgroup).  16-bit operands are exact in the reference, so what
     is left is fp32 accumulation order, the table's 8e-7 and the 16-bit output rounding (2^-9 relative)."""
     from peekvit_amd._lib import PV_EPI_BIAS_GELU_BF16

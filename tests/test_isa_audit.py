@@ -1,7 +1,7 @@
 """ISA audit (CPU, hipcc cross-compiles): the packed-fp32 form that misbehaved on gfx950 must not appear in kernels that compute while
 vector-memory loads are returning into VGPRs.
 
-Round 4 finding (DESIGN.md section 14, scripts/dbg/gelu_glitch.py + build_gelu_variants.py): `v_pk_fma_f32 ... op_sel:[0,1,0]` - the LOW
+Round 4 finding (DESIGN.md section 11, scripts/dbg/gelu_glitch.py + build_gelu_variants.py): `v_pk_fma_f32 ... op_sel:[0,1,0]` - the LOW
 result taking the HIGH register of a source pair - returned a low result computed as if that source were zero, in lanes 48-63 only, for
 ~1.4e-5 of the values, in the 128^2 GEMM kernel's GELU (table entries gathered from global memory, four gathers in flight); an inline-asm
 copy of the same instruction with fresh registers failed 40 of 40 launches, every other packed / scalar form 0 of 40.  hipcc emits such
