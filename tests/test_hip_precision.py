@@ -467,6 +467,18 @@ def test_graph_replay_of_a_model_the_guard_sends_to_the_fallback_mode(golden):
         assert engine.fallback_count == n2
         assert torch.equal(y2, y3) and torch.equal(y2, m(x)) and rel_l2(y2.cpu().numpy(), ref) < TOL_NORTH_STAR
     engine.reset_guard(m)
+    # round 4: WITHOUT a refresh() - a replayer whose eager repeats make the guard sticky re-captures by itself, so later calls neither replay the
+    # graph that trips nor run eagerly again
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = GraphedForward(m, x, warmup=1)
+        assert g._guarded
+        outs = [g(x).clone() for _ in range(3)]            # trips 2, 3 (-> sticky, re-capture) and one pure replay of the new capture
+        assert engine.guard_state(m).unsafe and not g._guarded
+        n3 = engine.fallback_count
+        y4 = g(x).clone()
+        assert engine.fallback_count == n3 and torch.equal(y4, outs[-1]) and rel_l2(y4.cpu().numpy(), ref) < TOL_NORTH_STAR
+    engine.reset_guard(m)
 
 
 def test_contract_self_check_of_mode_auto(monkeypatch):
