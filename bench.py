@@ -366,8 +366,11 @@ def main():
 
         def train_step(inp):
             nonlocal n_buckets
-            for p in params:
-                p.grad = None
+            if reducer is not None:
+                reducer.zero_grad()          # gradients accumulate straight into the flat all-reduce buckets (their slices are p.grad)
+            else:
+                for p in params:
+                    p.grad = None
             logits = infer(inp)
             torch.nn.functional.cross_entropy(logits, y).backward()
             if dist:

@@ -47,8 +47,17 @@ def _worker(rank, world, port, out_dir):
     (torch.nn.functional.cross_entropy(out, dist.shard_batch(y), reduction="sum") / x.shape[0]).backward()
     launched_during_backward = reducer.buckets_launched
     nb2 = reducer.finish()
-    reducer.remove()
     same = all(torch.equal(reduced[n], p.grad) for n, p in model.named_parameters() if p.grad is not None)
+    # a third time through reducer.zero_grad(): the parameters' gradients ARE slices of the flat buckets (no per-step copy in, none back),
+    # autograd accumulates into them and the all-reduce runs in place - same bits again
+    reducer.zero_grad()
+    views = all(p.grad.data_ptr() == v.data_ptr() for b in reducer._buckets for p, v in zip(b["params"], b["views"]))
+    out = model(dist.shard_batch(x))
+    (torch.nn.functional.cross_entropy(out, dist.shard_batch(y), reduction="sum") / x.shape[0]).backward()
+    reducer.finish()
+    views = views and all(p.grad.data_ptr() == v.data_ptr() for b in reducer._buckets for p, v in zip(b["params"], b["views"]))
+    same = same and views and all(torch.equal(reduced[n], p.grad) for n, p in model.named_parameters() if p.grad is not None)
+    reducer.remove()
     if rank == 0:
         np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same,
                  **{"g_" + n: g.numpy() for n, g in reduced.items()})
