@@ -174,6 +174,9 @@ struct GemmDev {
     int rpi, rpo, row_off, qcols;
     float qscale;
     int tiles_m, tiles_n;
+    int fr_delay_wgs;          // = the CU count (the workgroups of the first round)
+    int fr_delay;              // full-row kernel: shader-clock ticks every second group of 8 workgroups of the first round waits before it starts (de-phasing)
+    int fr_lead;               // full-row kernel, de-phased launch (round 4): the first fr_lead workgroups alternate 128- / 64-row tiles per group of 8
     int fr_full, fr_half;      // full-row kernel, split remainder: fr_full 128-row tiles (a multiple of 8) + fr_half 64-row tiles; 0, 0 = tiles_m plain tiles
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
     int gc;                    // column tiles per raster chunk (256^2 kernel): the tile list is chunk-major, so an XCD keeps the
@@ -1693,12 +1696,14 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 // (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 WHOLE rows: residual row from HBM, fmaf, fp32 row
 // store (N * 4 contiguous bytes), LayerNorm, 16-bit row store.
 // ------------------------------------------------------------------------------------------------
-template <int NT>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave
+template <int N_>
+__device__ __forceinline__ void pv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int NT, bool DP = false>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave; DP = the deep-pipelined K loop (round 4)
 __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     constexpr int N = 64 * NT, BM = 128, BK = 64;
     constexpr int A_BYTES = BM * BK * 2;                  // 16 KiB
     constexpr int BUF = A_BYTES + N * BK * 2;             // one K-tile buffer
-    constexpr int NCH = (N / 4 + 63) / 64;                // float4 per lane of a whole row (pv_ln_row)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1709,7 +1714,22 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     // no A staging and no MFMAs for it, one epilogue pass - per row the arithmetic is unchanged.
     int m0_;
     bool half = false;
-    if (p.fr_full > 0) {
+    if (p.fr_lead > 0) {
+        // De-phased launch: the dispatcher hands out workgroups in index order, so the first round = fr_lead workgroups alternates full and
+        // half tiles per group of 8 (one per XCD); the CUs that started on a half tile stay half a tile ahead of the others for the rest of
+        // the launch, and their HBM-bound epilogues run under the other half's K loops instead of all 256 at once.
+        const int L = blockIdx.x, lead2 = p.fr_lead >> 1;
+        int f = -1, h = -1;
+        if (L < p.fr_lead) { const int i = ((L >> 4) << 3) + (L & 7); if ((L >> 3) & 1) h = i; else f = i; }
+        else if (L - p.fr_lead < p.fr_full - lead2) f = lead2 + (L - p.fr_lead);
+        else h = lead2 + (L - p.fr_lead - (p.fr_full - lead2));
+        if (f >= 0) m0_ = f * BM;
+        else {
+            if (h >= p.fr_half) return;                     // (whole workgroup: before any barrier)
+            m0_ = p.fr_full * BM + h * 64;
+            half = true;
+        }
+    } else if (p.fr_full > 0) {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3, fper = p.fr_full >> 3, q = p.fr_half >> 3, r = p.fr_half & 7;
         if (j < fper) m0_ = (x * fper + j) * BM;
         else {
@@ -1720,6 +1740,15 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         }
     } else m0_ = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
     const int m0 = m0_;
+#ifdef PV_STAMPS
+    const size_t pv_stamp_slot = (size_t)blockIdx.x;
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 5] = rt_; p.dbg[pv_stamp_slot * 16 + 7] = (unsigned long long)(half ? 1 : 0); }
+#endif
+    if (p.fr_delay > 0 && (int)blockIdx.x < p.fr_delay_wgs && ((blockIdx.x >> 3) & 1)) {      // (workgroup-uniform)
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0_ < (unsigned long long)p.fr_delay) __builtin_amdgcn_s_sleep(32);
+    }
+    PV_STAMP(0);
     const bool skip_mm = half && wm == 1;              // (wave-uniform)
     const int g = lane >> 4, i16 = lane & 15;
 
@@ -1738,6 +1767,173 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
     __builtin_amdgcn_sched_barrier(0);
 
+    // Residual rows of the epilogue (this wave's 8 whole rows per pass, NCH x 16 B per lane and row) and their per-row scales.  Round 4: the
+    // loads run ahead of their use - the first four rows of pass 0 are issued before the LAST K-tile of the deep-pipelined loop (its counted
+    // waits leave them in flight), the other four at the start of the epilogue (they have the first batch's arithmetic to arrive under), pass 1's
+    // as pass 0 consumes its registers, four rows at a time - the stamps had 5.5 k of a pass's 16 - 18 k ticks between "loads issued" and
+    // "loads landed".
+    constexpr int NCH = (N / 4 + 63) / 64;                // float4 per lane of a whole row (pv_ln_row)
+    const int nvec = N / 4;
+    f32x4 rr[8][NCH];
+    float sc[8], lsc[8];                                   // (wave-uniform values: scalar loads)
+    auto res_scales = [&](int ps) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + ps * 64 + wid * 8 + j, mr = m < p.M ? m : p.M - 1;
+            sc[j] = p.row_scale ? p.row_scale[mr] : 1.0f;
+            lsc[j] = p.ln_row_scale ? p.ln_row_scale[mr] : 1.0f;
+        }
+    };
+    auto res_load = [&](int ps, int j) __attribute__((always_inline)) {
+        const int m = m0 + ps * 64 + wid * 8 + j, mr = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = lane + 64 * c < nvec ? lane + 64 * c : nvec - 1;       // lanes beyond the row re-read its last chunk (never stored)
+            rr[j][c] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)mr * p.ldr + idx * 4);
+        }
+    };
+    constexpr bool RES_AHEAD = DP && NT <= 6;              // (N = 512: 128 accumulator registers leave no room for 64 more under the K loop)
+
+  if constexpr (DP) {
+    // ---- deep-pipelined K loop (round 4) ----------------------------------------------------------------------------------------------
+    // The 256^2 kernel's structure on the 128 x N tile: LDS-DMA stays in flight across raw s_barriers behind COUNTED s_waitcnt vmcnt, the
+    // two wave groups (wm = 0 / 1 = the two waves of every SIMD) run staggered by one barrier.  A K-tile is NP = NT / 2 phases of 16 MFMAs:
+    // phase j multiplies all four row tiles of the wave by its column-tile pair j.  "W group j" = the 128 weight rows all four column
+    // groups read in phase j (rows wn * 16 NT + 32 j + 0..31, wn = 0..3) = two 1-KiB pieces per wave; A = two pieces per wave.
+    // Every piece is staged TWO K-tiles ahead into the slot its predecessor was last read from, one phase after that read:
+    //   phase 0 of K-tile s: reads A(s), Wg0(s)      stages Wg(NP-1)(s+1) -> buffer (s+1) & 1     (last read: phase NP-1 of K-tile s-1)
+    //   phase 1            : reads Wg1(s)            stages A(s+2), Wg0(s+2) -> buffer s & 1
+    //   phase j >= 2       : reads Wgj(s)            stages Wg(j-1)(s+2)
+    // so a piece has 1.3 - 1.7 K-tiles (2.5 - 3 k cycles) to arrive, and 2 NP + 2 pieces per wave are issued per K-tile in a fixed order.
+    // The wait that covers what phase j+1 reads sits at the end of phase j's load interval (one barrier pair before the first read, so it
+    // holds for every wave of both groups); its count = the pieces issued after the needed ones (scripts/fullrow_vmcnt_model.py):
+    // steady state {4NP-2, 4NP, .., 4NP, 4NP-2}, K-tile nk-2 {4NP-2, 4NP-2-2j .., 2NP-2}, K-tile nk-1 {2(NP-2-j)}.
+    // A 64-row tile still stages both A pieces (the counts assume a fixed number of operations per K-tile) and its group 1 multiplies the
+    // clamped rows like any others (never stored: a branch around the MFMAs made hipcc spill the fragments).
+    constexpr int NP = NT / 2;
+    const int srow8 = lane >> 3;
+    const int schunk = (lane & 7) ^ (srow8 & 7);
+    const char* ga[2];
+    const char* gw[2];
+    int lw_off[2];                                       // (wave-uniform) LDS byte offset of the wave's W piece i of group 0 inside a buffer
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int ra = m0 + j * 64 + wid * 8 + srow8; ra = ra < p.M ? ra : p.M - 1;
+        ga[j] = reinterpret_cast<const char*>(p.A + (int64_t)ra * p.lda + schunk * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = i * 8 + wid, r0 = (pc >> 2) * 16 * NT + (pc & 3) * 8;
+        gw[i] = reinterpret_cast<const char*>(p.W + (int64_t)(r0 + srow8) * p.ldw + schunk * 8);
+        lw_off[i] = A_BYTES + r0 * 128;
+    }
+    const int64_t wg_stride = 64 * p.ldw;               // bytes between W groups (32 rows)
+    auto stage_a = [&](int buf, int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pv_glds16(ga[j] + kt * (BK * 2), smem + buf * BUF + j * 8192 + wid * 1024);
+    };
+    auto stage_w = [&](int buf, int grp, int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pv_glds16(gw[i] + grp * wg_stride + kt * (BK * 2), smem + buf * BUF + lw_off[i] + grp * 4096);
+    };
+
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    const int fx0 = ((lane >> 4) ^ (lane & 7)) << 4;
+    lds_cc* a_rd[2][2];                                  // [buf][ks]   + mt * 2048
+    lds_cc* w_rd[2][2];                                  // [buf][ks]   + nt * 2048
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_rd[b][ks] = (lds_cc*)smem + b * BUF + (wm * 64 + i16) * 128 + (fx0 ^ (ks << 6));
+            w_rd[b][ks] = (lds_cc*)smem + b * BUF + A_BYTES + (wn * 16 * NT + i16) * 128 + (fx0 ^ (ks << 6));
+            asm volatile("" : "+v"(a_rd[b][ks]));
+            asm volatile("" : "+v"(w_rd[b][ks]));
+        }
+    bf16x8 xf[4][2], wf[2][2];
+
+    const int nk = p.K / BK;
+    // prologue, in the steady-state issue order: all of K-tile 0, then K-tile 1 but its last W group (phase 0 of K-tile 0 issues that)
+    stage_a(0, 0);
+#pragma unroll
+    for (int gq = 0; gq < NP; ++gq) stage_w(0, gq, 0);
+    stage_a(1, 1);
+#pragma unroll
+    for (int gq = 0; gq < NP - 1; ++gq) stage_w(1, gq, 1);
+    pv_wait_vmcnt<4 * NP - 2>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PV_STAMP(1);
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier interval behind group 0
+
+    // MODE 0: steady state (s + 2 < nk), 1: K-tile nk - 2, 2 / 3: K-tile nk - 1 (3: behind the residual-row loads)
+    auto phase = [&](auto buf_c, auto mode_c, auto j_c, int kt) __attribute__((always_inline)) {
+        constexpr int B = decltype(buf_c)::value, MODE = decltype(mode_c)::value, j = decltype(j_c)::value;
+        if constexpr (j == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    xf[mt][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a_rd[B][ks] + mt * 2048);
+        }
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[t_][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(w_rd[B][ks] + (2 * j + t_) * 2048);
+        if constexpr (j == 0) { if constexpr (MODE <= 1) stage_w(B ^ 1, NP - 1, kt + 1); }
+        else if constexpr (MODE == 0) {
+            if constexpr (j == 1) { stage_a(B, kt + 2); stage_w(B, 0, kt + 2); }
+            else stage_w(B, j - 1, kt + 2);
+        }
+        // the counted wait for what the NEXT phase reads (nothing after the last phase of the last K-tile)
+        if constexpr (MODE == 0) pv_wait_vmcnt<(j == 0 || j == NP - 1) ? 4 * NP - 2 : 4 * NP>();
+        else if constexpr (MODE == 1) pv_wait_vmcnt<j == 0 ? 4 * NP - 2 : j == NP - 1 ? 2 * NP - 2 : 4 * NP - 2 - 2 * j>();
+        else if constexpr (MODE == 2) { if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j)>(); }
+        else if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j) + 4 * NCH>();      // MODE 3: + the residual loads issued in front of this K-tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t_ = 0; t_ < 2; ++t_)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[2 * j + t_][mt] = PV_MFMA_16x16x32(wf[t_][ks], xf[mt][ks], acc[2 * j + t_][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto ktile = [&](auto buf_c, auto mode_c, int kt) __attribute__((always_inline)) {
+        phase(buf_c, mode_c, std::integral_constant<int, 0>{}, kt);
+        phase(buf_c, mode_c, std::integral_constant<int, 1>{}, kt);
+        if constexpr (NP > 2) phase(buf_c, mode_c, std::integral_constant<int, 2>{}, kt);
+        if constexpr (NP > 3) phase(buf_c, mode_c, std::integral_constant<int, 3>{}, kt);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 2) {
+        ktile(B0{}, M0{}, kt);
+        ktile(B1{}, M0{}, kt + 1);
+    }
+    ktile(B0{}, M1{}, kt);                               // K-tile nk - 2 (nk is even: the launcher sends other K to the plain loop)
+    if constexpr (RES_AHEAD) {
+        res_scales(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res_load(0, j);      // the first batch of pass 0; the second has the first's arithmetic to arrive under
+        __builtin_amdgcn_sched_barrier(0);
+        ktile(B1{}, M3{}, kt + 1);                       // K-tile nk - 1 (4 NCH register loads younger than every LDS-DMA)
+    } else ktile(B1{}, M2{}, kt + 1);
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // balance the stagger barrier
+    PV_STAMP(2);
+  } else {
     // ---- LDS-DMA sources: 1-KiB pieces of 8 rows x 128 B per wave, swizzled chunk (chunk ^ (row & 7)) on the source side ----
     const int srow = wid * 8 + (lane >> 3);
     const int schunk = (lane & 7) ^ ((lane >> 3) & 7);
@@ -1791,42 +1987,32 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         }
     }
 
+  }
+
     // ---- epilogue ------------------------------------------------------------------------------------------------------
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
-    const int nvec = N / 4;
     float4 ln_g[NCH], ln_b[NCH];                           // the lane's LayerNorm affine parameters, fetched once
     if (p.ln_out) pv_ln_load_affine<NCH>(ln_g, ln_b, p.ln_gamma, p.ln_beta, nvec, lane);
+    if constexpr (!RES_AHEAD) res_scales(0);
+#pragma unroll
+    for (int j = RES_AHEAD ? 4 : 0; j < 8; ++j) res_load(0, j);
+    constexpr bool RES_NEXT = NT <= 6;                     // pass 1's rows fetched while pass 0 works (N = 512: no registers to spare)
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         if (ps == 1 && half) break;                        // (workgroup-uniform) a 64-row tile has no second pass
-        // this wave's 8 rows of the pass: their residual segments first (NCH x 16 B per lane and row, whole contiguous rows)
-        f32x4 rr[8][NCH];
-        float sc[8], lsc[8];
-        int mrow[8];
+        if (ps == 1) {
+            res_scales(1);
+            if constexpr (!RES_NEXT) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = m0 + ps * 64 + wid * 8 + j;
-            mrow[j] = m < p.M ? m : p.M - 1;
-            sc[j] = 1.0f; lsc[j] = 1.0f;
-        }
-        if (p.row_scale) {                                 // (workgroup-uniform; hoisted so that the row loads below are branch-free)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sc[j] = p.row_scale[mrow[j]];
-        }
-        if (p.ln_row_scale) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) lsc[j] = p.ln_row_scale[mrow[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int idx = lane + 64 * c < nvec ? lane + 64 * c : nvec - 1;       // lanes beyond the row re-read its last chunk (never stored)
-                rr[j][c] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)mrow[j] * p.ldr + idx * 4);
+                for (int j = 0; j < 8; ++j) res_load(1, j);
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // K loop (ps = 0) / the previous pass's image reads (ps = 1) are done
+#ifdef PV_STAMPS
+        if (ps == 0) { PV_STAMP(8); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PV_STAMP(9); }
+#endif
         if (wm == ps) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -1840,6 +2026,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef PV_STAMPS
+        if (ps == 0) PV_STAMP(10);
+#endif
         // the wave's 8 rows in two batches of four: image row + residual -> fp32 row store, then the LayerNorm of the four rows with their
         // reduction chains interleaved (pv_ln_rows_regs; round 3 ran the rows one after the other: scripts/fullrow_probe.py put the fused
         // LayerNorm at 27 us per launch where its extra bytes cost 12), 16-bit row stores
@@ -1861,6 +2050,11 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                                             : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
                 }
             }
+            if (RES_NEXT && ps == 0 && !half) {            // (workgroup-uniform) pass 1's rows j0 .. j0+3 into the registers just consumed
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) res_load(1, j0 + jb);
+            }
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 const int m = m0 + ps * 64 + wid * 8 + j0 + jb;
@@ -1872,6 +2066,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                     }
                 }
             }
+#ifdef PV_STAMPS
+            if (ps == 0 && j0 == 0) PV_STAMP(11);
+#endif
             if (p.ln_out) {                                // (workgroup-uniform)
                 // p.N (= N), not the constant: the standalone kernel divides by a RUN-TIME D, and hipcc's division by a run-time value and by
                 // a power-of-two constant differ in the last bit (found by the bit-identity test at N = 512)
@@ -1892,31 +2089,57 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                     }
                 }
             }
+#ifdef PV_STAMPS
+            if (ps == 0 && j0 == 0) PV_STAMP(12);
+#endif
         }
+        PV_STAMP(3 + ps);
     }
+#ifdef PV_STAMPS
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 6] = rt_; }
+#endif
 }
 
+static int g_pv_frdp = -1;         // -1: PV_FULLROW_DP / default; 0 / 1: A/B override (scripts/fullrow_dephase_ab.py)
+extern "C" void pv_debug_set_fullrow_dp(int on) { g_pv_frdp = on; }
+static bool pv_fullrow_dp_enabled() {
+    static const int env = [] { const char* e = getenv("PV_FULLROW_DP"); return e ? atoi(e) : 1; }();
+    return g_pv_frdp >= 0 ? g_pv_frdp != 0 : env != 0;
+}
+static int g_pv_frdelay = 0;
+extern "C" void pv_debug_set_fullrow_delay(int ticks) { g_pv_frdelay = ticks; }
 static int g_pv_frsplit = -1;
 extern "C" void pv_debug_set_fullrow_split(int on) { g_pv_frsplit = on; }
-static bool pv_fullrow_split_enabled() {
+static int pv_fullrow_split_mode() {       // 0: plain 128-row tiles, 1: split remainder (round 3), 2: de-phased launch (round 4)
     static const int env = [] { const char* e = getenv("PV_FULLROW_SPLIT"); return e ? atoi(e) : 1; }();
-    return g_pv_frsplit >= 0 ? g_pv_frsplit != 0 : env != 0;
+    return g_pv_frsplit >= 0 ? g_pv_frsplit : env;
 }
+static bool pv_fullrow_split_enabled() { return pv_fullrow_split_mode() != 0; }
 
 template <int NT>
 static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
     constexpr int lds = 2 * (128 * 64 * 2 + 64 * NT * 64 * 2);
     if (attr_set.first_use()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
     // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
     GemmDev q = p;
-    q.fr_full = 0; q.fr_half = 0;
+    q.fr_full = 0; q.fr_half = 0; q.fr_lead = 0;
+    q.fr_delay = g_pv_frdelay > 0 ? g_pv_frdelay : 0; q.fr_delay_wgs = pv_cu_count();
     unsigned grid = (unsigned)p.tiles_m;
     const int cus = pv_cu_count() & ~7;
-    if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
+    const int64_t halves = (p.M + 63) / 64;
+    const int k_rounds = cus >= 16 ? (int)(halves / cus / 2) : 0;
+    if (pv_fullrow_split_mode() == 2 && k_rounds >= 2) {
+        // half the CUs run F x k, the other half H, F x (k - 1), H; what is left over goes out as half tiles at the end
+        q.fr_lead = cus;
+        q.fr_full = cus * k_rounds - cus / 2;
+        q.fr_half = (int)(halves - 2 * (int64_t)q.fr_full);
+        grid = (unsigned)(q.fr_full + q.fr_half);
+    } else if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
         const int full = p.tiles_m / cus * cus;
         const int64_t rem = p.M - (int64_t)full * 128;
         if (rem > 0 && rem <= (int64_t)cus * 64) {
@@ -1924,7 +2147,8 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
             grid = 8u * (unsigned)(full / 8 + (q.fr_half + 7) / 8);
         }
     }
-    PV_LAUNCH(pv_gemm_fullrow_kernel<NT>, dim3(grid), dim3(512), lds, stream, q);
+    if (pv_fullrow_dp_enabled() && p.K % 128 == 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, true>), dim3(grid), dim3(512), lds, stream, q);
+    else PV_LAUNCH((pv_gemm_fullrow_kernel<NT, false>), dim3(grid), dim3(512), lds, stream, q);
     return pv_check_launch();
 }
 
