@@ -257,6 +257,50 @@ __device__ __forceinline__ void pv_ln_rows_regs(RowRegs<NCH> (&r)[JB], const flo
     }
 }
 
+// Sixteen lanes per row (round 4, the full-row GEMM's epilogue): lane l16 of a 16-lane DPP row holds the 16-byte chunks l16 + 16 k (k < KC =
+// D / 64) of ITS token row - every lane busy at any D, reductions by DPP alone, four token rows per wave at once.  The arithmetic AND its
+// order are pv_ln_rows_regs': the wave-per-row form gives lane L = l16 + 16 i the chunks L and L + 64, sums a lane's chunks first
+// ((0 + S_i) + S_{i+4}), then the 16 lanes of each DPP row, then (r0 + r1) + (r2 + r3); here a lane forms the same four partials itself and
+// runs the same DPP tree on each of them, so every row rounds identically to the standalone kernel's (tests/test_hip_ops.py, bitwise).
+// gamma / beta: the lane's chunks are read from an LDS copy (gb = gamma[D] | beta[D] floats).
+template <int KC>
+__device__ __forceinline__ void pv_ln_row16(float4 (&v)[KC], const __attribute__((address_space(3))) char* gb, int D, int l16, float eps) {
+#pragma clang fp contract(off)
+    static_assert(KC >= 4 && KC <= 8, "D = 256 .. 512");
+    float pp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s_ = 0.f;
+        s_ += pv_add_s(v[i].x + v[i].y, v[i].z + v[i].w);
+        if (i + 4 < KC) s_ += pv_add_s(v[(i + 4) % KC].x + v[(i + 4) % KC].y, v[(i + 4) % KC].z + v[(i + 4) % KC].w);
+        pp[i] = pv_row16_sum(s_);
+    }
+    const float mean = ((pp[0] + pp[1]) + (pp[2] + pp[3])) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float q_ = 0.f;
+        {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q_ += pv_add_s(a * a + bb * bb, c * c + d * d);
+        }
+        if (i + 4 < KC) {
+            const float a = v[(i + 4) % KC].x - mean, bb = v[(i + 4) % KC].y - mean, c = v[(i + 4) % KC].z - mean, d = v[(i + 4) % KC].w - mean;
+            q_ += pv_add_s(a * a + bb * bb, c * c + d * d);
+        }
+        pp[i] = pv_row16_sum(q_);
+    }
+    const float rstd = 1.0f / sqrtf(((pp[0] + pp[1]) + (pp[2] + pp[3])) / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const f32x4 g = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(gb + (l16 + 16 * k) * 16);
+        const f32x4 be = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(gb + D * 4 + (l16 + 16 * k) * 16);
+        v[k].x = (v[k].x - mean) * rstd * g[0] + be[0];
+        v[k].y = (v[k].y - mean) * rstd * g[1] + be[1];
+        v[k].z = (v[k].z - mean) * rstd * g[2] + be[2];
+        v[k].w = (v[k].w - mean) * rstd * g[3] + be[3];
+    }
+}
+
 template <int NCH>
 __device__ __forceinline__ void pv_ln_row_regs(RowRegs<NCH>& r, const float4 (&gm)[NCH], const float4 (&bt)[NCH], int D, int nvec, int lane, float eps) {
     RowRegs<NCH> one[1] = {r};

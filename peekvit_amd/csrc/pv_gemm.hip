@@ -1767,32 +1767,29 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
     __builtin_amdgcn_sched_barrier(0);
 
-    // Residual rows of the epilogue (this wave's 8 whole rows per pass, NCH x 16 B per lane and row) and their per-row scales.  Round 4: the
-    // loads run ahead of their use - the first four rows of pass 0 are issued before the LAST K-tile of the deep-pipelined loop (its counted
-    // waits leave them in flight), the other four at the start of the epilogue (they have the first batch's arithmetic to arrive under), pass 1's
-    // as pass 0 consumes its registers, four rows at a time - the stamps had 5.5 k of a pass's 16 - 18 k ticks between "loads issued" and
-    // "loads landed".
-    constexpr int NCH = (N / 4 + 63) / 64;                // float4 per lane of a whole row (pv_ln_row)
-    const int nvec = N / 4;
-    f32x4 rr[8][NCH];
-    float sc[8], lsc[8];                                   // (wave-uniform values: scalar loads)
-    auto res_scales = [&](int ps) __attribute__((always_inline)) {
+    // Epilogue row mapping (round 4): a pass is 64 rows; wave `wid` owns rows wid * 8 .. + 7 of it in two batches of four, SIXTEEN lanes per row
+    // (row = wid * 8 + 4 b + (lane >> 4); lane l16 holds the 16-byte chunks l16 + 16 k, k < KC = N / 64): every lane busy at N = 384 (the
+    // wave-per-row form of rounds 2-3 left a quarter of the lanes without a second chunk), one wave instruction = four 256-byte row segments,
+    // LayerNorm reductions by DPP alone (pv_ln_row16, same summation order as the standalone kernel).
+    // The residual rows run ahead of their use: batch 0 of pass 0 is issued before the LAST K-tile of the deep-pipelined loop (its counted
+    // waits leave the loads in flight), batch 1 at the start of the epilogue, pass 1's batches as pass 0 consumes the registers.
+    constexpr int KC = NT;
+    const int q4 = lane >> 4, l16 = lane & 15;
+    constexpr int RB = NT <= 6 ? 2 : 1;                    // batches of residual rows in registers (N = 512: 128 accumulator registers leave room for one)
+    f32x4 rr[RB][KC];
+    float sc[RB], lsc[RB];
+    auto res_load = [&](int ps, int b) __attribute__((always_inline)) {
+        const int m = m0 + ps * 64 + wid * 8 + 4 * b + q4, mr = m < p.M ? m : p.M - 1;
+        sc[b % RB] = p.row_scale ? p.row_scale[mr] : 1.0f;        // (workgroup-uniform branches)
+        lsc[b % RB] = p.ln_row_scale ? p.ln_row_scale[mr] : 1.0f;
+        const float* src = p.res + (int64_t)mr * p.ldr + l16 * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = m0 + ps * 64 + wid * 8 + j, mr = m < p.M ? m : p.M - 1;
-            sc[j] = p.row_scale ? p.row_scale[mr] : 1.0f;
-            lsc[j] = p.ln_row_scale ? p.ln_row_scale[mr] : 1.0f;
-        }
+        for (int k = 0; k < KC; ++k) rr[b % RB][k] = *reinterpret_cast<const f32x4*>(src + 64 * k);
     };
-    auto res_load = [&](int ps, int j) __attribute__((always_inline)) {
-        const int m = m0 + ps * 64 + wid * 8 + j, mr = m < p.M ? m : p.M - 1;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int idx = lane + 64 * c < nvec ? lane + 64 * c : nvec - 1;       // lanes beyond the row re-read its last chunk (never stored)
-            rr[j][c] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)mr * p.ldr + idx * 4);
-        }
-    };
-    constexpr bool RES_AHEAD = DP && NT <= 6;              // (N = 512: 128 accumulator registers leave no room for 64 more under the K loop)
+    // LayerNorm affine parameters: one float of each per thread now, written to LDS behind the first image (gamma[N] | beta[N])
+    float ln_g1 = 0.f, ln_b1 = 0.f;
+    if (p.ln_out && tid < N) { ln_g1 = p.ln_gamma[tid]; ln_b1 = p.ln_beta[tid]; }
+    constexpr bool RES_AHEAD = DP && RB == 2;
 
   if constexpr (DP) {
     // ---- deep-pipelined K loop (round 4) ----------------------------------------------------------------------------------------------
@@ -1890,7 +1887,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         if constexpr (MODE == 0) pv_wait_vmcnt<(j == 0 || j == NP - 1) ? 4 * NP - 2 : 4 * NP>();
         else if constexpr (MODE == 1) pv_wait_vmcnt<j == 0 ? 4 * NP - 2 : j == NP - 1 ? 2 * NP - 2 : 4 * NP - 2 - 2 * j>();
         else if constexpr (MODE == 2) { if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j)>(); }
-        else if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j) + 4 * NCH>();      // MODE 3: + the residual loads issued in front of this K-tile
+        else if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j) + KC>();      // MODE 3: + the (at least) KC residual loads issued in front of this K-tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1925,11 +1922,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     }
     ktile(B0{}, M1{}, kt);                               // K-tile nk - 2 (nk is even: the launcher sends other K to the plain loop)
     if constexpr (RES_AHEAD) {
-        res_scales(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) res_load(0, j);      // the first batch of pass 0; the second has the first's arithmetic to arrive under
+        res_load(0, 0);                                  // batch 0 of pass 0; batch 1 has batch 0's arithmetic to arrive under
         __builtin_amdgcn_sched_barrier(0);
-        ktile(B1{}, M3{}, kt + 1);                       // K-tile nk - 1 (4 NCH register loads younger than every LDS-DMA)
+        ktile(B1{}, M3{}, kt + 1);                       // K-tile nk - 1 (>= KC register loads younger than every LDS-DMA)
     } else ktile(B1{}, M2{}, kt + 1);
     if (wm == 0) __builtin_amdgcn_s_barrier();          // balance the stagger barrier
     PV_STAMP(2);
@@ -1992,26 +1987,16 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     // ---- epilogue ------------------------------------------------------------------------------------------------------
     typedef __attribute__((address_space(3))) char lds_c;
     lds_c* const cimg = (lds_c*)smem;
-    float4 ln_g[NCH], ln_b[NCH];                           // the lane's LayerNorm affine parameters, fetched once
-    if (p.ln_out) pv_ln_load_affine<NCH>(ln_g, ln_b, p.ln_gamma, p.ln_beta, nvec, lane);
-    if constexpr (!RES_AHEAD) res_scales(0);
-#pragma unroll
-    for (int j = RES_AHEAD ? 4 : 0; j < 8; ++j) res_load(0, j);
-    constexpr bool RES_NEXT = NT <= 6;                     // pass 1's rows fetched while pass 0 works (N = 512: no registers to spare)
+    constexpr int GB_OFF = 64 * N * 4;                     // gamma | beta behind the 64-row fp32 image (2 N floats; the K-tile buffers are 256 N + 32 KiB)
+    if constexpr (!RES_AHEAD) res_load(0, 0);
+    if constexpr (RB == 2) res_load(0, 1);
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         if (ps == 1 && half) break;                        // (workgroup-uniform) a 64-row tile has no second pass
-        if (ps == 1) {
-            res_scales(1);
-            if constexpr (!RES_NEXT) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) res_load(1, j);
-            }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // K loop (ps = 0) / the previous pass's image reads (ps = 1) are done
 #ifdef PV_STAMPS
-        if (ps == 0) { PV_STAMP(8); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PV_STAMP(9); }
+        if (ps == 0) PV_STAMP(8);
 #endif
         if (wm == ps) {
 #pragma unroll
@@ -2024,73 +2009,58 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                 }
             }
         }
+        if (ps == 0 && p.ln_out && tid < N) {              // (the region is beyond every row of the image)
+            *reinterpret_cast<__attribute__((address_space(3))) float*>(cimg + GB_OFF + tid * 4) = ln_g1;
+            *reinterpret_cast<__attribute__((address_space(3))) float*>(cimg + GB_OFF + N * 4 + tid * 4) = ln_b1;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef PV_STAMPS
         if (ps == 0) PV_STAMP(10);
 #endif
-        // the wave's 8 rows in two batches of four: image row + residual -> fp32 row store, then the LayerNorm of the four rows with their
-        // reduction chains interleaved (pv_ln_rows_regs; round 3 ran the rows one after the other: scripts/fullrow_probe.py put the fused
-        // LayerNorm at 27 us per launch where its extra bytes cost 12), 16-bit row stores
 #pragma unroll
-        for (int j0 = 0; j0 < 8; j0 += 4) {
-            RowRegs<NCH> r[4];
+        for (int b = 0; b < 2; ++b) {
+            const int row = wid * 8 + 4 * b + q4, m = m0 + ps * 64 + row;
+            float4 v[KC];
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const int j = j0 + jb, row = wid * 8 + j;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int idx = lane + 64 * c;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (idx < nvec) v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((idx ^ (row & 7)) << 4));
-                    // (scalar FMAs by inline asm: packed, hipcc broadcasts a row scale that sits in an odd register with an op_sel bit - the
-                    //  form that misreads lanes 48-63 while this pass's residual rows are still returning, pv_common.h pv_add_s)
-                    r[jb].v[c] = idx < nvec ? make_float4(pv_fma_s(sc[j], v[0], rr[j][c][0]), pv_fma_s(sc[j], v[1], rr[j][c][1]), pv_fma_s(sc[j], v[2], rr[j][c][2]),
-                                                          pv_fma_s(sc[j], v[3], rr[j][c][3]))
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);          // lanes beyond the row stay zero (pv_ln_row sums all lanes)
-                }
+            for (int k = 0; k < KC; ++k) {
+                const int c = l16 + 16 * k;
+                const f32x4 im = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((c ^ (row & 7)) << 4));
+                // (scalar FMAs by inline asm: the packed form with an op_sel bit misreads lanes 48-63 while residual rows are still returning,
+                //  pv_common.h pv_add_s)
+                v[k] = make_float4(pv_fma_s(sc[b % RB], im[0], rr[b % RB][k][0]), pv_fma_s(sc[b % RB], im[1], rr[b % RB][k][1]),
+                                   pv_fma_s(sc[b % RB], im[2], rr[b % RB][k][2]), pv_fma_s(sc[b % RB], im[3], rr[b % RB][k][3]));
             }
-            if (RES_NEXT && ps == 0 && !half) {            // (workgroup-uniform) pass 1's rows j0 .. j0+3 into the registers just consumed
-                __builtin_amdgcn_sched_barrier(0);
+            const float lsc_b = lsc[b % RB];
+            // the next rows into the registers just consumed (workgroup-uniform branches): two batches in flight -> the same batch of pass 1,
+            // one -> the next batch
+            __builtin_amdgcn_sched_barrier(0);
+            if (RB == 2) { if (ps == 0 && !half) res_load(1, b); }
+            else if (b == 0) res_load(ps, 1);
+            else if (ps == 0 && !half) res_load(1, 0);
+            if (m < p.M) {
+                float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + l16 * 4;
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) res_load(1, j0 + jb);
-            }
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const int m = m0 + ps * 64 + wid * 8 + j0 + jb;
-                if (m < p.M) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int idx = lane + 64 * c;
-                        if (idx < nvec) PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + idx * 4), ((f32x4){r[jb].v[c].x, r[jb].v[c].y, r[jb].v[c].z, r[jb].v[c].w}));
-                    }
-                }
+                for (int k = 0; k < KC; ++k) PV_STORE32(reinterpret_cast<f32x4*>(o + 64 * k), ((f32x4){v[k].x, v[k].y, v[k].z, v[k].w}));
             }
 #ifdef PV_STAMPS
-            if (ps == 0 && j0 == 0) PV_STAMP(11);
+            if (ps == 0 && b == 0) PV_STAMP(11);
 #endif
             if (p.ln_out) {                                // (workgroup-uniform)
                 // p.N (= N), not the constant: the standalone kernel divides by a RUN-TIME D, and hipcc's division by a run-time value and by
                 // a power-of-two constant differ in the last bit (found by the bit-identity test at N = 512)
-                pv_ln_rows_regs<NCH, 4>(r, ln_g, ln_b, p.N, nvec, lane, p.ln_eps);
+                pv_ln_row16<KC>(v, (const __attribute__((address_space(3))) char*)cimg + GB_OFF, p.N, l16, p.ln_eps);
+                if (m < p.M) {
+                    u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * N) + l16;
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const int j = j0 + jb, m = m0 + ps * 64 + wid * 8 + j;
-                    if (m < p.M) {
-                        u32x2* o = reinterpret_cast<u32x2*>(p.ln_out + (int64_t)m * N);
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            const int idx = lane + 64 * c;
-                            if (idx < nvec) {
-                                u32x2 pk = {pv_pack_bf16x2(pv_mul_s(r[jb].v[c].x, lsc[j]), pv_mul_s(r[jb].v[c].y, lsc[j])), pv_pack_bf16x2(pv_mul_s(r[jb].v[c].z, lsc[j]), pv_mul_s(r[jb].v[c].w, lsc[j]))};
-                                PV_STORE16(o + idx, pk);
-                            }
-                        }
+                    for (int k = 0; k < KC; ++k) {
+                        u32x2 pk = {pv_pack_bf16x2(pv_mul_s(v[k].x, lsc_b), pv_mul_s(v[k].y, lsc_b)), pv_pack_bf16x2(pv_mul_s(v[k].z, lsc_b), pv_mul_s(v[k].w, lsc_b))};
+                        PV_STORE16(o + 16 * k, pk);
                     }
                 }
             }
 #ifdef PV_STAMPS
-            if (ps == 0 && j0 == 0) PV_STAMP(12);
+            if (ps == 0 && b == 0) PV_STAMP(12);
 #endif
         }
         PV_STAMP(3 + ps);

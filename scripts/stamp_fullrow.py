@@ -41,4 +41,4 @@ for name, N, K in [("out", 384, 384), ("fc2", 384, 1536)]:
             last = 4 if kind == 0 else 3
             clk = ((x[:, last] - x[:, 0]) / ((x[:, 6] - x[:, 5]) * 10e-9)).median().item() / 1e9
             print(f"{name} K={K} dp={dp} {'half' if kind else 'full'} tiles {int(sel.sum())}: prologue {seg(0,1):.0f}  kloop {seg(1,2):.0f} ({seg(1,2) / (K // 64):.0f}/ktile)  "
-                  f"pass0 {seg(2,3):.0f} [issue res loads+barrier {seg(2,8):.0f} | loads land {seg(8,9):.0f} | image {seg(9,10):.0f} | 4 rows add+store {seg(10,11):.0f} | LN+store {seg(11,12):.0f} | rows 4-7 {seg(12,3):.0f}]  pass1 {seg(3,4) if kind == 0 else 0:.0f}  total {seg(0,last):.0f} ticks  clock {clk:.2f} GHz", flush=True)
+                  f"pass0 {seg(2,3):.0f} [K-loop end -> barrier {seg(2,8):.0f} | image + barrier {seg(8,10):.0f} | batch 0: image rows + residual -> fp32 stores {seg(10,11):.0f} | LayerNorm + 16-bit stores {seg(11,12):.0f} | batch 1 {seg(12,3):.0f}]  pass1 {seg(3,4) if kind == 0 else 0:.0f}  total {seg(0,last):.0f} ticks  clock {clk:.2f} GHz", flush=True)
