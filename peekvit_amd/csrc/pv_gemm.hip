@@ -174,9 +174,6 @@ struct GemmDev {
     int rpi, rpo, row_off, qcols;
     float qscale;
     int tiles_m, tiles_n;
-    int fr_delay_wgs;          // = the CU count (the workgroups of the first round)
-    int fr_delay;              // full-row kernel: shader-clock ticks every second group of 8 workgroups of the first round waits before it starts (de-phasing)
-    int fr_lead;               // full-row kernel, de-phased launch (round 4): the first fr_lead workgroups alternate 128- / 64-row tiles per group of 8
     int fr_full, fr_half;      // full-row kernel, split remainder: fr_full 128-row tiles (a multiple of 8) + fr_half 64-row tiles; 0, 0 = tiles_m plain tiles
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
     int gc;                    // column tiles per raster chunk (256^2 kernel): the tile list is chunk-major, so an XCD keeps the
@@ -1692,6 +1689,10 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 //  needs, scripts/fullrow_probe.py) - is bit-identical and 6 - 10 % SLOWER (N = 384: K = 384 97.8 -> 103.8 us, K = 1536 203.7 -> 223.5 us):
 //  a 32-deep stage has 64-byte rows, so every 1-KiB DMA piece touches 16 half cache lines instead of 8 whole ones, and the staging path
 //  is what bounds this loop.  A ring of 64-deep stages would need 192 KiB at N = 384.)
+// (Measured dead ends, round 4, profiles/r04_fullrow_*: de-phasing the CUs - half of them starting on a 64-row tile, or half a tile late - so that
+//  one half's epilogues run under the other half's K loops: no gain, the delay only adds; a persistent launch with the next tile's first
+//  two K-tiles staged from inside the epilogue and the parameters in LDS: bit-identical, prologue 4.1 -> 2.4 k ticks, vit_small 2 % SLOWER
+//  in the model (101.1 -> 99.0 k img/s) - a tile's wall time stayed put while its tick count moved with the clock.)
 // Epilogue: two passes of 64 rows; the wave group that owns the rows writes bias-initialised accumulators to an fp32 LDS image
 // (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 WHOLE rows: residual row from HBM, fmaf, fp32 row
 // store (N * 4 contiguous bytes), LayerNorm, 16-bit row store.
@@ -1714,22 +1715,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     // no A staging and no MFMAs for it, one epilogue pass - per row the arithmetic is unchanged.
     int m0_;
     bool half = false;
-    if (p.fr_lead > 0) {
-        // De-phased launch: the dispatcher hands out workgroups in index order, so the first round = fr_lead workgroups alternates full and
-        // half tiles per group of 8 (one per XCD); the CUs that started on a half tile stay half a tile ahead of the others for the rest of
-        // the launch, and their HBM-bound epilogues run under the other half's K loops instead of all 256 at once.
-        const int L = blockIdx.x, lead2 = p.fr_lead >> 1;
-        int f = -1, h = -1;
-        if (L < p.fr_lead) { const int i = ((L >> 4) << 3) + (L & 7); if ((L >> 3) & 1) h = i; else f = i; }
-        else if (L - p.fr_lead < p.fr_full - lead2) f = lead2 + (L - p.fr_lead);
-        else h = lead2 + (L - p.fr_lead - (p.fr_full - lead2));
-        if (f >= 0) m0_ = f * BM;
-        else {
-            if (h >= p.fr_half) return;                     // (whole workgroup: before any barrier)
-            m0_ = p.fr_full * BM + h * 64;
-            half = true;
-        }
-    } else if (p.fr_full > 0) {
+    if (p.fr_full > 0) {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3, fper = p.fr_full >> 3, q = p.fr_half >> 3, r = p.fr_half & 7;
         if (j < fper) m0_ = (x * fper + j) * BM;
         else {
@@ -1744,10 +1730,6 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     const size_t pv_stamp_slot = (size_t)blockIdx.x;
     if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 5] = rt_; p.dbg[pv_stamp_slot * 16 + 7] = (unsigned long long)(half ? 1 : 0); }
 #endif
-    if (p.fr_delay > 0 && (int)blockIdx.x < p.fr_delay_wgs && ((blockIdx.x >> 3) & 1)) {      // (workgroup-uniform)
-        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0_ < (unsigned long long)p.fr_delay) __builtin_amdgcn_s_sleep(32);
-    }
     PV_STAMP(0);
     const bool skip_mm = half && wm == 1;              // (wave-uniform)
     const int g = lane >> 4, i16 = lane & 15;
@@ -2070,17 +2052,15 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 #endif
 }
 
-static int g_pv_frdp = -1;         // -1: PV_FULLROW_DP / default; 0 / 1: A/B override (scripts/fullrow_dephase_ab.py)
+static int g_pv_frdp = -1;         // -1: PV_FULLROW_DP / default; 0 / 1: A/B override (scripts/fullrow_ab4.py)
 extern "C" void pv_debug_set_fullrow_dp(int on) { g_pv_frdp = on; }
 static bool pv_fullrow_dp_enabled() {
     static const int env = [] { const char* e = getenv("PV_FULLROW_DP"); return e ? atoi(e) : 1; }();
     return g_pv_frdp >= 0 ? g_pv_frdp != 0 : env != 0;
 }
-static int g_pv_frdelay = 0;
-extern "C" void pv_debug_set_fullrow_delay(int ticks) { g_pv_frdelay = ticks; }
 static int g_pv_frsplit = -1;
 extern "C" void pv_debug_set_fullrow_split(int on) { g_pv_frsplit = on; }
-static int pv_fullrow_split_mode() {       // 0: plain 128-row tiles, 1: split remainder (round 3), 2: de-phased launch (round 4)
+static int pv_fullrow_split_mode() {       // 0: plain 128-row tiles, 1: split remainder (round 3)
     static const int env = [] { const char* e = getenv("PV_FULLROW_SPLIT"); return e ? atoi(e) : 1; }();
     return g_pv_frsplit >= 0 ? g_pv_frsplit : env;
 }
@@ -2097,19 +2077,10 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
     // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
     GemmDev q = p;
-    q.fr_full = 0; q.fr_half = 0; q.fr_lead = 0;
-    q.fr_delay = g_pv_frdelay > 0 ? g_pv_frdelay : 0; q.fr_delay_wgs = pv_cu_count();
+    q.fr_full = 0; q.fr_half = 0;
     unsigned grid = (unsigned)p.tiles_m;
     const int cus = pv_cu_count() & ~7;
-    const int64_t halves = (p.M + 63) / 64;
-    const int k_rounds = cus >= 16 ? (int)(halves / cus / 2) : 0;
-    if (pv_fullrow_split_mode() == 2 && k_rounds >= 2) {
-        // half the CUs run F x k, the other half H, F x (k - 1), H; what is left over goes out as half tiles at the end
-        q.fr_lead = cus;
-        q.fr_full = cus * k_rounds - cus / 2;
-        q.fr_half = (int)(halves - 2 * (int64_t)q.fr_full);
-        grid = (unsigned)(q.fr_full + q.fr_half);
-    } else if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
+    if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
         const int full = p.tiles_m / cus * cus;
         const int64_t rem = p.M - (int64_t)full * 128;
         if (rem > 0 && rem <= (int64_t)cus * 64) {

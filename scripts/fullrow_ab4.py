@@ -1,5 +1,5 @@
-"""Round 4: full-row GEMM (+ fused LayerNorm) launch orders - 0 plain 128-row tiles, 1 split remainder, 2 de-phased (half the CUs start on a
-64-row tile) - interleaved, with a bit-identity check of the outputs.  Optional argv: extra mode numbers.  gpurun_out/fullrow_dephase_ab.json"""
+"""Round 4: full-row GEMM (+ fused LayerNorm) variants, interleaved, with a bit-identity check of the outputs: split remainder on / off, the plain
+or the deep-pipelined K loop.  argv: mode numbers.  gpurun_out/fullrow_ab4.json"""
 import ctypes as C, json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,9 +10,8 @@ dev = "cuda:0"
 lib = _lib.load()
 lib.pv_debug_set_fullrow_split.restype, lib.pv_debug_set_fullrow_split.argtypes = None, [C.c_int]
 lib.pv_debug_set_fullrow_dp.restype, lib.pv_debug_set_fullrow_dp.argtypes = None, [C.c_int]
-lib.pv_debug_set_fullrow_delay.restype, lib.pv_debug_set_fullrow_delay.argtypes = None, [C.c_int]
-# mode = 1000 * (delay ticks / 1000) + 10 * dp + split: dp 0 = the plain K loop (one vmcnt(0) + barrier per K-tile), 1 = the deep-pipelined one
-modes = [int(x) for x in sys.argv[1:]] or [1, 11, 2, 12]
+# mode = 10 * dp + split: dp 0 = the plain K loop (one vmcnt(0) + barrier per K-tile), 1 = the deep-pipelined one
+modes = [int(x) for x in sys.argv[1:]] or [0, 1, 10, 11]
 g = torch.Generator(device=dev).manual_seed(0)
 out = {}
 for name, M, N, K in [("vit_small out", 512 * 197, 384, 384), ("vit_small fc2", 512 * 197, 384, 1536), ("vit_tiny out B512", 512 * 401, 256, 256),
@@ -28,7 +27,6 @@ for name, M, N, K in [("vit_small out", 512 * 197, 384, 384), ("vit_small fc2", 
     def run(m):
         lib.pv_debug_set_fullrow_split(m % 10)
         lib.pv_debug_set_fullrow_dp(m // 10 % 10)
-        lib.pv_debug_set_fullrow_delay(m // 1000 * 1000)
         ops.gemm(a, w, bias, bufs[m][0], PV_EPI_BIAS_RES_F32, res=res, ln=(gam, bet, 1e-5, bufs[m][1], None))
 
     for m in modes:
@@ -50,5 +48,4 @@ for name, M, N, K in [("vit_small out", 512 * 197, 384, 384), ("vit_small fc2", 
     print(f"{name:20s} M={M:6d} N={N} K={K:4d} identical={same} " + "  ".join(f"{k} {v:7.1f} us" for k, v in r.items()) + f"   floor {nbytes / 6.29e6:6.1f} us", flush=True)
 lib.pv_debug_set_fullrow_split(-1)
 lib.pv_debug_set_fullrow_dp(-1)
-lib.pv_debug_set_fullrow_delay(0)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fullrow_dephase_ab.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fullrow_ab4.json"), "w"), indent=1)
