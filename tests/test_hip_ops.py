@@ -221,7 +221,11 @@ def test_gemm_kernels_agree_bitwise(ops):
                                    # more than one round of 128-row tiles on 256 CUs with a remainder of at most half a round: the split remainder
                                    # (whole rounds of 128-row tiles + one round of 64-row tiles, ragged last tile) of the full-row kernel; and
                                    # a remainder beyond half a round (plain 128-row tiles)
-                                   (256 * 128 + 5003, 384, 384), (2 * 256 * 128 + 64 * 256 - 1, 256, 128), (256 * 128 + 20000, 512, 128)])
+                                   (256 * 128 + 5003, 384, 384), (2 * 256 * 128 + 64 * 256 - 1, 256, 128), (256 * 128 + 20000, 512, 128),
+                                   # round 4, the deep-pipelined K loop of the full-row kernel (K % 128 == 0; K = 64 and 192 keep the plain loop): 2, 3, 5, 8 and
+                                   # 16 K-tile pairs at every width, 64-row tail tiles, fewer rows than one tile
+                                   (5000, 384, 640), (777, 256, 1024), (4097, 512, 256), (130, 384, 2048), (63, 256, 256), (3 * 128 + 1, 384, 192),
+                                   (256 * 128 + 64 * 40 + 3, 384, 768)])
 def test_gemm_fused_layernorm_bit_identical_to_separate_kernels(ops, M, N, K):
     """GEMM with fused LayerNorm (full-row tile for N = 256 / 384 / 512, row-block kernel otherwise) == plain GEMM followed by
     pv_layernorm_bf16, bit for bit (with and without row scale); N = 384 ... also cover the full-row kernel WITHOUT LayerNorm against the
