@@ -570,7 +570,10 @@ def main():
             del x, out
             infer_model.to("cpu")
             torch.cuda.empty_cache()
-            line["extra_configs"] = [extra_config(k, dev, args.steps if k in ("vit_small_fwd", "rankvit_b16_fwd") else max(5, args.steps // 2), min(args.warmup, 3) + 2)
+            # (a 5 ms step wants more than 20 of them behind one synchronize: vit_small runs 5x the steps and warm-up, half a second in all)
+            ex_steps = {"vit_small_fwd": 5 * args.steps, "rankvit_b16_fwd": args.steps}
+            ex_warm = {"vit_small_fwd": 4 * (min(args.warmup, 3) + 2)}
+            line["extra_configs"] = [extra_config(k, dev, ex_steps.get(k, max(5, args.steps // 2)), ex_warm.get(k, min(args.warmup, 3) + 2))
                                      for k in ("vit_small_fwd", "rankvit_b16_fwd", "vit_b_16_train_step", "vit_b_16_hostile_weights_fwd")]
         print(json.dumps(line), flush=True)
     if dist:
