@@ -287,6 +287,40 @@ def test_full_batch_properties_vit_b_16(monkeypatch):
     assert rel_l2(ls0, ls) < TOL_CONTRACT       # split-K only reorders fp32 sums, but a last-bit change upstream flips 16-bit roundings downstream
 
 
+def test_full_batch_properties_vit_small(monkeypatch):
+    """BASELINE config 2 size (vit_small, B = 512, 224x224: 788 row tiles of the full-row GEMM = three rounds of 128-row tiles + one of
+    64-row tiles on 256 CUs, the deep-pipelined K loop at K = 384 and 1536): permutation equivariance bit-exact; an image's logits do not
+    depend on the batch it travels in, bit for bit, once the small-batch split-K form is off; the contract against the CPU oracle on a
+    sample of the big batch."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_small")
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    small = torch.randn(8, 3, 224, 224, generator=gen).to(torch.bfloat16).float()
+    B = 512
+    big = torch.randn(B, 3, 224, 224, generator=gen).to(torch.bfloat16).float()
+    pos = [0, 63, 64, 200, 255, 256, 400, 511]
+    for p, s in zip(pos, small):
+        big[p] = s
+    with torch.no_grad():
+        lb = m(big.to(DEV)).cpu()
+        ls = m(small.to(DEV)).cpu()
+    assert torch.isfinite(lb).all()
+    assert rel_l2(lb[pos], ls) < TOL_CONTRACT
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg).items()}
+    with torch.no_grad():
+        ref = O.vit_forward(small, sd, cfg, "fp32")
+    assert rel_l2(lb[pos], ref) < TOL_CONTRACT                         # the big batch against the reference's arithmetic
+    perm = torch.randperm(B, generator=gen)
+    with torch.no_grad():
+        lp = m(big[perm].to(DEV)).cpu()
+    assert torch.equal(lp, lb[perm])
+    monkeypatch.setattr(engine, "_SMALL_M_SPLITK", False)
+    with torch.no_grad():
+        ls0 = m(small.to(DEV)).cpu()
+        lb0 = m(big.to(DEV)).cpu()
+    assert torch.equal(lb0[pos], ls0)
+
+
 def test_default_path_with_fused_layernorm_meets_the_contract():
     """At larger batches the default path has ONE all-token LayerNorm launch (block 0's ln_1; plus the last block's two launches on its
     class-token rows): ViT-B/16 folds the others into its GEMMs
