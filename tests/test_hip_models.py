@@ -186,6 +186,42 @@ def test_rankvit_keep_sets_do_not_depend_on_the_batch_size():
     assert rel_l2(keeps["big"][1][[7, 40]].numpy(), keeps["small"][1].numpy()) < TOL_CONTRACT
 
 
+def test_full_batch_properties_rankvit_b_16(golden):
+    """BASELINE config 4 size (RankViT-B/16 [3,6,9] @ 0.5, B = 2048): the two golden images, wherever they sit in the big batch, keep the
+    token sets the REFERENCE keeps for them at every ranked layer and answer within the contract; permuting the batch permutes the kept
+    indices and the logits bit for bit (ranking, compaction and every GEMM are per-image deterministic at a fixed batch size); every kept
+    index is an image token and no token is kept twice."""
+    g = golden("rankvit")
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    m.set_budget(0.5)
+    small = _x(cfg)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    B = 2048
+    big = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=gen).to(torch.bfloat16).float()
+    pos = [3, 1999]
+    big[pos[0]], big[pos[1]] = small[0], small[1]
+    with torch.no_grad():
+        lb = m(big.to(DEV)).cpu()
+    keeps = [m.encoder.layers[li].last_keep.cpu().clone() for li in (3, 6, 9)]
+    assert torch.isfinite(lb).all()
+    S = 197
+    for li, k in zip((3, 6, 9), keeps):
+        n_in = S - 1
+        S = 1 + -(-n_in // 2)
+        assert k.shape == (B, S - 1) and int(k.min()) >= 0 and int(k.max()) < n_in
+        ks = np.sort(k.numpy().astype(np.int64), axis=1)
+        assert (np.diff(ks, axis=1) > 0).all()                           # no token twice
+        ref = np.sort(g[f"vit_b_16_b0.5_keep{li}"].astype(np.int64), axis=1)
+        assert np.array_equal(ks[pos], ref)                              # = the reference's kept sets (tests/golden/rankvit.npz)
+    assert rel_l2(lb[pos].numpy(), g["vit_b_16_b0.5_logits"]) < TOL_CONTRACT
+    perm = torch.randperm(B, generator=gen)
+    with torch.no_grad():
+        lp = m(big[perm].to(DEV)).cpu()
+    assert torch.equal(lp, lb[perm])
+    for li, k in zip((3, 6, 9), keeps):
+        assert torch.equal(m.encoder.layers[li].last_keep.cpu(), k[perm])
+
+
 @pytest.mark.parametrize("tag,name,gb", [("vit_micro", "vit_micro", 10), ("vit_micro_gb0", "vit_micro", 0), ("vit_b_16", "vit_b_16", 10)])
 def test_residualvit_parity(golden, tag, name, gb):
     g = golden("residualvit")
