@@ -1734,20 +1734,31 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     const bool skip_mm = half && wm == 1;              // (wave-uniform)
     const int g = lane >> 4, i16 = lane & 15;
 
-    // accumulators start from the bias (ordinary loads, consumed before any LDS-DMA is issued)
+    // accumulators start from the bias.  Ordinary loads, consumed before any LDS-DMA is issued - or (round 4, deep-pipelined loop at N <= 384,
+    // where 4 N bytes of LDS are left behind the two K-tile buffers) an LDS-DMA of the N floats issued FIRST, so that it is older than every
+    // piece and the prologue's counted wait covers it: the bias loads' latency (~2 k ticks per tile) no longer sits in front of the first piece,
+    // and no register load sits in the queue for the compiler to drain with vmcnt(0).
+    constexpr bool BIAS_LDS = DP && NT <= 6;
+    constexpr int BIAS_OFF = 2 * BUF;
     f32x4 acc[NT][4];   // [nt][mt]: out[row wm*64 + mt*16 + i16][col wn*16*NT + nt*16 + 4g + 0..3]
+    if constexpr (BIAS_LDS) {
+        if (p.bias && wid < NT)                                // (wave-uniform) 64 floats per wave
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + wid * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(smem + BIAS_OFF + wid * 256), 4, 0, 0);
+    } else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 16 * NT + nt * 16 + 4 * g);
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 16 * NT + nt * 16 + 4 * g);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
+        __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
-    __builtin_amdgcn_sched_barrier(0);
 
     // Epilogue row mapping (round 4): a pass is 64 rows; wave `wid` owns rows wid * 8 .. + 7 of it in two batches of four, SIXTEEN lanes per row
     // (row = wid * 8 + 4 b + (lane >> 4); lane l16 holds the 16-byte chunks l16 + 16 k, k < KC = N / 64): every lane busy at N = 384 (the
@@ -1839,9 +1850,18 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     stage_a(1, 1);
 #pragma unroll
     for (int gq = 0; gq < NP - 1; ++gq) stage_w(1, gq, 1);
-    pv_wait_vmcnt<4 * NP - 2>();
+    pv_wait_vmcnt<4 * NP - 2>();                         // A(0), Wg0(0) (and the older bias) have landed: everything younger stays in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BIAS_LDS) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) char*)smem + BIAS_OFF + (wn * 16 * NT + nt * 16 + 4 * g) * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+        }
+    }
     PV_STAMP(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier interval behind group 0
 
@@ -2072,7 +2092,7 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     constexpr int lds = 2 * (128 * 64 * 2 + 64 * NT * 64 * 2);
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT <= 6 ? lds + 256 * NT : lds);      // (+ the bias)
     }
     // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
     // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
@@ -2088,7 +2108,7 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
             grid = 8u * (unsigned)(full / 8 + (q.fr_half + 7) / 8);
         }
     }
-    if (pv_fullrow_dp_enabled() && p.K % 128 == 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, true>), dim3(grid), dim3(512), lds, stream, q);
+    if (pv_fullrow_dp_enabled() && p.K % 128 == 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, true>), dim3(grid), dim3(512), NT <= 6 ? lds + 256 * NT : lds, stream, q);
     else PV_LAUNCH((pv_gemm_fullrow_kernel<NT, false>), dim3(grid), dim3(512), lds, stream, q);
     return pv_check_launch();
 }
