@@ -1674,16 +1674,18 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // Full-row tile for NARROW hidden dims: 128 rows x N (N = 256, 384 or 512 = the whole output row), 8 waves as 2 (M) x 4 (N),
 // 64 x N/4 outputs per wave, A 128 x 64 + W N x 64 per K tile in two LDS buffers (96 / 128 / 160 KiB), one workgroup per CU.
-// The residual GEMMs of vit_small / vit_tiny widths (out-proj, fc2: PV_EPI_BIAS_RES_F32) are memory- and epilogue-bound, not
-// MFMA- or power-bound (rocprof, profiles/r02_vit_small_*: MFMA busy 25 %, 2.3 GHz); with the whole row in one workgroup
+// The residual GEMMs of vit_small / vit_tiny widths (out-proj, fc2: PV_EPI_BIAS_RES_F32) are memory- and epilogue-bound rather than
+// MFMA-bound (rocprof: MFMA busy 23 %; in-kernel clock 1.2 - 2.1 GHz back to back, 2.1 GHz `sclk` at 1.2 kW in the model: close to, not
+// at, the power cap - profiles/r04_fullrow_stamps_dp.txt); with the whole row in one workgroup
 //   - N = 384 wastes no quarter-empty 256-wide column tile,
 //   - the LayerNorm that consumes the row next (ln_2 after out-proj, the next block's ln_1 after fc2) runs on the finished fp32
 //     values while they are still in the workgroup's LDS: its launch and its re-read of the residual stream disappear
 //     (models/vit.py:51+53, :55 + the next block's :48).  The per-row arithmetic is pv_ln_row (the standalone kernel's), the
 //     residual add is the 256^2 epilogue's fmaf, K is accumulated in the same order: outputs are bit-identical to
 //     pv_gemm_bf16 followed by pv_layernorm_bf16 (tests/test_hip_ops.py).
-// K loop: 2 buffers, LDS-DMA of tile kt+1 in flight under the MFMAs of tile kt, one barrier per K tile (the 128^2 kernel's
-// structure: these shapes have 6 - 24 K tiles per output tile and the epilogue moves 10 bytes per output element).
+// K loop (DP = false, K not a multiple of 128): 2 buffers, LDS-DMA of tile kt+1 in flight under the MFMAs of tile kt, one barrier per
+// K tile (the 128^2 kernel's structure).  DP = true (round 4, the default): the deep-pipelined loop described where it starts - 1.8 k
+// instead of 3.0 k ticks per K-tile.
 // (Measured dead end, round 4: the same loop as a ring of FOUR 32-deep stages with three stages of LDS-DMA in flight behind a counted
 //  vmcnt - to take the DMA latency per K tile off the critical path (3.3 k cycles per 64 of K against the 2.3 k the global -> LDS path
 //  needs, scripts/fullrow_probe.py) - is bit-identical and 6 - 10 % SLOWER (N = 384: K = 384 97.8 -> 103.8 us, K = 1536 203.7 -> 223.5 us):
@@ -1694,8 +1696,8 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 //  two K-tiles staged from inside the epilogue and the parameters in LDS: bit-identical, prologue 4.1 -> 2.4 k ticks, vit_small 2 % SLOWER
 //  in the model (101.1 -> 99.0 k img/s) - a tile's wall time stayed put while its tick count moved with the clock.)
 // Epilogue: two passes of 64 rows; the wave group that owns the rows writes bias-initialised accumulators to an fp32 LDS image
-// (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 WHOLE rows: residual row from HBM, fmaf, fp32 row
-// store (N * 4 contiguous bytes), LayerNorm, 16-bit row store.
+// (16-byte chunk c of row r at chunk c ^ (r & 7)), then every wave takes 8 whole rows, four at a time with sixteen lanes per row
+// (round 4): residual row from HBM (requested ahead), fmaf, fp32 row store, LayerNorm (pv_ln_row16), 16-bit row store.
 // ------------------------------------------------------------------------------------------------
 template <int N_>
 __device__ __forceinline__ void pv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
