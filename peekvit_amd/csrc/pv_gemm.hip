@@ -1702,8 +1702,41 @@ static int pv_launch_gemm256_rows(const GemmDev& p, hipStream_t stream) {
 template <int N_>
 __device__ __forceinline__ void pv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int NT, bool DP = false>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave; DP = the deep-pipelined K loop (round 4)
+// Immediates of the counted waits of the deep-pipelined full-row K loop, from a compile-time model of its LDS-DMA issue order (the same model
+// as scripts/fullrow_vmcnt_model.py).  NPH phases per K-tile, PW pieces per wave and W group, 2 pieces of A.  Per K-tile s a wave issues
+//   phase 0: W group NPH-1 of K-tile s+1      phase 1: A and W group 0 of K-tile s+2      phase j >= 2: W group j-1 of K-tile s+2
+// (prologue: all of K-tile 0, then K-tile 1 but its last group).  The wait at the end of phase j's load interval must leave in flight
+// exactly the pieces issued AFTER the ones phase j+1 (or phase 0 of the next K-tile) reads.  v[mode][j]: mode 0 steady state, 1 K-tile
+// nk-2, 2 K-tile nk-1 (its last phase waits for nothing).
+struct PvFrCounts { int pro; int v[3][4]; };
+constexpr PvFrCounts pv_fr_counts(int NPH, int PW) {
+    constexpr int NK = 8;                                // long enough for a steady state between prologue and tail
+    int kind[512] = {}, tile[512] = {};                  // kind 0 = A, 1 + g = W group g
+    int n = 0;
+    auto issue = [&](int k, int t, int cnt) { for (int i = 0; i < cnt; ++i) { kind[n] = k; tile[n] = t; ++n; } };
+    auto younger = [&](int k, int t) { int last = -1; for (int i = 0; i < n; ++i) if (kind[i] == k && tile[i] == t) last = i; return n - 1 - last; };
+    PvFrCounts c = {};
+    issue(0, 0, 2);
+    for (int g = 0; g < NPH; ++g) issue(1 + g, 0, PW);
+    issue(0, 1, 2);
+    for (int g = 0; g < NPH - 1; ++g) issue(1 + g, 1, PW);
+    c.pro = younger(1, 0);                               // A(0) is older than W group 0 of K-tile 0
+    for (int s = 0; s < NK; ++s)
+        for (int j = 0; j < NPH; ++j) {
+            if (j == 0) { if (s + 1 < NK) issue(NPH, s + 1, PW); }
+            else if (s + 2 < NK) { if (j == 1) { issue(0, s + 2, 2); issue(1, s + 2, PW); } else issue(j, s + 2, PW); }
+            int w = 0;
+            if (j < NPH - 1) w = younger(2 + j, s);
+            else if (s + 1 < NK) w = younger(1, s + 1);
+            const int mode = s == NK - 1 ? 2 : s == NK - 2 ? 1 : 0;
+            if (mode != 0 || s == 3) c.v[mode][j] = w;
+        }
+    return c;
+}
+
+template <int NT, int DPH = 0>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave; DPH = phases per K-tile of the deep-pipelined K loop (round 4), 0 = the plain loop
 __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
+    constexpr bool DP = DPH > 0;
     constexpr int N = 64 * NT, BM = 128, BK = 64;
     constexpr int A_BYTES = BM * BK * 2;                  // 16 KiB
     constexpr int BUF = A_BYTES + N * BK * 2;             // one K-tile buffer
@@ -1789,44 +1822,49 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
   if constexpr (DP) {
     // ---- deep-pipelined K loop (round 4) ----------------------------------------------------------------------------------------------
     // The 256^2 kernel's structure on the 128 x N tile: LDS-DMA stays in flight across raw s_barriers behind COUNTED s_waitcnt vmcnt, the
-    // two wave groups (wm = 0 / 1 = the two waves of every SIMD) run staggered by one barrier.  A K-tile is NP = NT / 2 phases of 16 MFMAs:
-    // phase j multiplies all four row tiles of the wave by its column-tile pair j.  "W group j" = the 128 weight rows all four column
-    // groups read in phase j (rows wn * 16 NT + 32 j + 0..31, wn = 0..3) = two 1-KiB pieces per wave; A = two pieces per wave.
+    // two wave groups (wm = 0 / 1 = the two waves of every SIMD) run staggered by one barrier.  A K-tile is NP phases (shipped: 2) of 8 NTP
+    // MFMAs, NTP = NT / NP: phase j multiplies all four row tiles of the wave by its column tiles NTP j .. NTP j + NTP - 1.  "W group j" = the
+    // 64 NTP weight rows the four column groups read in phase j (rows wn * 16 NT + 16 NTP j + ..) = NTP 1-KiB pieces per wave; A = two pieces.
     // Every piece is staged TWO K-tiles ahead into the slot its predecessor was last read from, one phase after that read:
     //   phase 0 of K-tile s: reads A(s), Wg0(s)      stages Wg(NP-1)(s+1) -> buffer (s+1) & 1     (last read: phase NP-1 of K-tile s-1)
     //   phase 1            : reads Wg1(s)            stages A(s+2), Wg0(s+2) -> buffer s & 1
     //   phase j >= 2       : reads Wgj(s)            stages Wg(j-1)(s+2)
-    // so a piece has 1.3 - 1.7 K-tiles (2.5 - 3 k cycles) to arrive, and 2 NP + 2 pieces per wave are issued per K-tile in a fixed order.
+    // so a piece has more than a K-tile (2.5 - 3 k cycles) to arrive, and NT + 2 pieces per wave are issued per K-tile in a fixed order.
     // The wait that covers what phase j+1 reads sits at the end of phase j's load interval (one barrier pair before the first read, so it
-    // holds for every wave of both groups); its count = the pieces issued after the needed ones (scripts/fullrow_vmcnt_model.py):
-    // steady state {4NP-2, 4NP, .., 4NP, 4NP-2}, K-tile nk-2 {4NP-2, 4NP-2-2j .., 2NP-2}, K-tile nk-1 {2(NP-2-j)}.
+    // holds for every wave of both groups); its immediate = the pieces issued after the needed ones, from the compile-time model of the
+    // issue order above (pv_fr_counts; N = 384, two phases: steady state {8, 8}, K-tile nk-2 {8, 3}, K-tile nk-1 {0}).
     // A 64-row tile still stages both A pieces (the counts assume a fixed number of operations per K-tile) and its group 1 multiplies the
     // clamped rows like any others (never stored: a branch around the MFMAs made hipcc spill the fragments).
-    constexpr int NP = NT / 2;
+    constexpr int NP = DP ? DPH : 1;                     // phases per K-tile
+    constexpr int NTP = NT / NP;                         // column tiles (16 columns) of a wave per phase = pieces per wave and W group
+    static_assert(NT % NP == 0 && NTP >= 2 && NTP <= 4, "phases of 2 - 4 column tiles");
+    constexpr PvFrCounts CNT = pv_fr_counts(NP, NTP);
     const int srow8 = lane >> 3;
     const int schunk = (lane & 7) ^ (srow8 & 7);
     const char* ga[2];
-    const char* gw[2];
-    int lw_off[2];                                       // (wave-uniform) LDS byte offset of the wave's W piece i of group 0 inside a buffer
+    const char* gw[NTP];
+    int lw_off[NTP];                                     // (wave-uniform) LDS byte offset of the wave's W piece i of group 0 inside a buffer
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int ra = m0 + j * 64 + wid * 8 + srow8; ra = ra < p.M ? ra : p.M - 1;
         ga[j] = reinterpret_cast<const char*>(p.A + (int64_t)ra * p.lda + schunk * 8);
     }
+    // W group j = the 16 NTP weight rows each of the four column groups reads in phase j (rows wn * 16 NT + 16 NTP j + ..): 8 NTP pieces of 8 rows,
+    // 2 NTP per column group; the wave's pieces are i * 8 + wid
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pc = i * 8 + wid, r0 = (pc >> 2) * 16 * NT + (pc & 3) * 8;
+    for (int i = 0; i < NTP; ++i) {
+        const int pc = i * 8 + wid, r0 = (pc / (2 * NTP)) * 16 * NT + (pc % (2 * NTP)) * 8;
         gw[i] = reinterpret_cast<const char*>(p.W + (int64_t)(r0 + srow8) * p.ldw + schunk * 8);
         lw_off[i] = A_BYTES + r0 * 128;
     }
-    const int64_t wg_stride = 64 * p.ldw;               // bytes between W groups (32 rows)
+    const int64_t wg_stride = 32 * NTP * p.ldw;         // bytes between W groups (16 NTP rows)
     auto stage_a = [&](int buf, int kt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) pv_glds16(ga[j] + kt * (BK * 2), smem + buf * BUF + j * 8192 + wid * 1024);
     };
     auto stage_w = [&](int buf, int grp, int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pv_glds16(gw[i] + grp * wg_stride + kt * (BK * 2), smem + buf * BUF + lw_off[i] + grp * 4096);
+        for (int i = 0; i < NTP; ++i) pv_glds16(gw[i] + grp * wg_stride + kt * (BK * 2), smem + buf * BUF + lw_off[i] + grp * (2048 * NTP));
     };
 
     typedef __attribute__((address_space(3))) const char lds_cc;
@@ -1842,7 +1880,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
             asm volatile("" : "+v"(a_rd[b][ks]));
             asm volatile("" : "+v"(w_rd[b][ks]));
         }
-    bf16x8 xf[4][2], wf[2][2];
+    bf16x8 xf[4][2], wf[NTP][2];
 
     const int nk = p.K / BK;
     // prologue, in the steady-state issue order: all of K-tile 0, then K-tile 1 but its last W group (phase 0 of K-tile 0 issues that)
@@ -1852,7 +1890,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     stage_a(1, 1);
 #pragma unroll
     for (int gq = 0; gq < NP - 1; ++gq) stage_w(1, gq, 1);
-    pv_wait_vmcnt<4 * NP - 2>();                         // A(0), Wg0(0) (and the older bias) have landed: everything younger stays in flight
+    pv_wait_vmcnt<CNT.pro>();                            // A(0), Wg0(0) (and the older bias) have landed: everything younger stays in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (BIAS_LDS) {
@@ -1878,20 +1916,19 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
                     xf[mt][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a_rd[B][ks] + mt * 2048);
         }
 #pragma unroll
-        for (int t_ = 0; t_ < 2; ++t_)
+        for (int t_ = 0; t_ < NTP; ++t_)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                wf[t_][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(w_rd[B][ks] + (2 * j + t_) * 2048);
+                wf[t_][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(w_rd[B][ks] + (NTP * j + t_) * 2048);
         if constexpr (j == 0) { if constexpr (MODE <= 1) stage_w(B ^ 1, NP - 1, kt + 1); }
         else if constexpr (MODE == 0) {
             if constexpr (j == 1) { stage_a(B, kt + 2); stage_w(B, 0, kt + 2); }
             else stage_w(B, j - 1, kt + 2);
         }
         // the counted wait for what the NEXT phase reads (nothing after the last phase of the last K-tile)
-        if constexpr (MODE == 0) pv_wait_vmcnt<(j == 0 || j == NP - 1) ? 4 * NP - 2 : 4 * NP>();
-        else if constexpr (MODE == 1) pv_wait_vmcnt<j == 0 ? 4 * NP - 2 : j == NP - 1 ? 2 * NP - 2 : 4 * NP - 2 - 2 * j>();
-        else if constexpr (MODE == 2) { if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j)>(); }
-        else if constexpr (j < NP - 1) pv_wait_vmcnt<2 * (NP - 2 - j) + KC>();      // MODE 3: + the (at least) KC residual loads issued in front of this K-tile
+        if constexpr (MODE <= 1) pv_wait_vmcnt<CNT.v[MODE][j]>();
+        else if constexpr (MODE == 2) { if constexpr (j < NP - 1) pv_wait_vmcnt<CNT.v[2][j]>(); }
+        else if constexpr (j < NP - 1) pv_wait_vmcnt<CNT.v[2][j] + KC>();      // MODE 3: + the (at least) KC residual loads issued in front of this K-tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1899,9 +1936,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int t_ = 0; t_ < 2; ++t_)
+            for (int t_ = 0; t_ < NTP; ++t_)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[2 * j + t_][mt] = PV_MFMA_16x16x32(wf[t_][ks], xf[mt][ks], acc[2 * j + t_][mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[NTP * j + t_][mt] = PV_MFMA_16x16x32(wf[t_][ks], xf[mt][ks], acc[NTP * j + t_][mt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -2076,9 +2113,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 
 static int g_pv_frdp = -1;         // -1: PV_FULLROW_DP / default; 0 / 1: A/B override (scripts/fullrow_ab4.py)
 extern "C" void pv_debug_set_fullrow_dp(int on) { g_pv_frdp = on; }
-static bool pv_fullrow_dp_enabled() {
+static int pv_fullrow_dp_mode() {           // 0: plain K loop, otherwise the deep-pipelined one
     static const int env = [] { const char* e = getenv("PV_FULLROW_DP"); return e ? atoi(e) : 1; }();
-    return g_pv_frdp >= 0 ? g_pv_frdp != 0 : env != 0;
+    return g_pv_frdp >= 0 ? g_pv_frdp : env;
 }
 static int g_pv_frsplit = -1;
 extern "C" void pv_debug_set_fullrow_split(int on) { g_pv_frsplit = on; }
@@ -2093,8 +2130,8 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
     constexpr int lds = 2 * (128 * 64 * 2 + 64 * NT * 64 * 2);
     if (attr_set.first_use()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT <= 6 ? lds + 256 * NT : lds);      // (+ the bias)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NT <= 6 ? lds + 256 * NT : lds);      // (+ the bias)
     }
     // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
     // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
@@ -2110,8 +2147,10 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
             grid = 8u * (unsigned)(full / 8 + (q.fr_half + 7) / 8);
         }
     }
-    if (pv_fullrow_dp_enabled() && p.K % 128 == 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, true>), dim3(grid), dim3(512), NT <= 6 ? lds + 256 * NT : lds, stream, q);
-    else PV_LAUNCH((pv_gemm_fullrow_kernel<NT, false>), dim3(grid), dim3(512), lds, stream, q);
+    // the deep-pipelined loop (K-tiles in pairs) with TWO phases of 8 NT MFMAs per K-tile: phases of 16 MFMAs (NT / 2 of them, the first form of
+    // round 4) cost a barrier pair more per K-tile at N = 384 / 512 and measured 0.4 % behind in the model (scripts/vit_small_inproc_ab.py)
+    if (p.K % 128 == 0 && pv_fullrow_dp_mode() != 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, 2>), dim3(grid), dim3(512), NT <= 6 ? lds + 256 * NT : lds, stream, q);
+    else PV_LAUNCH((pv_gemm_fullrow_kernel<NT, 0>), dim3(grid), dim3(512), lds, stream, q);
     return pv_check_launch();
 }
 
