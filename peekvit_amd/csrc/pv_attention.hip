@@ -47,6 +47,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #define PV_P_SHIFT 0.0f
 #endif
 #endif
+#define PV_P_UNSHIFT (1.0f / (float)(1 << (int)PV_P_SHIFT))       // 2^-PV_P_SHIFT, exact
 
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
 __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
@@ -731,7 +732,16 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
             for (int ks = 0; ks < KS; ++ks) { qq_[ks] = frag(Qs, qt, ks); oo_[ks] = frag(Os, qt, ks); }
             const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * g);
+            // fp16 build (round 5, fp16 training): P is packed as p * 2^PV_P_SHIFT like the forward kernel's (the fp16 MFMA flushes subnormal
+            // operands: unshifted, every p < 6.1e-5 would vanish from dV = dO^T . P); dS = P o (dP - D) keeps its own magnitude - the
+            // factor is taken out again inside the bracket, (dP - D) * 2^-PV_P_SHIFT as one FMA against the pre-scaled D - and dV is
+            // multiplied by 2^-PV_P_SHIFT (exact) where it is stored.  PV_P_SHIFT = 0 (bf16 build): the arithmetic of rounds 1-4, bit for bit.
+#ifdef PV_OPERAND_F16
+            const float mm[4] = {m4.x + PV_P_SHIFT, m4.y + PV_P_SHIFT, m4.z + PV_P_SHIFT, m4.w + PV_P_SHIFT};
+            const float dd[4] = {d4.x * PV_P_UNSHIFT, d4.y * PV_P_UNSHIFT, d4.z * PV_P_UNSHIFT, d4.w * PV_P_UNSHIFT};
+#else
             const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#endif
 #pragma unroll
             for (int t = 0; t < KPW; ++t) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = s;
@@ -744,7 +754,11 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     p[r] = key_ok[t] ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, mm[r])) : 0.f;
+#ifdef PV_OPERAND_F16
+                    ds[r] = p[r] * fmaf(c[r], PV_P_UNSHIFT, -dd[r]);
+#else
                     ds[r] = p[r] * (c[r] - dd[r]);
+#endif
                 }
                 pw[t] = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
                 dw[t] = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
@@ -794,6 +808,9 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     const u32x2 kv = {pv_pack_bf16x2(dk[t][dt][0], dk[t][dt][1]), pv_pack_bf16x2(dk[t][dt][2], dk[t][dt][3])};
+#ifdef PV_OPERAND_F16
+                    dv[t][dt] = dv[t][dt] * PV_P_UNSHIFT;
+#endif
                     const u32x2 vv = {pv_pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pv_pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
                     *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
                     *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;

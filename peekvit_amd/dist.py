@@ -14,6 +14,7 @@ the global-norm clip that follows sees fully reduced gradients.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -89,15 +90,28 @@ class OverlappedGradReducer:
     last block first).  `finish()` - called where the reference's loop has `clip_grad_norm_` (train/train.py:120) - launches what is left,
     waits for every collective and averages in place.
 
-        reducer = OverlappedGradReducer(model.parameters())
+        reducer = OverlappedGradReducer(model.parameters(), model=model)
         reducer.zero_grad()                      # (optional) gradients accumulate straight into the bucket views
-        loss.backward(); reducer.finish(); clip_grad_norm_(...); optimizer.step()
+        loss.backward(); reducer.finish(); clip_grad_norm_(...)
+        if not reducer.skip_step: optimizer.step()
 
     A loop that sets `p.grad = None` instead (autograd then hands the parameter a tensor of its own) still works: the hook moves that
-    gradient into its view - one copy, still no concatenation and no copy back."""
+    gradient into its view - one copy, still no concatenation and no copy back.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True):
+    Gradient ACCUMULATION (several backward passes per optimizer step): every backward but the last runs inside `with reducer.no_sync():`
+    (nothing is launched, the gradients add up in the bucket views); a second backward outside it before `finish()` raises - the first
+    one's all-reduces are in flight on the very buffers it would accumulate into (round-4 review).
+    Every rank launches EVERY bucket in `finish()`, gradient or not (a bucket without one travels as zeros): the collective sequence does
+    not depend on which parameters a rank's batch happened to touch.
+    `model=` (round 5): with the fp16 training arithmetic a backward whose gradients overflowed is to be SKIPPED on every rank alike:
+    `finish()` all-reduces that verdict (MAX) and reports it as `skip_step`; the buckets then hold garbage and the caller must not step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 25 << 20, average: bool = True, model: Optional[torch.nn.Module] = None):
         self.params = [p for p in params if p.requires_grad]
+        self.model, self.skip_step, self._sync = model, False, True
+        if model is not None:
+            from . import train_engine
+            train_engine.train_state(model).on_skip = lambda _m: None      # the gradients alias the buckets: never set to None; see skip_step
         self.bucket_bytes, self.average = bucket_bytes, average
         self._buckets = []                   # {"params", "views", "flat", "pending", "launched"}
         self._of = {}
@@ -135,12 +149,26 @@ class OverlappedGradReducer:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate into the buckets without launching anything (all micro-batches but the last)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def _on_grad(self, p: torch.nn.Parameter):
         b, i = self._of[id(p)]
         v = b["views"][i]
+        if b["launched"]:
+            raise RuntimeError("OverlappedGradReducer: a gradient arrived for a bucket whose all-reduce is already in flight - a second backward() "
+                               "before finish().  Run every backward but the last inside `with reducer.no_sync():`")
         if p.grad.data_ptr() != v.data_ptr():          # the loop cleared p.grad: autograd gave the parameter a tensor of its own
             v.copy_(p.grad)
             p.grad = v
+        if not self._sync:
+            return
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -163,7 +191,7 @@ class OverlappedGradReducer:
         """Launch what has not left yet, wait, average in place.  Returns the number of buckets of this step."""
         self._finishing = True
         for b in self._buckets:
-            if not b["launched"] and b["pending"] < len(b["params"]):      # (a bucket none of whose parameters received a gradient stays home)
+            if not b["launched"]:                      # every bucket leaves on every rank (round-4 review: a rank-dependent skip mismatches the collective)
                 for p, v in zip(b["params"], b["views"]):
                     if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                         if p.grad is None:
@@ -180,6 +208,14 @@ class OverlappedGradReducer:
                 b["flat"].copy_(host)
             if self.average:
                 b["flat"].div_(world)
+        self.skip_step = False
+        if self.model is not None:
+            from . import train_engine
+            if train_engine.pass_operand(self.model) == "f16" or train_engine.last_step_skipped(self.model):
+                dev = self._buckets[0]["flat"].device if self._buckets else torch.device("cpu")
+                word = torch.tensor([1.0 if train_engine.last_step_skipped(self.model) else 0.0], device="cpu" if td.get_backend() == "gloo" else dev)
+                td.all_reduce(word, op=td.ReduceOp.MAX)
+                self.skip_step = bool(word.item() > 0.0)
         n_buckets, self._work, self.buckets_launched = len(self._work), [], 0
         for b in self._buckets:
             b["pending"], b["launched"] = len(b["params"]), False

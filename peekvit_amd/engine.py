@@ -434,6 +434,20 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
             _region.active = False
 
 
+@contextlib.contextmanager
+def no_param_checks():
+    """TRAINING passes on fp16 operands (train_engine): the once-per-parameter-version host checks above would run after EVERY optimizer step -
+    some fifty device reads and as many passes over the weights per step (measured: 11 ms of a 240 ms ViT-B/16 step).  Training does not need
+    them: a weight or LayerNorm output beyond 65504 shows as an inf in the first epilogue that packs it (range flag bit 1 -> that model trains on
+    bf16 operands from then on), and weights in fp16's subnormal range cost precision, not correctness, for the one step they are used in."""
+    old = getattr(_region, "no_param_checks", False)
+    _region.no_param_checks = True
+    try:
+        yield
+    finally:
+        _region.no_param_checks = old
+
+
 def _evict_with(owner, cache: dict, key):
     """Drop `cache[key]` when `owner` (the parameter / module whose id() is in the key) is collected: an id-keyed entry must not outlive
     its object - device memory would pile up across model loads, and a recycled id could be served another object's derivative."""
@@ -448,7 +462,7 @@ _lnok: Dict[int, tuple] = {}
 
 def _check_ln_range(ln: nn.LayerNorm):
     """fp16 operands only: |LayerNorm(x)| <= max|gamma| * sqrt(D) + max|beta| must fit fp16 (checked once per parameter version)."""
-    if _lib.OPERAND != "f16":
+    if _lib.OPERAND != "f16" or getattr(_region, "no_param_checks", False):
         return
     key, ver = id(ln), (pver(ln.weight), pver(ln.bias), ln.weight.data_ptr())
     ent = _lnok.get(key)
@@ -563,7 +577,7 @@ def use_workspace(ws: "_Workspace"):
 # ------------------------------------------------------------------------------------------------
 # bf16 weight cache: one cast per (parameter storage, version)
 # ------------------------------------------------------------------------------------------------
-_wcache: Dict[tuple, tuple] = {}      # (id(param), operand) -> (weakref, version, data_ptr, cast tensor, (stream, event) | None)
+_wcache: Dict[tuple, tuple] = {}      # (id(param), operand) -> (weakref, version, data_ptr, cast tensor, (stream, event) | None, host-checked)
 
 # Cached derivatives of a parameter (16-bit copies, transposes, folded weights, LayerNorm bounds) are keyed by the tensor's autograd version
 # counter - which fused optimizers do NOT advance: torch.optim.Adam(fused=True).step() rewrites the parameters with `_version` unchanged
@@ -629,9 +643,15 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
         if ent[4] is not None:
             cur = torch.cuda.current_stream(p.device)
             if ent[4][1].query():
-                _wcache[key] = ent[:4] + (None,)
+                _wcache[key] = ent = ent[:4] + (None, ent[5])
             elif cur.cuda_stream != ent[4][0]:
                 cur.wait_event(ent[4][1])
+        if not ent[5] and _lib.OPERAND == "f16" and not getattr(_region, "no_param_checks", False):
+            # cast by a training pass (which skips the host check): an inference forward on the same parameter version checks it now
+            src = p.detach()
+            src = (src if src.dtype == torch.float32 else src.float())
+            _check_f16_cast((src if src.is_contiguous() else src.contiguous()).view(src.shape[0], -1), ent[3])
+            _wcache[key] = ent[:5] + (True,)
         return ent[3]
     src = p.detach()
     if src.dtype != torch.float32:
@@ -640,13 +660,15 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
         src = src.contiguous()
     with torch.inference_mode(False):
         w = ops.cast_bf16(src.view(src.shape[0], -1))
-    if _lib.OPERAND == "f16":                                            # once per parameter version
+    checked = _lib.OPERAND != "f16"
+    if _lib.OPERAND == "f16" and not getattr(_region, "no_param_checks", False):       # once per parameter version
         _check_f16_cast(src.view(src.shape[0], -1), w)
+        checked = True
     ev = None
     if _STREAMS > 1 and not torch.cuda.is_current_stream_capturing():
         ev = (torch.cuda.current_stream(p.device).cuda_stream, torch.cuda.Event())
         ev[1].record()
-    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), pver(p), p.data_ptr(), w, ev)
+    _wcache[key] = (weakref.ref(p, lambda _r, k=key: _wcache.pop(k, None)), pver(p), p.data_ptr(), w, ev, checked)
     return w
 
 

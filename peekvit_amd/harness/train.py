@@ -27,7 +27,7 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
     model.train()
     loss_fn = torch.nn.CrossEntropyLoss()
     last = float("nan")
-    reducer = pdist.OverlappedGradReducer(model.parameters()) if distributed else None   # buckets leave while backward still runs
+    reducer = pdist.OverlappedGradReducer(model.parameters(), model=model) if distributed else None   # buckets leave while backward still runs
     device = torch.device(device)
     if device.type == "cuda":                              # host -> HBM copy of the next batch under this step (harness.pipeline)
         from .pipeline import DevicePrefetcher
@@ -41,9 +41,11 @@ def train_epoch(model, loader, optimizer, device, clip: float, distributed: bool
         loss.backward()
         if distributed:
             reducer.finish()                               # every bucket reduced before the global-norm clip (train.py:120-121)
+        if distributed and reducer.skip_step:
+            continue                                       # an fp16 gradient overflowed on some rank (train_engine: loss scaling): every rank skips alike
         if clip:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
-        optimizer.step()
+        optimizer.step()                                   # (single process: a skipped step has every .grad = None - the optimizer passes over them)
         last = loss.detach()
     last = float(last) if torch.is_tensor(last) else last   # one read-back per epoch, not one per step
     if reducer is not None:

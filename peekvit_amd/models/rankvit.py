@@ -116,9 +116,11 @@ class RankVisionTransformer(_ViTBase):
             return x.new_zeros((0, self.num_classes), dtype=torch.float32)
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
-            with engine.on_device(x):
+            def train_body():
                 tokens = self.encoder(train_engine.embed_tokens_train(self, x), _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
+            with engine.on_device(x):
+                return train_engine.model_forward_train(self, x, train_body)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             body = lambda xs: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
             # what a ranked layer decided for every image: its kept SET (sorted indices); mode auto's self-check compares arithmetic only where

@@ -136,7 +136,7 @@ class ResidualViTBlock(ResidualModule):
             # training on the MI355X kernels: gate + masking (GateFn) and the masked block (MaskedBlockFn), both with hand-written backward;
             # block.mask is a view of the gate's output and stays differentiable for the auxiliary mask losses (utils/losses.py)
             masked, row_scale, thr, h1 = train_engine.gate_forward_train(self, input)
-            self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
+            self.mask = train_engine.enter(row_scale)[:, self.num_special_tokens:-1].unsqueeze(-1)     # (auxiliary mask losses: their gradient enters the scaled chain here)
             self.residual_gate.threshold = thr.view(-1, 1, 1)                 # what ResidualGate.forward leaves behind (residualvit.py:66)
             return train_engine.masked_block_forward_train(self, masked, row_scale, h1=h1)
         special, img, btok = self._split(input)
@@ -187,7 +187,7 @@ class ResidualViTBlock(ResidualModule):
         if self.skip == 'attention+mlp' and nq == 1 and self._hip_gated_train(input):
             # training: gate over every token (block.mask stays the full, differentiable mask), masked block on the class-token row
             masked, row_scale, thr, h1 = train_engine.gate_forward_train(self, input)
-            self.mask = row_scale[:, self.num_special_tokens:-1].unsqueeze(-1)
+            self.mask = train_engine.enter(row_scale)[:, self.num_special_tokens:-1].unsqueeze(-1)     # (auxiliary mask losses: their gradient enters the scaled chain here)
             self.residual_gate.threshold = thr.view(-1, 1, 1)
             return train_engine.block_forward_rows_train(self, masked, mask=row_scale, h1=h1)
         if self.skip == 'attention+mlp' and self._hip_gated(input):
@@ -215,6 +215,22 @@ class ResidualViTBlock(ResidualModule):
 
     def forward(self, input: torch.Tensor):
         torch._assert(input.dim() == 3, f"Expected (batch_size, seq_length, hidden_dim) got {input.shape}")
+        tp = train_engine.current_pass()
+        if tp is not None and tp.scaled and not self._trains_on_hip(input):
+            # a stock-op block in the middle of a loss-scaled fp16 training pass (skip modes 'attention' / 'mlp', gumbel gates, ...): its
+            # parameters must see TRUE gradients - the gradient leaves the scaled chain behind the block and re-enters it in front
+            with train_engine.stock_region():
+                return train_engine.leave(self._dispatch(train_engine.enter(input, tp=tp)), tp=tp)
+        return self._dispatch(input)
+
+    def _trains_on_hip(self, input: torch.Tensor) -> bool:
+        if self.skip == 'attention+mlp':
+            return self._hip_gated_train(input)
+        if self.skip in ('attention', 'mlp'):
+            return False
+        return train_engine.train_eligible(input, self, self._p_drop) and train_engine.supported(self.hidden_dim, self.num_heads, input.shape[1])
+
+    def _dispatch(self, input: torch.Tensor):
         if self.skip == 'attention':
             return self.forward_skip_attention(input)
         if self.skip == 'mlp':
@@ -314,7 +330,7 @@ class ResidualVisionTransformer(_ViTBase):
         lo, hi = self.budget_interval
         return torch.rand(n) * (hi - lo) + lo
 
-    def _add_budget_token(self, x):
+    def _add_budget_token(self, x, wrap=None):
         """Append the budget token row(s) (reference models/residualvit.py:552-585)."""
         n = x.shape[0]
         if self.training:
@@ -329,7 +345,7 @@ class ResidualVisionTransformer(_ViTBase):
                      + self.learnable_budget_token_2.expand(n, -1, -1) * (1 - self.current_budget))
         else:
             extra = torch.empty((n, 1, self.hidden_dim), device=x.device).fill_(self.current_budget)
-        return torch.cat([x, extra], dim=1)
+        return torch.cat([x, wrap(extra) if wrap is not None else extra], dim=1)
 
     def forward(self, x: torch.Tensor):
         self._check_image(x)
@@ -351,11 +367,14 @@ class ResidualVisionTransformer(_ViTBase):
             # training on the MI355X kernels end to end: patch embedding (+ class tokens, + pos_embedding) and its backward are the
             # ViT's EmbedFn; the budget token row is appended behind it (it carries no positional embedding, residualvit.py:338-345);
             # the gated blocks dispatch themselves (MaskedBlockFn); final LayerNorm + head on the class rows only
-            with engine.on_device(x):
+            def train_body():
                 tokens = train_engine.embed_tokens_train(self, x)
                 if self.add_budget_token:
-                    tokens = self._add_budget_token(tokens)
+                    # the budget-token row is built by stock ops from a parameter: its gradient LEAVES the scaled chain there
+                    tokens = self._add_budget_token(tokens, wrap=train_engine.leave)
                 return train_engine.pool_and_head_train(self, self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens))
+            with engine.on_device(x):
+                return train_engine.model_forward_train(self, x, train_body)
         tokens = self._composite_tokens(x)
         if self.add_budget_token:
             tokens = self._add_budget_token(tokens)

@@ -204,10 +204,12 @@ class VisionTransformer(_ViTBase):
             return x.new_zeros((0, self.num_classes), dtype=torch.float32)
         if train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout)) and \
                 train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length):
-            with engine.on_device(x):
+            def body():
                 tokens = train_engine.embed_tokens_train(self, x)  # same kernels, recorded for loss.backward()
                 tokens = self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens)
                 return train_engine.pool_and_head_train(self, tokens)
+            with engine.on_device(x):
+                return train_engine.model_forward_train(self, x, body)     # one training pass: operand type + loss scale (train_engine docstring)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
             return engine.run_guarded(self, x, lambda: engine.forward_split(x, self._hip_forward), probe=self._hip_forward)
         return self._composite_head(self.encoder(self._composite_tokens(x)))

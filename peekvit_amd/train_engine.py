@@ -17,28 +17,293 @@ Per encoder block (reference models/vit.py:45-55), R = B*S token rows:
             dx = dx1 + LN1'(dh1)                 (dgamma1, dbeta1)
 Data gradients (x.W) are the forward NT GEMM on the transposed bf16 weight; weight gradients (dY^T.X) are the same NT GEMM on
 the transposed activations with split-K over the R rows (pv_transpose_bf16 + pv_gemm_bf16 ksplit + pv_sum_slices_f32).
-Gradients of bf16 tensors travel in bf16 (as under torch autocast); the residual-stream gradient and all parameter
+Gradients of 16-bit tensors travel in 16 bits (as under torch autocast); the residual-stream gradient and all parameter
 gradients are fp32.
+
+Operand type (round 5).  A MODEL-level training forward in precision mode "auto" runs on IEEE fp16 operands - the library the inference
+path uses - so that the training forward sits inside the same 1e-3 contract as evaluation (bf16 operands: 4.7e-3 at ViT-B/16).  fp16
+gradients need a LOSS SCALE: everything between the head and the stem - the HIP chain - runs in "scaled space", L * dL/dx, with L a power
+of two chosen so that the largest gradient entering the chain sits at 2^7: measured on the golden models (scripts/train_f16_probe.py,
+profiles/r05_train_f16_probe.txt) the largest 16-bit gradient inside the chain is 12x the entering one (the class-row gradient fans out
+through LN2' and the attention), so the largest value anywhere sits near 1.5e3 - 40x below 65504 - and the smallest per-tensor maximum near 2,
+whose typical elements are still 300x above fp16's smallest normal number (the fp16 MFMA flushes subnormal operands).  The chain's boundaries multiply by L (where a gradient enters: behind
+the last block, `block.mask` handed to auxiliary losses) or by 1/L (where one leaves: every parameter gradient, the stem, the budget
+token) - see enter() / leave() / _unscale() - so autograd and the optimizer only ever see true gradients: the reference's loop
+(train/train.py:112-121) runs unchanged.  L follows the entering gradient's measured maximum with one step's delay (the first step reads
+it synchronously).  An fp16 overflow anywhere in the chain turns into inf / NaN that propagates to the small per-block reductions every
+backward node adds to `TrainPass.chk`; the end-of-backward callback reads that word (one host synchronisation per step - the
+reference's loop synchronises right behind it for `loss.item()`), and on overflow SKIPS the step the way torch.cuda.amp.GradScaler does
+- every parameter's `.grad` is set to None, which torch optimizers pass over - and lowers the target.  An overflow of the FORWARD
+(a 16-bit activation beyond 65504: range flag bit 1) sends that model's training to bf16 operands for good.
+Blocks called on their own under autograd (no model-level pass) keep bf16 operands and no scale, as in rounds 1-4.
 """
 from __future__ import annotations
 
+import contextlib
+import math
 import os
+import threading
+import warnings
 import weakref
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import (PV_EPI_BIAS_BF16, PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_GELU_GRAD_BF16)
 from .engine import _f32, bf16_weight, pver, workspace
 
-_wtcache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
+# ------------------------------------------------------------------------------------------------------------------------------------
+# operand type + loss scale of one training pass (module docstring)
+# ------------------------------------------------------------------------------------------------------------------------------------
+# PEEKVIT_AMD_TRAIN_OPERAND: "" (default) = fp16 in precision mode "auto", bf16 in mode "bf16"; "bf16" / "f16" force one
+_TRAIN_OPERAND = os.environ.get("PEEKVIT_AMD_TRAIN_OPERAND", "")
+SCALE_TARGET = float(os.environ.get("PEEKVIT_AMD_TRAIN_SCALE_TARGET", "128"))    # L * max|entering gradient|
+_tls = threading.local()
+debug_amax = None            # a list: BlockFn.backward appends the maxima of its 16-bit gradients (diagnostics only)
+steps_skipped = 0            # training steps skipped because an fp16 gradient overflowed (tests / bench read it)
+forward_fallbacks = 0        # models sent to bf16-operand training because their fp16 forward overflowed
+
+
+class TrainState:
+    """What the training path has learnt about one model (plain attribute `_pv_train`)."""
+    __slots__ = ("operand", "target", "amax", "scale", "steps", "skipped", "last_skipped", "on_skip", "warned")
+
+    def __init__(self):
+        self.operand = None            # None: decided per pass from the precision mode; "bf16": sticky (an fp16 forward overflowed / weights do not fit)
+        self.target = SCALE_TARGET
+        self.amax = None               # max |gradient entering the chain| of the last finished pass (host float)
+        self.scale = 1.0               # L of the last pass
+        self.steps, self.skipped, self.last_skipped = 0, 0, False
+        self.on_skip = None            # callable(model) -> None replacing the default "every .grad = None" (dist.OverlappedGradReducer)
+        self.warned = False
+
+
+def train_state(model: nn.Module) -> TrainState:
+    st = getattr(model, "_pv_train", None)
+    if st is None:
+        st = TrainState()
+        object.__setattr__(model, "_pv_train", st)
+    return st
+
+
+def last_step_skipped(model: nn.Module) -> bool:
+    """Did the last backward through `model` overflow fp16 (its gradients were dropped: skip optimizer.step() / it is a no-op)?"""
+    return train_state(model).last_skipped
+
+
+class TrainPass:
+    """One model-level training forward and the backward passes through its graph."""
+
+    def __init__(self, model: Optional[nn.Module], state: Optional[TrainState], operand: str, device):
+        self.model, self.state, self.operand = model, state, operand
+        self.scaled = operand == "f16" and model is not None
+        self.L = 1.0
+        self.active = False
+        with torch.inference_mode(False), torch.no_grad():
+            self.flag = torch.zeros(1, dtype=torch.int32, device=device) if self.scaled else None
+            self.chk = torch.zeros(1, dtype=torch.float32, device=device) if self.scaled else None
+        self.fwd_flag = None
+        self.amax = None
+
+    # -- backward side ---------------------------------------------------------------------------------------------------------
+    def begin_backward(self, grad: torch.Tensor, primary: bool) -> float:
+        """Called by the boundary nodes: the first one of a backward pass fixes L and queues the end-of-pass callback."""
+        if not self.active:
+            self.active = True
+            st = self.state
+            amax = st.amax
+            if amax is None and primary:
+                amax = float(grad.detach().abs().max())            # first pass of this model: one synchronous read
+            if amax is None or not math.isfinite(amax) or amax <= 0.0:
+                self.L = 1.0
+            else:
+                self.L = 2.0 ** max(min(math.floor(math.log2(st.target / amax)), 40), -40)
+            st.scale = self.L
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        if primary:
+            with torch.no_grad():
+                self.amax = grad.detach().abs().max()
+        return self.L
+
+    def note(self, t: torch.Tensor):
+        """A small fp32 reduction of this node's gradients (LayerNorm-backward column sums, ...): inf / NaN anywhere upstream shows here."""
+        if self.scaled:
+            with torch.no_grad():
+                self.chk.add_(t.sum())
+
+    def _finish(self):
+        global steps_skipped, forward_fallbacks
+        self.active = False
+        st = self.state
+        with torch.no_grad():
+            words = [self.chk, (self.amax if self.amax is not None else self.chk.new_zeros(())).reshape(1),
+                     (self.fwd_flag if self.fwd_flag is not None else self.flag).float()]
+            chk, amax, fbits = torch.cat(words).tolist()                 # the step's one host synchronisation
+            self.chk.zero_()
+        self.amax = None
+        fwd_over = (int(fbits) & 1) != 0
+        if math.isfinite(chk) and not fwd_over:
+            st.steps += 1
+            st.last_skipped = False
+            if amax > 0.0 and math.isfinite(amax):
+                st.amax = amax
+            return
+        st.skipped += 1
+        st.last_skipped = True
+        steps_skipped += 1
+        if fwd_over:
+            st.operand = "bf16"
+            forward_fallbacks += 1
+            warnings.warn("peekvit_amd: a 16-bit activation of the training forward left the fp16 range (|v| > 65504); this step's gradients were "
+                          "dropped and this model trains on bf16 operands from now on", RuntimeWarning, stacklevel=2)
+        else:
+            st.target = max(st.target / 4.0, 2.0)
+            st.amax = amax if amax > 0.0 and math.isfinite(amax) else st.amax
+            if not st.warned:
+                st.warned = True
+                warnings.warn(f"peekvit_amd: an fp16 gradient overflowed at loss scale {self.L:g}; this step's gradients were dropped (every .grad "
+                              "is None: optimizer.step() passes over them) and the scale target was lowered", RuntimeWarning, stacklevel=2)
+        if st.on_skip is not None:
+            st.on_skip(self.model)
+        else:
+            for p in self.model.parameters():
+                p.grad = None
+
+
+def current_pass() -> Optional[TrainPass]:
+    return getattr(_tls, "tp", None)
+
+
+def pass_operand(model: nn.Module) -> str:
+    """The operand type a model-level training forward of `model` uses now."""
+    from . import engine
+    st = train_state(model)
+    if st.operand is not None:
+        return st.operand
+    if _TRAIN_OPERAND in ("bf16", "f16"):
+        return _TRAIN_OPERAND
+    return "f16" if engine._PRECISION == "auto" else "bf16"
+
+
+@contextlib.contextmanager
+def _kernels(tp: Optional[TrainPass], operand: Optional[str] = None):
+    """Operand library + range flag of a pass on the CALLING thread (the backward runs on autograd's device thread)."""
+    op = tp.operand if tp is not None else operand
+    if op is None:
+        yield
+        return
+    from . import engine
+    old_op = _lib.set_operand(op)
+    old_flag = ops.current_range_flag()
+    ops.set_range_flag(tp.flag if tp is not None and tp.scaled else None)
+    try:
+        if tp is not None and tp.scaled:
+            with engine.no_param_checks():
+                yield
+        else:
+            yield
+    finally:
+        _lib.set_operand(old_op)
+        ops.set_range_flag(old_flag)
+
+
+def model_forward_train(model: nn.Module, x: torch.Tensor, body):
+    """Run `body()` (embed -> encoder -> pool_and_head_train, recorded by autograd) as one training pass of `model`."""
+    from . import engine
+    st = train_state(model)
+    for _attempt in range(2):
+        tp = TrainPass(model, st, pass_operand(model), x.device)
+        old = current_pass()
+        _tls.tp = tp
+        try:
+            with _kernels(tp):
+                out = body()
+            if tp.scaled:
+                with torch.no_grad():
+                    tp.fwd_flag = tp.flag.clone()
+            else:
+                st.last_skipped = False          # (a pass without a loss scale has nothing to overflow: bf16 has fp32's range)
+            return out
+        except engine.F16RangeError as e:
+            if tp.operand != "f16":
+                raise
+            st.operand = "bf16"
+            warnings.warn(f"peekvit_amd: {e}; this model trains on bf16 operands", RuntimeWarning, stacklevel=2)
+        finally:
+            _tls.tp = old
+    raise AssertionError("unreachable")
+
+
+class _ScaleGradFn(torch.autograd.Function):
+    """Identity whose backward multiplies by L (a gradient ENTERING the scaled chain) or by 1 / L (one LEAVING it)."""
+
+    @staticmethod
+    def forward(ctx, x, tp, enter, primary):
+        ctx.tp, ctx.enter, ctx.primary = tp, enter, primary
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        tp = ctx.tp
+        if ctx.enter:
+            L = tp.begin_backward(g, ctx.primary)
+            return (g if L == 1.0 else g * L), None, None, None
+        L = tp.L
+        if ctx.primary:                   # the gradient that leaves through the stem's input: the chain's last word
+            tp.note(g.reshape(g.shape[0], -1).sum(0))
+        return (g if L == 1.0 else g * (1.0 / L)), None, None, None
+
+
+def enter(t: torch.Tensor, primary: bool = False, tp: Optional[TrainPass] = None) -> torch.Tensor:
+    """Mark `t` as the place where gradients ENTER the scaled HIP chain from stock autograd (forward: identity)."""
+    tp = current_pass() if tp is None else tp
+    return _ScaleGradFn.apply(t, tp, True, primary) if tp is not None and tp.scaled and t.requires_grad else t
+
+
+def leave(t: torch.Tensor, primary: bool = False, tp: Optional[TrainPass] = None) -> torch.Tensor:
+    """Mark `t` as a place where gradients LEAVE the scaled chain into stock autograd (a stock-op parameter path feeding the chain)."""
+    tp = current_pass() if tp is None else tp
+    return _ScaleGradFn.apply(t, tp, False, primary) if tp is not None and tp.scaled and t.requires_grad else t
+
+
+@contextlib.contextmanager
+def stock_region():
+    """A stretch of stock autograd ops INSIDE a model-level pass (between leave() and enter()): HIP functions called in there are on their
+    own - no pass, bf16 operands, true gradients - exactly as when a block is called outside any model forward."""
+    old_tp = current_pass()
+    _tls.tp = None
+    old_op = _lib.set_operand("bf16")
+    old_flag = ops.current_range_flag()
+    ops.set_range_flag(None)
+    try:
+        yield
+    finally:
+        _tls.tp = old_tp
+        _lib.set_operand(old_op)
+        ops.set_range_flag(old_flag)
+
+
+def _unscale(tp: Optional[TrainPass], *grads):
+    """Parameter gradients leave the chain: one multi-tensor multiply by 1 / L (in place)."""
+    if tp is None or not tp.scaled or tp.L == 1.0:
+        return
+    ts, seen = [], set()
+    for g in grads:
+        if g is not None and g.data_ptr() not in seen:
+            seen.add(g.data_ptr())
+            ts.append(g)
+    if ts:
+        torch._foreach_mul_(ts, 1.0 / tp.L)
+
+
+_wtcache: Dict[tuple, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
 
 
 def bf16_weight_t(p: torch.Tensor) -> torch.Tensor:
-    """bf16 TRANSPOSE [K, N] of an fp32 [N, K] parameter (the 'weight' of the data-gradient GEMM), cached per version."""
-    key = id(p)
+    """16-bit TRANSPOSE [K, N] of an fp32 [N, K] parameter (the 'weight' of the data-gradient GEMM), cached per version and operand type."""
+    key = (id(p), _lib.OPERAND)
     ent = _wtcache.get(key)
     if ent is not None and ent[0]() is p and ent[1] == pver(p) and ent[2] == p.data_ptr():
         return ent[3]
@@ -67,8 +332,8 @@ def _wgrad_transposed(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, accu
     Ni = x.shape[1]
     Rp = _pad_rows(R)
     dev = dy.device
-    dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), torch.bfloat16, dev), pad_to=Rp, colsum_out=db)
-    x_t = ops.transpose(x, workspace.get("wg_b", (Ni, Rp), torch.bfloat16, dev), pad_to=Rp)
+    dy_t = ops.transpose(dy, workspace.get("wg_a", (No, Rp), _lib.operand_dtype(), dev), pad_to=Rp, colsum_out=db)
+    x_t = ops.transpose(x, workspace.get("wg_b", (Ni, Rp), _lib.operand_dtype(), dev), pad_to=Rp)
     tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
     ksplit = 1
     while ksplit < 32 and tiles * ksplit < 512 and Rp % (ksplit * 2 * 128) == 0:
@@ -153,7 +418,7 @@ class BlockFn(torch.autograd.Function):
         dh = D // H
         Mh = blk.mlp.fc1.out_features
         R, dev, eps = B * S, x.device, blk.ln_1.eps
-        bf = torch.bfloat16
+        bf = _lib.operand_dtype()
         h1 = torch.empty((R, D), dtype=bf, device=dev)
         qkv = torch.empty((R, 3 * D), dtype=bf, device=dev)
         att = torch.empty((R, D), dtype=bf, device=dev)
@@ -171,17 +436,23 @@ class BlockFn(torch.autograd.Function):
         ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=R)
         ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
         ctx.save_for_backward(x, h1, qkv, att, x1, h2, pair)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        with _kernels(ctx.tp, ctx.operand):
+            return BlockFn._bw(ctx, dout)
+
+    @staticmethod
+    def _bw(ctx, dout):
         blk = ctx.blk
         x, h1, qkv, att, x1, h2, pair = ctx.saved_tensors
         B, S, D, H, dh, Mh, qscale = ctx.dims
         gl, pre = pair[:, :Mh], pair[:, Mh:]
         mha = blk.self_attention.self_attention
-        R, dev, bf = B * S, x.device, torch.bfloat16
+        R, dev, bf = B * S, x.device, _lib.operand_dtype()
         dout = dout.float() if dout.dtype != torch.float32 else dout
         ws = workspace
 
@@ -192,6 +463,7 @@ class BlockFn(torch.autograd.Function):
         # GEMMs - a fifth of the step - and bias sums are not computed.  needs_input_grad follows forward's argument order.
         need = dict(zip(("ln1w", "ln1b", "inw", "inb", "ow", "ob", "ln2w", "ln2b", "w1", "b1", "w2", "b2"), ctx.needs_input_grad[2:14]))
         d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
+        db2_handed = db2 is not None
         dw2 = None
         if need["w2"]:
             dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
@@ -223,6 +495,12 @@ class BlockFn(torch.autograd.Function):
         dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
         dxb = torch.empty((B, S, D), dtype=bf, device=dev)
         ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        if debug_amax is not None:           # diagnostics (scripts/train_f16_probe.py): the largest 16-bit gradient of every kind in this block, in scaled units
+            debug_amax.append({k: float(v.float().abs().max()) for k, v in (("d2", d2), ("dpre", dpre), ("d1", d1), ("datt", datt), ("dqkv", dqkv), ("dh1", dhid), ("dx", dxb))})
+        if ctx.tp is not None:
+            ctx.tp.note(dgb1)
+        # parameter gradients leave the scaled chain (dbo = dgb2[2]; a handed-over db2 was unscaled by the block that produced it)
+        _unscale(ctx.tp, dgb1, dgb2, dwin, dbin, dwo, dw1, db1, dw2, None if db2_handed else db2)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])    # hand-off to the previous block's backward (see _bf16_grad)
         return (None, dx, dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2)
 
@@ -243,7 +521,7 @@ class MaskedBlockFn(torch.autograd.Function):
         H = mha.num_heads
         dh = D // H
         Mh = blk.mlp.fc1.out_features
-        R, dev, bf = B * S, x.device, torch.bfloat16
+        R, dev, bf = B * S, x.device, _lib.operand_dtype()
         h1 = torch.empty((R, D), dtype=bf, device=dev)
         qkv = torch.empty((R, 3 * D), dtype=bf, device=dev)
         att = torch.empty((R, D), dtype=bf, device=dev)
@@ -266,17 +544,23 @@ class MaskedBlockFn(torch.autograd.Function):
         ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=R)
         ops.gemm(pair[:, :Mh], bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
         ctx.save_for_backward(x, mrow, h1, qkv, att, u, x1, h2, pair)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        with _kernels(ctx.tp, ctx.operand):
+            return MaskedBlockFn._bw(ctx, dout)
+
+    @staticmethod
+    def _bw(ctx, dout):
         blk = ctx.blk
         x, mrow, h1, qkv, att, u, x1, h2, pair = ctx.saved_tensors
         B, S, D, H, dh, Mh, qscale = ctx.dims
         gl, pre = pair[:, :Mh], pair[:, Mh:]
         mha = blk.self_attention.self_attention
-        R, dev, bf = B * S, x.device, torch.bfloat16
+        R, dev, bf = B * S, x.device, _lib.operand_dtype()
         dout = dout.float() if dout.dtype != torch.float32 else dout
         ws = workspace
         dout3 = dout
@@ -284,6 +568,7 @@ class MaskedBlockFn(torch.autograd.Function):
         # frozen block weights (the reference finetunes ResidualViT's gates / class tokens / head only, train/train.py:100): no weight-gradient GEMMs
         need = dict(zip(("ln1w", "ln1b", "inw", "inb", "ow", "ob", "ln2w", "ln2b", "w1", "b1", "w2", "b2"), ctx.needs_input_grad[3:15]))
         d2, db2 = _bf16_grad(dout3, ws.get("bw_d", (R, D), bf, dev))
+        db2_handed = db2 is not None
         dw2 = None
         if need["w2"]:
             dw2, db2c = _wgrad(d2, gl, "fc2", bias_grad=db2 is None)
@@ -317,6 +602,9 @@ class MaskedBlockFn(torch.autograd.Function):
         dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
         ops.layernorm_bwd_masked(x.view(R, D), dhid, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), mrow, dx1, None, dx.view(R, D), dxb, False, dgb1,
                                  dm, True, blk.ln_1.eps)
+        if ctx.tp is not None:
+            ctx.tp.note(dgb1)
+        _unscale(ctx.tp, dgb1, dgb2, dwin, dbin, dwo, dw1, db1, dw2, None if db2_handed else db2)      # (dm stays inside the chain: it feeds GateFn)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])
         return (None, dx, dm.view(B, S), dgb1[0], dgb1[1], dwin, dbin, dwo, dbo, dgb2[0], dgb2[1], dw1, db1, dw2, db2, None)
 
@@ -335,13 +623,14 @@ class GateFn(torch.autograd.Function):
         x = x if x.is_contiguous() else x.contiguous()
         masked = torch.empty_like(x)
         thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
-        h1 = torch.empty((x.shape[0] * x.shape[1], x.shape[2]), dtype=torch.bfloat16, device=x.device) if ln is not None else None
+        h1 = torch.empty((x.shape[0] * x.shape[1], x.shape[2]), dtype=_lib.operand_dtype(), device=x.device) if ln is not None else None
         _mask, rs = ops.residual_gate(x, masked, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), temp, sbias, thr_out=thr,
                                       ln=None if ln is None else (_f32(ln[0]), _f32(ln[1]), float(ln[2]), h1))
         ctx.save_for_backward(x, wg, bg, wb, bb)
         ctx.cfg = (float(temp), float(sbias))
+        ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
         if h1 is None:
-            h1 = torch.empty((0,), dtype=torch.bfloat16, device=x.device)
+            h1 = torch.empty((0,), dtype=_lib.operand_dtype(), device=x.device)
         ctx.mark_non_differentiable(thr, h1)
         return masked, rs, thr, h1
 
@@ -351,7 +640,12 @@ class GateFn(torch.autograd.Function):
         B, S, D = x.shape
         dmasked = torch.zeros_like(x) if dmasked is None else (dmasked.float() if dmasked.dtype != torch.float32 else dmasked).contiguous()
         drs = torch.zeros((B, S), dtype=torch.float32, device=x.device) if drs is None else drs.float().contiguous()
-        dx, dwg, dbg, dwb, dbb = ops.residual_gate_bwd(x, dmasked, drs, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), *ctx.cfg)
+        with _kernels(ctx.tp, ctx.operand):
+            dx, dwg, dbg, dwb, dbb = ops.residual_gate_bwd(x, dmasked, drs, _f32(wg).view(-1), _f32(bg), _f32(wb).view(-1), _f32(bb), *ctx.cfg)
+        if ctx.tp is not None:
+            ctx.tp.note(dwg)
+        dbg, dbb = dbg.clone(), dbb.clone()        # (views of one 4-element reduction: unscaled as tensors of their own)
+        _unscale(ctx.tp, dwg, dbg, dwb, dbb)       # dx stays in the chain
         return dx, dwg.view_as(wg), dbg.view_as(bg), dwb.view_as(wb), dbb.view_as(bb), None, None, None
 
 
@@ -400,7 +694,7 @@ class RowsBlockFn(torch.autograd.Function):
         H = mha.num_heads
         dh = D // H
         Mh = blk.mlp.fc1.out_features
-        R, dev, eps, bf = B * S, x.device, blk.ln_1.eps, torch.bfloat16
+        R, dev, eps, bf = B * S, x.device, blk.ln_1.eps, _lib.operand_dtype()
         qscale = float(dh) ** -0.5
         mrow = None if m is None else (m.float() if m.dtype != torch.float32 else m).contiguous().view(R)
         h1 = torch.empty((R, D), dtype=bf, device=dev)
@@ -425,19 +719,25 @@ class RowsBlockFn(torch.autograd.Function):
         ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=B)
         ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(B, D), PV_EPI_BIAS_RES_F32, M=B, res=x1)
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
+        ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
         ctx.masked = mrow is not None
         ctx.save_for_backward(x, h1, kv, q, att, x1, h2, pair, *([mrow] if mrow is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        with _kernels(ctx.tp, ctx.operand):
+            return RowsBlockFn._bw(ctx, dout)
+
+    @staticmethod
+    def _bw(ctx, dout):
         blk = ctx.blk
         x, h1, kv, q, att, x1, h2, pair = ctx.saved_tensors[:8]
         mrow = ctx.saved_tensors[8] if ctx.masked else None
         B, S, D, H, dh, Mh, qscale = ctx.dims
         gl, pre = pair[:, :Mh], pair[:, Mh:]
         mha = blk.self_attention.self_attention
-        R, dev, bf, f32 = B * S, x.device, torch.bfloat16, torch.float32
+        R, dev, bf, f32 = B * S, x.device, _lib.operand_dtype(), torch.float32
         ws = workspace
         dout = (dout.float() if dout.dtype != f32 else dout).contiguous().view(B, D)
         # ---- MLP branch, class rows ---------------------------------------------------------------------------
@@ -494,6 +794,9 @@ class RowsBlockFn(torch.autograd.Function):
         dx[:, 0] += dx1                                                        # the residual path exists for the class rows only
         dxb[:, 0] = dx[:, 0]
         dgb1[2] += dx1.sum(0)
+        if ctx.tp is not None:
+            ctx.tp.note(dgb1)
+        _unscale(ctx.tp, dgb1, dgb2, dwin, dbin, dwo, dw1, db1, dw2, db2)
         dx._pv_bf16 = (dxb, dx._version, dgb1[2])
         return (None, dx, dm, dgb1[0], dgb1[1], dwin, dbin, dwo, dgb2[2], dgb2[0], dgb2[1], dw1, db1, dw2, db2, None)
 
@@ -514,12 +817,18 @@ class EmbedFn(torch.autograd.Function):
         from . import engine
         tokens = engine.embed_tokens(model, img)
         ctx.model = model
+        ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
         ctx.has_reg = reg is not None
         ctx.save_for_backward(img)
         return tokens
 
     @staticmethod
     def backward(ctx, dtok):
+        with _kernels(ctx.tp, ctx.operand):
+            return EmbedFn._bw(ctx, dtok)
+
+    @staticmethod
+    def _bw(ctx, dtok):
         model = ctx.model
         (img,) = ctx.saved_tensors
         dtok = dtok.float() if dtok.dtype != torch.float32 else dtok
@@ -536,9 +845,9 @@ class EmbedFn(torch.autograd.Function):
         dwc, dbc = None, None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:          # a frozen stem (gates / class tokens / head finetuning) costs nothing here
             dpatch32 = dtok[:, nsp:, :].contiguous().view(B * Np, D)
-            dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), torch.bfloat16, dev))
+            dpatch = ops.cast_bf16(dpatch32, workspace.get("bw_dgl", (B * Np, D), _lib.operand_dtype(), dev))
             if ctx.needs_input_grad[2]:
-                cols = workspace.get("cols", (B * Np, K), torch.bfloat16, dev)
+                cols = workspace.get("cols", (B * Np, K), _lib.operand_dtype(), dev)
                 if u8:
                     from .engine import IMAGENET_MEAN, IMAGENET_STD
                     ops.im2col_u8(img, P, cols, getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD))
@@ -549,6 +858,9 @@ class EmbedFn(torch.autograd.Function):
             else:
                 dbc = ops.colsum(dpatch, torch.empty((D,), dtype=torch.float32, device=dev))
         dpos = ops.colsum(dtok.view(B, S * D), torch.empty((S * D,), dtype=torch.float32, device=dev)).view(1, S, D)
+        if ctx.tp is not None:
+            ctx.tp.note(dpos)                      # the chain's last word: anything non-finite upstream has reached the token gradient
+        _unscale(ctx.tp, dwc, dbc, dpos)
         dcls = dpos[:, :ncls].clone()
         dreg = dpos[:, ncls:nsp].clone() if ctx.has_reg else None
         return (None, None, dwc, dbc, dpos, dcls, dreg)
@@ -558,7 +870,7 @@ def embed_tokens_train(model: nn.Module, img: torch.Tensor) -> torch.Tensor:
     if img.requires_grad:
         # someone differentiates with respect to the IMAGE (saliency maps, adversarial examples): EmbedFn has no col2im, so the stem runs on
         # the stock convolution (0.7 % of the FLOPs) and autograd delivers dL/d(image); the blocks behind it stay on the HIP functions
-        return model._composite_tokens(img.float() if img.dtype != torch.float32 else img) + model.encoder.pos_embedding
+        return leave(model._composite_tokens(img.float() if img.dtype != torch.float32 else img) + model.encoder.pos_embedding, primary=True)
     reg = model.register_tokens if model.num_registers > 0 else None
     return EmbedFn.apply(model, img, model.conv_proj.weight, model.conv_proj.bias, model.encoder.pos_embedding, model.class_tokens, reg)
 
@@ -595,6 +907,7 @@ def sort_and_drop_train(x: torch.Tensor, budget: float):
 def pool_and_head_train(model: nn.Module, tokens: torch.Tensor) -> torch.Tensor:
     """Final LayerNorm on the class-token rows, sum, head: [B, n_cls, D] fp32 stock ops under autograd (0.02 % of the
     step's FLOPs; the gradient re-enters the HIP backward as dL/d(tokens), zero outside the class rows)."""
+    tokens = enter(tokens, primary=True)              # stock autograd ends here: the gradient enters the (scaled) HIP chain
     cls = model.encoder.ln(tokens[:, 0:model.num_class_tokens])
     return model.head(cls.sum(dim=1))
 

@@ -57,9 +57,33 @@ def _worker(rank, world, port, out_dir):
     reducer.finish()
     views = views and all(p.grad.data_ptr() == v.data_ptr() for b in reducer._buckets for p, v in zip(b["params"], b["views"]))
     same = same and views and all(torch.equal(reduced[n], p.grad) for n, p in model.named_parameters() if p.grad is not None)
+    # gradient ACCUMULATION (round-4 review): two micro-batches per step - the first backward inside no_sync() launches nothing and adds into
+    # the bucket views, the second launches; the reduced result is the global gradient of both micro-batches.  A second backward OUTSIDE
+    # no_sync() before finish() raises instead of racing the in-flight all-reduce.
+    reducer.zero_grad()
+    xs, ys = dist.shard_batch(x), dist.shard_batch(y)
+    with reducer.no_sync():
+        (torch.nn.functional.cross_entropy(model(xs[:1]), ys[:1], reduction="sum") / x.shape[0]).backward()
+        launched_in_no_sync = reducer.buckets_launched
+    (torch.nn.functional.cross_entropy(model(xs[1:]), ys[1:], reduction="sum") / x.shape[0]).backward()
+    reducer.finish()
+    accum = all(torch.allclose(reduced[n], p.grad, rtol=1e-4, atol=1e-6) for n, p in model.named_parameters() if p.grad is not None) and launched_in_no_sync == 0
+    reducer.zero_grad()
+    (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    raised = False
+    try:
+        (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    reducer.finish()
+    # every rank launches every bucket, gradient or not (a bucket without one travels as zeros: the collective sequence must not depend on which
+    # parameters a rank's batch touched): a finish() with no backward at all still reduces all of them
+    reducer.zero_grad()
+    nb_uniform = reducer.finish()
     reducer.remove()
     if rank == 0:
-        np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same,
+        np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same, accum=accum, raised=raised,
+                 nb_uniform=nb_uniform, n_buckets=len(reducer._buckets),
                  **{"g_" + n: g.numpy() for n, g in reduced.items()})
     td.barrier()
     td.destroy_process_group()
@@ -84,5 +108,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert int(got["nb"]) > 1                                             # really bucketed
     assert int(got["nb2"]) > 1 and int(got["early"]) >= 1                 # overlapped reducer: buckets left before backward ended
     assert bool(got["same"])                                              # ... and produced bit-identical reduced gradients
+    assert bool(got["accum"]) and bool(got["raised"])                     # no_sync() accumulation; a second backward outside it is refused
+    assert int(got["nb_uniform"]) == int(got["n_buckets"])                # every bucket leaves on every rank
     for n, p in model.named_parameters():
         assert np.allclose(got["g_" + n], p.grad.numpy(), rtol=1e-4, atol=1e-6), n

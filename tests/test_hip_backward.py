@@ -491,21 +491,24 @@ def test_training_step_vs_reference_golden(golden, name, batch):
     loss = torch.nn.functional.cross_entropy(logits, y)
     loss.backward()
     assert ops.launch_count - n0 > 20 * cfg["num_layers"], "the HIP training path did not run"
-    # The forward of the TRAINING arithmetic, stated and tested (round 3 review): bf16 operands (fp16 gradients would need loss scaling), so its
-    # logits sit at the explicit "bf16" mode's distance from the reference's train-mode logits - 4e-3 .. 7e-3 measured, asserted at 1.2e-2 - and NOT
-    # inside the 1e-3 contract of the inference path; what training is held to is the gradient tolerance below (3e-2) and the loss curve.
-    assert rel_l2(logits.detach().float().cpu().numpy(), g[f"{name}/logits"]) < 1.2e-2
-    assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-3 * float(g[f"{name}/loss"])      # bf16-operand training path
+    # Round 5: the training arithmetic is the inference path's - IEEE fp16 operands, with a loss scale for the 16-bit gradients (train_engine
+    # docstring) - so the training FORWARD is inside north_star's 1e-3 (5.0e-4 .. 6.7e-4 measured; bf16 operands, rounds 1-4: 4 - 6e-3, asserted
+    # at 1.2e-2), and the gradients follow: complete gradients 3.6e-4 .. 9.8e-4 from the reference's (bf16: 3 - 8e-3, asserted at 3e-2), gradient
+    # norms 2 - 4e-4 (profiles/r05_train_f16_probe.txt).  Asserted at 1e-3 (logits), 2e-3 (gradients), 1e-3 (norms).
+    from peekvit_amd import train_engine
+    assert train_engine.pass_operand(m) == "f16" and train_engine.train_state(m).scale > 1.0 and not train_engine.last_step_skipped(m)
+    assert rel_l2(logits.detach().float().cpu().numpy(), g[f"{name}/logits"]) < 1e-3
+    assert abs(loss.item() - float(g[f"{name}/loss"])) < 2e-4 * float(g[f"{name}/loss"])
     named = dict(m.named_parameters())
     names = [str(n) for n in g[f"{name}/names"]]
     total_ref = float(g[f"{name}/total_norm"])
     gn = np.array([float(named[n].grad.norm()) for n in names])
-    assert np.all(np.abs(gn - g[f"{name}/grad_norms"]) < 3e-2 * g[f"{name}/grad_norms"] + 1e-4 * total_ref), np.abs(gn / g[f"{name}/grad_norms"] - 1).max()
+    assert np.all(np.abs(gn - g[f"{name}/grad_norms"]) < 1e-3 * g[f"{name}/grad_norms"] + 1e-5 * total_ref), np.abs(gn / g[f"{name}/grad_norms"] - 1).max()
     total = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0))
-    assert abs(total - total_ref) < 1e-2 * total_ref
+    assert abs(total - total_ref) < 1e-3 * total_ref
     for key in g.files:
         if key.startswith(f"{name}/grad/"):
-            assert rel_l2(named[key.split("/grad/")[1]].grad, g[key]) < 3e-2, key
+            assert rel_l2(named[key.split("/grad/")[1]].grad, g[key]) < 2e-3, (key, rel_l2(named[key.split("/grad/")[1]].grad, g[key]))
 
 
 def test_full_batch_training_step_is_additive_vit_b_16():
@@ -673,3 +676,113 @@ def test_training_curve_tracks_the_fp32_composite(monkeypatch):
     worst = max(abs(a - b) for a, b in zip(curves["hip"], curves["torch"]))
     assert worst < 2e-2, (worst, curves)
     assert sum(curves["hip"][-5:]) < 0.5 * sum(curves["hip"][:5]), curves["hip"]
+
+
+# ---- round 5: the fp16-operand, loss-scaled training arithmetic (train_engine module docstring) --------------------------------------------
+def test_fp16_training_is_the_default_and_scales_its_gradients():
+    """Precision mode auto: a model-level training pass runs on the fp16 operand library with a power-of-two loss scale chosen from the
+    gradient that enters the chain; autograd only ever sees TRUE gradients (parameter gradients equal the bf16-operand path's within 16-bit
+    noise - a missed boundary would be off by the scale, 2^10 or more); mode "bf16" keeps bf16 operands and no scale."""
+    from peekvit_amd import engine, train_engine
+    cfg, (m16, mbf), x, y = _train_pair("vit_tiny", 4)
+    assert train_engine.pass_operand(m16) == "f16"
+    torch.nn.functional.cross_entropy(m16(x), y).backward()
+    st = train_engine.train_state(m16)
+    assert st.scale >= 2.0 and st.steps == 1 and st.skipped == 0 and not train_engine.last_step_skipped(m16)
+    assert abs(st.scale * st.amax - train_engine.SCALE_TARGET) <= 0.5 * train_engine.SCALE_TARGET          # a power of two: within a factor 2 below the target
+    with engine.precision("bf16"):
+        assert train_engine.pass_operand(mbf) == "bf16"
+        torch.nn.functional.cross_entropy(mbf(x), y).backward()
+    assert train_engine.train_state(mbf).scale == 1.0
+    for (n, a), (_, b) in zip(m16.named_parameters(), mbf.named_parameters()):
+        assert a.grad is not None and torch.isfinite(a.grad).all(), n
+        assert rel_l2(a.grad, b.grad) < 3e-2, (n, rel_l2(a.grad, b.grad))
+
+
+def test_fp16_training_overflow_skips_the_step_like_a_grad_scaler():
+    """An fp16 gradient that overflows turns into inf / NaN, reaches the per-block check word, and the end-of-backward callback drops the step:
+    every .grad is None (torch optimizers pass over such parameters: the weights and Adam's state do not move), the scale target is lowered,
+    a warning is issued once - and the next step trains again."""
+    from peekvit_amd import train_engine
+    cfg, (m, _), x, y = _train_pair("vit_micro", 6)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    st = train_engine.train_state(m)
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    opt.step()
+    assert st.steps == 1 and st.skipped == 0
+    before = [p.detach().clone() for p in m.parameters()]
+    opt.zero_grad()
+    st.target = 2.0 ** 30                                     # scaled gradients far beyond 65504
+    skipped0 = train_engine.steps_skipped
+    with pytest.warns(RuntimeWarning, match="overflowed"):
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+    assert train_engine.last_step_skipped(m) and st.skipped == 1 and train_engine.steps_skipped == skipped0 + 1
+    assert all(p.grad is None for p in m.parameters())
+    assert float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)) == 0.0          # the reference's loop: clip, then step - both no-ops
+    opt.step()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    assert st.target < 2.0 ** 30
+    st.target = train_engine.SCALE_TARGET
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    assert not train_engine.last_step_skipped(m) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_fp16_training_forward_overflow_falls_back_to_bf16_operands():
+    """A 16-bit activation of the training forward beyond 65504 (range flag bit 1): that step is dropped and the model trains on bf16 operands
+    from then on (bf16 has fp32's range)."""
+    from peekvit_amd import train_engine
+    cfg, (m, _), x, y = _train_pair("vit_micro", 6)
+    with torch.no_grad():
+        m.encoder.layers[0].mlp.fc1.bias.fill_(3.0e5)        # gelu(3e5) = 3e5 does not fit fp16
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+    assert train_engine.last_step_skipped(m) and all(p.grad is None for p in m.parameters())
+    assert train_engine.pass_operand(m) == "bf16"
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    assert not train_engine.last_step_skipped(m) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_fp16_training_gradient_accumulation_adds_true_gradients():
+    """Two backward passes without zeroing in between (each with its own loss scale) accumulate TRUE gradients: whole batch == sum of halves."""
+    cfg, (m, m2), x, y = _train_pair("vit_tiny", 6)
+    torch.nn.functional.cross_entropy(m(x), y, reduction="sum").backward()
+    torch.nn.functional.cross_entropy(m2(x[:3]), y[:3], reduction="sum").backward()
+    torch.nn.functional.cross_entropy(m2(x[3:]), y[3:], reduction="sum").backward()
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert rel_l2(b.grad, a.grad) < 2e-3, (n, rel_l2(b.grad, a.grad))
+
+
+def test_fp16_training_with_a_stock_op_block_in_the_middle(monkeypatch):
+    """ResidualViT with skip mode 'mlp' in layer 0 (a stock-op composite) and the HIP gated block in layer 1: the composite's parameters sit
+    in the MIDDLE of the loss-scaled chain and must still see true gradients (the gradient leaves the chain behind the block and re-enters it in
+    front).  Every parameter gradient against the all-stock-op model."""
+    from peekvit_amd import ops, synth
+    from peekvit_amd.models.residualvit import ResidualVisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_micro"]
+    extra = dict(residual_layers=["mlp", "attention+mlp"], gate_temp=1, add_input=False, gate_type="sigmoid", gate_threshold=0.5,
+                 gate_bias=2, add_budget_token="learnable")
+    models = []
+    for _ in range(2):
+        m = ResidualVisionTransformer(**cfg, **extra)
+        synth.load_synth_weights(m, dict(cfg, **extra), "residualvit", seed=0)
+        models.append(m.cuda().train())
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(6, 3, cfg["image_size"], cfg["image_size"], generator=g, device="cuda").to(torch.bfloat16).float()
+    y = torch.randint(0, cfg["num_classes"], (6,), generator=g, device="cuda")
+
+    def loss_of(m):
+        torch.manual_seed(7)
+        logits = m(x)
+        return torch.nn.functional.cross_entropy(logits, y) + 0.1 * sum(blk.mask.mean() for blk in m.encoder.layers)
+
+    n0 = ops.launch_count
+    loss_of(models[0]).backward()
+    assert ops.launch_count - n0 > 30
+    monkeypatch.setenv("PEEKVIT_AMD_TRAIN", "torch")
+    loss_of(models[1]).backward()
+    for (n, a), (_, b) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert (a.grad is None) == (b.grad is None), n
+        if b.grad is not None and float(b.grad.norm()) > 0:
+            one_number = a.numel() == 1 or "budget_token_gate" in n
+            assert rel_l2(a.grad, b.grad) < (6e-2 if one_number else 3e-2), (n, rel_l2(a.grad, b.grad))
