@@ -842,6 +842,356 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention backward, round 5 form (`pv_attn_bwd2_kernel`, PV_ABW_V2): the same two wave-private passes and the same arithmetic per element as
+// pv_attn_bwd_kernel above, restaged so that TWO (three for S <= 192) workgroups share a CU and one's staging / stores run under the other's
+// MFMAs.  The round 1-4 kernel held Q, K, V and dO of its head in LDS at once (106 KiB at S = 197, dh = 64: ONE workgroup per CU) and
+// staged them through registers before anything else ran: per workgroup 21.5 us against 5.6 us of MFMA issue - each CU serialised load ->
+// compute -> store (rocprofv3, round 4: mfma_busy 0.21).  Here a workgroup is 4 waves and its LDS holds two images at a time:
+//   phase 1  K | V by LDS-DMA (the forward kernel's lane-linear swizzled images); pass 1 takes its Q / dO fragments straight from global
+//            memory (a 16-query tile per wave, like the forward kernel's Q);
+//   phase 2  Q | dO by LDS-DMA into the SAME space, issued behind the barrier that ends pass 1; pass 2 takes its K / V fragments (the
+//            wave's own key tiles) straight from global memory.
+// Rows >= S of an image duplicate row S - 1 (LDS-DMA cannot write zeros): padded KEYS are masked in both passes (score -inf / key_ok),
+// padded QUERIES get the statistic -inf, i.e. p = 0, so their (finite, duplicate) rows contribute exact zeros.  dh = 48: the pad chunk
+// of an image row duplicates chunk 0; every product over the padded columns has a zero on its register side.
+// ------------------------------------------------------------------------------------------------
+#ifndef PV_ABW_V2
+#define PV_ABW_V2 1
+#endif
+template <int DH, int NKT, int WGS>     // WGS: workgroups per CU the register budget is set for (launch bounds)
+__global__ __launch_bounds__(256, WGS) void pv_attn_bwd2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                                  uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H, float qscale) {
+    constexpr int NW = 4;
+    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;
+    constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
+    constexpr int NCH = SP * CPR, NIT = (NCH + 255) / 256;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const A_ = smem;                 // phase 1: K, phase 2: Q
+    char* const B_ = smem + IMG;           // phase 1: V, phase 2: dO
+    float* const st_m = reinterpret_cast<float*>(smem + 2 * IMG);
+    float* const st_d = st_m + SP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
+    const uint16_t* ob = dout + (int64_t)b * S * D + h * DH;
+    uint16_t* gb = dqkv + (int64_t)b * S * ld + h * DH;
+
+    // ---- LDS-DMA staging of two row-major [S, DH] matrices as swizzled images (pv_attn_kernel's scheme: physical chunk it*256 + tid) ----
+    const int lsw = (tid & 7) ^ ((tid >> 3) & 7);
+    const int r_lane = CPR == 8 ? (tid >> 3) : 2 * (tid >> 3) + (lsw >> 2);
+    int c_lane = CPR == 8 ? lsw : (lsw & 3);
+    if (c_lane * 8 >= DH) c_lane = 0;
+    auto stage = [&](const uint16_t* a, int64_t lda_, const uint16_t* bsrc, int64_t ldb_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) {
+                    int row = it * (256 / CPR) + r_lane;
+                    row = row < S ? row : S - 1;
+                    const uint16_t* src = (which ? bsrc + (int64_t)row * ldb_ : a + (int64_t)row * lda_) + c_lane * 8;
+                    const size_t dst = (size_t)(it * 256 + wid * 64) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)((which ? B_ : A_) + dst), 16, 0, 0);
+                }
+            }
+        }
+    };
+    stage(qb + D, ld, qb + 2 * D, ld);                         // K | V
+
+    int foff[KS], toff[NDT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
+    {
+        const int tq_ = i16 >> 2, tp_ = i16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+    }
+    auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * TB);
+    };
+    auto tfrag = [&](const char* X, int tile, int dt) __attribute__((always_inline)) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * TB));
+    };
+    // a 16-row tile's plain fragments from GLOBAL memory: lane (g, i16) holds X[tile*16 + i16][ks*32 + 8g .. +8], zero beyond DH, row clamped
+    auto gfrag = [&](const uint16_t* X, int64_t ldx, int tile, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
+        int r = tile * 16 + i16;
+        r = r < S ? r : S - 1;
+        const uint16_t* rp = X + (int64_t)r * ldx;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dcol = ks * 32 + 8 * g;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (dcol < DH) v = *reinterpret_cast<const u32x4*>(rp + dcol);
+            f[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    const int nqt = (S + 15) >> 4;
+    f32x4 cq[NDT], ck[NDT], cv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { cq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ck[dt] = cq[dt]; cv[dt] = cq[dt]; }
+
+    // first tile's Q / dO fragments travel with the K | V pieces
+    bf16x8 qf[KS], of[KS];
+    if (wid < nqt) { gfrag(qb, ld, wid, qf); gfrag(ob, D, wid, of); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // =============================== pass 1: per 16-query tile (K | V in LDS) ===============================
+    for (int qt = wid; qt < nqt; qt += NW) {
+        const int q0 = qt << 4;
+        f32x4 sc[NKT], dp[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                a = PV_MFMA_16x16x32(frag(A_, kt, ks), qf[ks], a, 0, 0, 0);
+                c = PV_MFMA_16x16x32(frag(B_, kt, ks), of[ks], c, 0, 0, 0);
+            }
+            sc[kt] = a; dp[kt] = c;
+        }
+        // the next tile's fragments are requested now: they arrive under this tile's softmax and dQ products
+        bf16x8 qn[KS], on[KS];
+        const bool more = qt + NW < nqt;
+        if (more) { gfrag(qb, ld, qt + NW, qn); gfrag(ob, D, qt + NW, on); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * LOG2E;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], LOG2E, nm));
+                sc[kt][r] = pe;
+                l += pe;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        float dd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] *= inv;
+                dd = fmaf(sc[kt][r], dp[kt][r], dd);
+            }
+        dd += __shfl_xor(dd, 16, 64);
+        dd += __shfl_xor(dd, 32, 64);
+        if (g == 0) {          // a padded query (duplicate of row S - 1) gets p = 0 in pass 2
+            const bool okq = q0 + i16 < S;
+            st_m[q0 + i16] = okq ? nm + __builtin_amdgcn_logf(inv) : -INFINITY;
+            st_d[q0 + i16] = okq ? dd : 0.f;
+        }
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto ds_pack = [&](int kt) __attribute__((always_inline)) {
+            return (u32x2){pv_pack_bf16x2(sc[kt][0] * (dp[kt][0] - dd), sc[kt][1] * (dp[kt][1] - dd)),
+                           pv_pack_bf16x2(sc[kt][2] * (dp[kt][2] - dd), sc[kt][3] * (dp[kt][3] - dd))};
+        };
+#pragma unroll
+        for (int tt = 0; tt < NKT / 2; ++tt) {
+            const u32x2 d0 = ds_pack(2 * tt), d1 = ds_pack(2 * tt + 1);
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const s16x8 kk = __builtin_shufflevector(tfrag(A_, 2 * tt, dt), tfrag(A_, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+                dq[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, kk), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (NKT & 1) {
+            const s16x4 dsf = __builtin_bit_cast(s16x4, ds_pack(NKT - 1));
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(tfrag(A_, NKT - 1, dt), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q0 + i16 < S) {
+            uint16_t* op = gb + (int64_t)(q0 + i16) * ld + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const u32x2 ov = {pv_pack_bf16x2(dq[dt][0] * qscale, dq[dt][1] * qscale), pv_pack_bf16x2(dq[dt][2] * qscale, dq[dt][3] * qscale)};
+                *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+                cq[dt] += (f32x4){pv_unpack_lo(ov[0]), pv_unpack_hi(ov[0]), pv_unpack_lo(ov[1]), pv_unpack_hi(ov[1])};
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qf[ks] = qn[ks]; of[ks] = on[ks]; }
+        }
+    }
+    __syncthreads();                       // every wave has left pass 1: the K | V images are free, the statistics are written
+
+    // =============================== phase 2: Q | dO images, pass 2 per unit of KPW 16-key tiles ===============================
+    stage(qb, ld, ob, D);
+    constexpr int KPW = (NKT >= 5) ? 2 : 1;         // 4 waves: two key tiles per wave from five tiles on (13 tiles = 7 units = two rounds)
+    bf16x8 kf[KPW][KS], vf[KPW][KS];
+    auto load_unit = [&](int ku) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < KPW; ++t) {
+            const int kt = ku * KPW + t, ktc = kt < NKT ? kt : NKT - 1;
+            gfrag(qb + D, ld, ktc, kf[t]);
+            gfrag(qb + 2 * D, ld, ktc, vf[t]);
+        }
+    };
+    if (wid * KPW < nqt) load_unit(wid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int ku = wid; ku * KPW < nqt; ku += NW) {
+        bool key_ok[KPW];
+        int k0[KPW];
+#pragma unroll
+        for (int t = 0; t < KPW; ++t) {
+            const int kt = ku * KPW + t;
+            k0[t] = kt << 4;
+            key_ok[t] = kt < nqt && k0[t] + i16 < S;
+        }
+        f32x4 dv[KPW][NDT], dk[KPW][NDT];
+#pragma unroll
+        for (int t = 0; t < KPW; ++t)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[t][dt] = dv[t][dt]; }
+        auto pds = [&](int qt, u32x2 (&pw)[KPW], u32x2 (&dw)[KPW]) __attribute__((always_inline)) {
+            bf16x8 qq_[KS], oo_[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qq_[ks] = frag(A_, qt, ks); oo_[ks] = frag(B_, qt, ks); }
+            const float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * g);
+#ifdef PV_OPERAND_F16
+            const float mm[4] = {m4.x + PV_P_SHIFT, m4.y + PV_P_SHIFT, m4.z + PV_P_SHIFT, m4.w + PV_P_SHIFT};
+            const float dd[4] = {d4.x * PV_P_UNSHIFT, d4.y * PV_P_UNSHIFT, d4.z * PV_P_UNSHIFT, d4.w * PV_P_UNSHIFT};
+#else
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#endif
+#pragma unroll
+            for (int t = 0; t < KPW; ++t) {
+                f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, c = s_;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s_ = PV_MFMA_16x16x32(qq_[ks], kf[t][ks], s_, 0, 0, 0);
+                    c = PV_MFMA_16x16x32(oo_[ks], vf[t][ks], c, 0, 0, 0);
+                }
+                float p[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = key_ok[t] ? __builtin_amdgcn_exp2f(fmaf(s_[r], LOG2E, mm[r])) : 0.f;
+#ifdef PV_OPERAND_F16
+                    ds[r] = p[r] * fmaf(c[r], PV_P_UNSHIFT, -dd[r]);
+#else
+                    ds[r] = p[r] * (c[r] - dd[r]);
+#endif
+                }
+                pw[t] = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
+                dw[t] = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+            }
+        };
+#pragma unroll 1
+        for (int tt = 0; tt < NKT / 2; ++tt) {
+            u32x2 p0[KPW], d0[KPW], p1[KPW], d1[KPW];
+            pds(2 * tt, p0, d0);
+            pds(2 * tt + 1, p1, d1);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const s16x8 oo = __builtin_shufflevector(tfrag(B_, 2 * tt, dt), tfrag(B_, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8 qq = __builtin_shufflevector(tfrag(A_, 2 * tt, dt), tfrag(A_, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int t = 0; t < KPW; ++t) {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[t][0], p0[t][1], p1[t][0], p1[t][1]});
+                    const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[t][0], d0[t][1], d1[t][0], d1[t][1]});
+                    dv[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, oo), pf, dv[t][dt], 0, 0, 0);
+                    dk[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, qq), dsf, dk[t][dt], 0, 0, 0);
+                }
+            }
+        }
+        if (NKT & 1) {
+            u32x2 pw[KPW], dw[KPW];
+            pds(NKT - 1, pw, dw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const s16x4 oo = tfrag(B_, NKT - 1, dt), qq = tfrag(A_, NKT - 1, dt);
+#pragma unroll
+                for (int t = 0; t < KPW; ++t) {
+                    dv[t][dt] = PV_MFMA_16x16x16(oo, __builtin_bit_cast(s16x4, pw[t]), dv[t][dt], 0, 0, 0);
+                    dk[t][dt] = PV_MFMA_16x16x16(qq, __builtin_bit_cast(s16x4, dw[t]), dk[t][dt], 0, 0, 0);
+                }
+            }
+        }
+        // the wave's next unit: its K / V fragments are requested before this unit's stores
+        const bool more = (ku + NW) * KPW < nqt;
+        bool ok_now[KPW];
+        int k0_now[KPW];
+#pragma unroll
+        for (int t = 0; t < KPW; ++t) { ok_now[t] = key_ok[t]; k0_now[t] = k0[t]; }
+        if (more) load_unit(ku + NW);
+#pragma unroll
+        for (int t = 0; t < KPW; ++t)
+            if (ok_now[t]) {
+                uint16_t* op = gb + (int64_t)(k0_now[t] + i16) * ld + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const u32x2 kv = {pv_pack_bf16x2(dk[t][dt][0], dk[t][dt][1]), pv_pack_bf16x2(dk[t][dt][2], dk[t][dt][3])};
+#ifdef PV_OPERAND_F16
+                    dv[t][dt] = dv[t][dt] * PV_P_UNSHIFT;
+#endif
+                    const u32x2 vv = {pv_pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pv_pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
+                    *reinterpret_cast<u32x2*>(op + D + dt * 16) = kv;
+                    *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = vv;
+                    ck[dt] += (f32x4){pv_unpack_lo(kv[0]), pv_unpack_hi(kv[0]), pv_unpack_lo(kv[1]), pv_unpack_hi(kv[1])};
+                    cv[dt] += (f32x4){pv_unpack_lo(vv[0]), pv_unpack_hi(vv[0]), pv_unpack_lo(vv[1]), pv_unpack_hi(vv[1])};
+                }
+            }
+    }
+    if (dbp) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [NW][3][DH]
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = pv_row16_sum(cq[dt][r]), bsum = pv_row16_sum(ck[dt][r]), c = pv_row16_sum(cv[dt][r]);
+                if (i16 == 0) {
+                    const int col = dt * 16 + 4 * g + r;
+                    red[(wid * 3 + 0) * DH + col] = a; red[(wid * 3 + 1) * DH + col] = bsum; red[(wid * 3 + 2) * DH + col] = c;
+                }
+            }
+        __syncthreads();
+        for (int e = tid; e < 3 * DH; e += NW * 64) {
+            const int part = e / DH, col = e - part * DH;
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red[(w * 3 + part) * DH + col];
+            dbp[(int64_t)b * 3 * D + part * D + h * DH + col] = t;
+        }
+    }
+}
+
+template <int DH, int NKT>
+static int pv_launch_attn_bwd2(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t stream) {
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int lds = 2 * NKT * 16 * DHP * 2 + 2 * NKT * 16 * 4;
+    // three workgroups per CU (<= 168 registers per wave) only where the kernel fits them without spilling (dh = 32 up to eleven key tiles: hipcc's
+    // own count, -Rpass-analysis=kernel-resource-usage); a scratch reload is a vector-memory operation that waits for every LDS-DMA piece in flight
+    constexpr int WGS = (DH == 32 && NKT <= 11 && 3 * lds <= 160 * 1024) ? 3 : 2;
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd2_kernel<DH, NKT, WGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    PV_LAUNCH((pv_attn_bwd2_kernel<DH, NKT, WGS>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, dout, dqkv, dbp, S, H, qscale);
+    return pv_check_launch();
+}
+
 template <int DH, int NKT>
 static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
@@ -859,7 +1209,11 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
 template <int DH>
 static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t s) {
     switch ((S + 15) / 16) {
+#if PV_ABW_V2
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd2<DH, N>(qkv, dout, dqkv, dbp, B, S, H, qscale, s);
+#else
 #define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd<DH, N>(qkv, dout, dqkv, dbp, B, S, H, qscale, s);
+#endif
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
         PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
 #undef PV_ATTN_CASE
