@@ -37,6 +37,23 @@ const char* pv_arch(void);
 int pv_operand_type(void);
 const char* pv_error_string(int code);
 
+/* Scratch sizing (ABI v8; SURVEY.md section 8b lists it in the minimum export set).  Every entry point that needs scratch takes it from the
+ * caller (`ws`, `colsum_ws`, `pv_gemm_args.colsum_partial`, the split-K slices); this returns the number of BYTES the named use needs for the
+ * given sizes, so that a C caller does not have to copy formulas out of the comments below (peekvit_amd/ops.py sizes its buffers with it).
+ * dims / ndims per `use`:
+ *   PV_WS_TRANSPOSE_COLSUM    {R, C, ldd}      pv_transpose_bf16(colsum_ws)
+ *   PV_WS_COLSUM              {R, C}           pv_colsum_f32(ws)
+ *   PV_WS_LAYERNORM_BWD       {rows, D}        pv_layernorm_bwd / pv_layernorm_bwd_masked(ws)
+ *   PV_WS_GEMM_COLSUM_PARTIAL {M, N}           pv_gemm_args.colsum_partial (PV_EPI_GELU_GRAD_BF16 on the 256-row tile kernel)
+ *   PV_WS_GEMM_SPLITK         {M, N, ksplit}   the fp32 [ksplit, M, N] slices of pv_gemm_bf16 / pv_gemm_tn_bf16 with ksplit > 1
+ * Returns a negative PV_ERR_* for an unknown use, a wrong ndims or a non-positive size. */
+#define PV_WS_TRANSPOSE_COLSUM 1
+#define PV_WS_COLSUM 2
+#define PV_WS_LAYERNORM_BWD 3
+#define PV_WS_GEMM_COLSUM_PARTIAL 4
+#define PV_WS_GEMM_SPLITK 5
+int64_t pv_workspace_size(int use, const int64_t* dims, int ndims);
+
 /* fp32 -> bf16 cast of a contiguous buffer (weights packing at load time). n elements. */
 int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
@@ -205,6 +222,12 @@ int pv_layernorm_split_bf16(const float* x, int64_t ldx, const float* gamma, con
 /* Attention core in exact fp32 (f32-input MFMA): qkv fp32 [B,S,3*H*dh] (q pre-scaled) -> out bf16 [B*S, 3*H*dh] in
  * [hi | lo | hi] planes.  dh in {32,48,64}, S <= 208. */
 int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
+/* LOCAL fallback of the attention-score guard (ABI v8): models/blocks.py:93-95 for ONE layer whose scores left PV_SCORE_LIMIT.
+ * qkv fp32 [B,S,3D] (q pre-scaled: that layer's in-projection computed in split precision - pv_layernorm_split_bf16 +
+ * pv_gemm_bf16 on the [hi|lo|hi] . [hi|hi|lo] operands with PV_EPI_BIAS_F32); out: 16-bit [B*S, D] = the ordinary operand of the
+ * out-projection GEMM of the library's operand type.  Scores from split operands (q = q_hi + q_lo, k likewise: three MFMA products),
+ * probabilities and P.V as in pv_attention_bf16.  dh in {32, 48, 64}; S <= 208 (416 at dh = 32). */
+int pv_attention_split_bf16(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream);
 
 /* Weight-gradient GEMM without transposed copies ("TN"): out[t][m][n] = sum over K slice t of A[k][m] * W[k][n], with
  * A = dY bf16 [K, M] (row stride lda), W = X bf16 [K, N] (row stride ldw), out fp32 [ksplit][M][ldo] partial slices for

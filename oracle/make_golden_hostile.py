@@ -43,13 +43,20 @@ def main():
     VT, _, _ = import_reference()
     torch.set_num_threads(8)
     out = {}
-    for name, which in (("vit_tiny", ("hostile", "loguniform", "ln_gain", "massive_token")), ("vit_b_16", ("hostile", "loguniform"))):
+    path = os.path.join(GOLD, "hostile.npz")
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+    if only and os.path.exists(path):
+        # add variants to the fixture file without touching the entries it already holds (round 5: --only=trained_like)
+        out = {k: v for k, v in np.load(path).items()}
+    for name, which in (("vit_tiny", ("hostile", "loguniform", "ln_gain", "massive_token", "trained_like")), ("vit_b_16", ("hostile", "loguniform", "trained_like"))):
         vs = synth.hostile_variants(synth.MODEL_CONFIGS[name])
         for v in which:
+            if only and v not in only:
+                continue
             logits, rows = run(VT, name, vs[v])
             out[f"{name}/{v}/logits"], out[f"{name}/{v}/block_cls"] = logits, rows
             print(f"  {name} {v}: |logits| mean {np.abs(logits).mean():.4f}  max |class row| {np.abs(rows).max():.3g}")
-    np.savez_compressed(os.path.join(GOLD, "hostile.npz"), **out)
+    np.savez_compressed(path, **out)
     import json
     with open(os.path.join(GOLD, "hostile_meta.json"), "w") as f:
         json.dump({"reference_sha256": reference_sha256(), "torch": torch.__version__}, f, indent=1, sort_keys=True)

@@ -22,6 +22,7 @@ _i64, _f32, _p, _i32 = C.c_int64, C.c_float, C.c_void_p, C.c_int32
 PV_EPI_BIAS_BF16, PV_EPI_BIAS_GELU_BF16, PV_EPI_BIAS_RES_F32, PV_EPI_BIAS_POS_F32 = 0, 1, 2, 3
 PV_EPI_BIAS_F32, PV_EPI_BIAS_GELU_SPLIT_BF16 = 4, 5
 PV_EPI_BIAS_GELU_PAIR_BF16, PV_EPI_GELU_GRAD_BF16 = 6, 7
+PV_WS_TRANSPOSE_COLSUM, PV_WS_COLSUM, PV_WS_LAYERNORM_BWD, PV_WS_GEMM_COLSUM_PARTIAL, PV_WS_GEMM_SPLITK = 1, 2, 3, 4, 5
 
 
 class GemmArgs(C.Structure):
@@ -37,7 +38,7 @@ class GemmArgs(C.Structure):
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
-        self.struct_size = C.sizeof(GemmArgs)      # ABI v7: the library refuses a struct of another length
+        self.struct_size = C.sizeof(GemmArgs)      # since ABI v7: the library refuses a struct of another length
 
 
 # name -> (restype, argtypes); every symbol include/peekvit_hip.h declares
@@ -53,6 +54,8 @@ SIGNATURES = {
     "pv_im2col_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_split_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_attention_f32_split": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_attention_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
+    "pv_workspace_size": (C.c_int64, [C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "pv_gemm_tn_bf16": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "pv_sum_slices_f32": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
     "pv_sum_slices_add_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
@@ -86,7 +89,7 @@ SIGNATURES = {
     "pv_residual_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lock = threading.Lock()
 _libs: dict = {}
 

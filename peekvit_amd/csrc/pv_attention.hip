@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
             if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
         // ---- softmax numerator: in-lane over 4*NKT keys, then across the 4 lane groups ------------------------
         float m = -INFINITY;
+        // Round 5: the maxima below are INLINE ASM, which the hazard recognizer does not look into: hipcc (ROCm 7.2) scheduled them two
+        // instructions behind the MFMA that writes their operands (dh = 32, second query tile of a wave: v_mfma v[6:9] ... v_max3 v32, v32, v6, v7
+        // three lines later), so a maximum could be formed from what those registers held BEFORE - harmless as long as every exp2(s - m) stays
+        // finite, non-finite output rows as soon as a missed score exceeds the stale maximum by more than the packing headroom (fp16 build:
+        // 2^6; scripts/dbg/attn_nonfinite.py: 4 of 198 rows at S = 99, dh = 32 on N(0,1) scores, 70 rows at scores ~50; the cause of round 3's
+        // "carried maximum" NaN rows).  Fix: every score tile is pinned behind its MFMA by an (empty) volatile asm, then one volatile asm of
+        // 20 wait states - more than the 18 the longest MFMA needs before a vector read - through which the running maximum passes: the
+        // maxima cannot start before it, and it cannot start before the last MFMA has been issued.
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) asm volatile("" : "+v"(sc[kt]));
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(m));
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {      // v_max3: two scores per instruction, no canonicalising v_max pairs
             asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(sc[kt][0]), "v"(sc[kt][1]));
@@ -533,6 +544,226 @@ static int pv_dispatch_attn_f32(const float* qkv, uint16_t* out, int64_t B, int 
         }
     }
     return PV_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LOCAL fallback of the attention-score guard (round 5): the same attention with the SCORES computed from split operands.
+//   in : qkv fp32 [B,S,3D] (q pre-scaled) - the in-projection of THIS layer computed in split precision (bf16x3 GEMM, PV_EPI_BIAS_F32)
+//   out: 16-bit [B*S, D], the operand of the ordinary out-projection GEMM
+// The rounding of q and k to 16 bits leaves an error in a score that grows with the score, and the softmax turns it into a relative error of
+// the probabilities (PV_SCORE_LIMIT above).  Here q = q_hi + q_lo, k = k_hi + k_lo (two 16-bit halves each: 22 mantissa bits in the fp16 build)
+// and S^T = k_hi.q_hi + (k_hi.q_lo + k_lo.q_hi): three MFMA products per score tile instead of one, everything behind the scores - p = exp(s - m)
+// packed to 16 bits, O^T = V^T.P^T with v rounded once - exactly pv_attn_kernel's (an error of 2^-11 in p or v is not amplified by anything).
+// fp16 build: the lo halves are packed times 2^11 (exact) into an accumulator of their own - unscaled, the lo half of every |q| < 0.125 would
+// be an fp16 subnormal, which the MFMA flushes - and the accumulators are joined by one FMA per score.
+// One workgroup (4 waves) per (image, head), K_hi | K_lo | V images in LDS (80 KiB at S = 197, dh = 64: two workgroups per CU), staged through
+// registers (the split has to happen on the way); rows >= S duplicate row S - 1 and are masked like pv_attn_kernel's.
+// ------------------------------------------------------------------------------------------------
+#ifdef PV_OPERAND_F16
+#define PV_LO_SCALE 2048.0f
+#else
+#define PV_LO_SCALE 1.0f
+#endif
+__device__ __forceinline__ void pv_split8(const float4 a, const float4 b, u32x4& hi, u32x4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t h = pv_pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = pv_pack_bf16x2((v[2 * i] - pv_unpack_lo(h)) * PV_LO_SCALE, (v[2 * i + 1] - pv_unpack_hi(h)) * PV_LO_SCALE);
+    }
+}
+
+template <int DH, int NKT>
+__global__ __launch_bounds__(256, 2) void pv_attn_split_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
+    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, KS = DHP / 32, NKT32 = NKT / 2, SP = NKT * 16, NDT = DH / 16, IMG = SP * DHP * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Kh = smem;
+    char* const Kl = smem + IMG;
+    char* const Vs = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const float* qb = qkv + (int64_t)b * S * ld + h * DH;
+
+    // ---- stage K (split) and V: one 16-byte operand chunk (8 values) per thread and trip ----
+    for (int e = tid; e < SP * CPR; e += 256) {
+        const int row = e / CPR, c = e - row * CPR;
+        const int r = row < S ? row : S - 1;
+        u32x4 kh = {0u, 0u, 0u, 0u}, kl = kh, vv = kh;
+        if (c * 8 < DH) {
+            const float* rp = qb + (int64_t)r * ld + c * 8;
+            const float4 k0 = *reinterpret_cast<const float4*>(rp + D), k1 = *reinterpret_cast<const float4*>(rp + D + 4);
+            const float4 v0 = *reinterpret_cast<const float4*>(rp + 2 * D), v1 = *reinterpret_cast<const float4*>(rp + 2 * D + 4);
+            pv_split8(k0, k1, kh, kl);
+            vv = (u32x4){pv_pack_bf16x2(v0.x, v0.y), pv_pack_bf16x2(v0.z, v0.w), pv_pack_bf16x2(v1.x, v1.y), pv_pack_bf16x2(v1.z, v1.w)};
+        }
+        const int off = pv_swz<CPR>(row, c);
+        *reinterpret_cast<u32x4*>(Kh + off) = kh;
+        *reinterpret_cast<u32x4*>(Kl + off) = kl;
+        *reinterpret_cast<u32x4*>(Vs + off) = vv;
+    }
+    // Q of a 16-query tile: lane (g, i16) holds Q[q0 + i16][ks*32 + 8g .. +8] as hi / lo fragments
+    auto qload = [&](int qt, float4 (&raw)[KS][2]) __attribute__((always_inline)) {
+        int qr = qt * 16 + i16;
+        qr = qr < S ? qr : S - 1;
+        const float* qp = qb + (int64_t)qr * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dcol = ks * 32 + 8 * g;
+            raw[ks][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[ks][1] = raw[ks][0];
+            if (dcol < DH) { raw[ks][0] = *reinterpret_cast<const float4*>(qp + dcol); raw[ks][1] = *reinterpret_cast<const float4*>(qp + dcol + 4); }
+        }
+    };
+    const int nqt = (S + 15) >> 4;
+    float4 raw[KS][2];
+    if (wid < nqt) qload(wid, raw);
+    typedef __attribute__((address_space(3))) const char lds_cc;
+    int koff[KS], voff[NDT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
+    {
+        const int tq_ = i16 >> 2, tp_ = i16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) voff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+    }
+    __syncthreads();
+
+    for (int qt = wid; qt < nqt; qt += 4) {
+        const int q0 = qt << 4;
+        bf16x8 qh[KS], ql[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 hi, lo;
+            pv_split8(raw[ks][0], raw[ks][1], hi, lo);
+            qh[ks] = __builtin_bit_cast(bf16x8, hi);
+            ql[ks] = __builtin_bit_cast(bf16x8, lo);
+        }
+        if (qt + 4 < nqt) qload(qt + 4, raw);            // the next tile's rows arrive under this tile's products
+        f32x4 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 ah = {0.f, 0.f, 0.f, 0.f}, al = ah;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + koff[ks] + kt * (16 * DHP * 2));
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + koff[ks] + kt * (16 * DHP * 2));
+                ah = PV_MFMA_16x16x32(kh, qh[ks], ah, 0, 0, 0);
+                al = PV_MFMA_16x16x32(kh, ql[ks], al, 0, 0, 0);
+                al = PV_MFMA_16x16x32(kl, qh[ks], al, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] = fmaf(al[r], 1.0f / PV_LO_SCALE, ah[r]);
+            // (without this hipcc hoists the K fragments of every key tile to the top of the loop: 256 registers and 70 spilled at 13 tiles)
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * 1.44269504088896340736f + PV_P_SHIFT;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.44269504088896340736f, nm));
+                sc[kt][r] = pe;
+                l += pe;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < NKT32; ++tt) {
+            u32x4 pw = {pv_pack_bf16x2(sc[2 * tt][0], sc[2 * tt][1]), pv_pack_bf16x2(sc[2 * tt][2], sc[2 * tt][3]),
+                        pv_pack_bf16x2(sc[2 * tt + 1][0], sc[2 * tt + 1][1]), pv_pack_bf16x2(sc[2 * tt + 1][2], sc[2 * tt + 1][3])};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff[dt] + tt * (32 * DHP * 2)));
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff[dt] + tt * (32 * DHP * 2) + 16 * DHP * 2));
+                const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (NKT & 1) {
+            constexpr int kt = NKT - 1;
+            u32x2 pw = {pv_pack_bf16x2(sc[kt][0], sc[kt][1]), pv_pack_bf16x2(sc[kt][2], sc[kt][3])};
+            const s16x4 pf = __builtin_bit_cast(s16x4, pw);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff[dt] + kt * (16 * DHP * 2)));
+                o[dt] = PV_MFMA_16x16x16(v0, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q0 + i16 < S) {
+            const float inv = 1.0f / l;
+            uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                u32x2 ov = {pv_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pv_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+                *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
+            }
+        }
+    }
+}
+
+template <int DH, int NKT>
+static int pv_launch_attn_split(const float* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int lds = 3 * NKT * 16 * DHP * 2;
+    static_assert(lds <= 160 * 1024, "K_hi | K_lo | V of one head must fit the LDS");
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_split_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    PV_LAUNCH((pv_attn_split_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    return pv_check_launch();
+}
+
+template <int DH>
+static int pv_dispatch_attn_split(const float* qkv, uint16_t* out, int64_t B, int S, int H, hipStream_t stream) {
+    switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_split<DH, N>(qkv, out, B, S, H, stream);
+        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
+        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
+        default: break;
+    }
+    if constexpr (DH == 32) {
+        switch ((S + 15) / 16) {
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_split<DH, N>(qkv, out, B, S, H, stream);
+            PV_ATTN_CASE(14) PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20)
+            PV_ATTN_CASE(21) PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
+#undef PV_ATTN_CASE
+            default: break;
+        }
+    }
+    return PV_ERR_UNSUPPORTED;
+}
+
+extern "C" int pv_attention_split_bf16(const float* qkv, uint16_t* out, int64_t B, int64_t S, int64_t H, int64_t dh, void* stream) {
+    if (!qkv || !out || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return PV_ERR_INVALID_ARG;
+    if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {          // S <= 208 at dh = 48 / 64, S <= 416 at dh = 32 (three 16-bit images of the head in LDS)
+        case 32: return pv_dispatch_attn_split<32>(qkv, out, B, (int)S, (int)H, s);
+        case 48: return pv_dispatch_attn_split<48>(qkv, out, B, (int)S, (int)H, s);
+        case 64: return pv_dispatch_attn_split<64>(qkv, out, B, (int)S, (int)H, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

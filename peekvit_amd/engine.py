@@ -111,8 +111,26 @@ def range_flag_for(device) -> torch.Tensor:
             alive = {t.ident for t in threading.enumerate()}
             for k in [k for k in _flags if k[1] not in alive]:      # words of threads that have exited
                 del _flags[k]
-            f = _flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+            f = _flags[key] = torch.zeros(FLAG_WORDS, dtype=torch.int32, device=device)
     return f
+
+
+# The flag tensor has FLAG_WORDS words (round 5).  Word 0 collects every bit as before; the attention launches of encoder layer i (engine.run_layers
+# numbers the blocks of a model forward) raise their score bit in word 1 + i % (FLAG_WORDS - 1) instead, so that a forward whose only problem is a
+# large attention score knows WHICH layers have it and repeats with only those layers' attention half in split precision (LOCAL fallback below).
+FLAG_WORDS = 64
+
+
+def _flag_bits(words) -> int:
+    bits = 0
+    for w in words:
+        bits |= int(w)
+    return bits
+
+
+def _score_layers(words) -> set:
+    """Layer numbers (mod FLAG_WORDS - 1) whose attention raised the score bit."""
+    return {k - 1 for k, w in enumerate(words) if k >= 1 and int(w) & _FLAG_SCORE}
 
 
 def _warn_once(key: str, msg: str):
@@ -164,11 +182,13 @@ class GuardState:
              fp16's subnormal range), or the data-dependent guard tripped on three forwards in a row: go straight to the fallback mode
     no_fold  a row mean large against its spread was seen: LayerNorm folding stays off for this module (fp16 operands otherwise)
     gen      the optimizer-step generation the verdicts were made for; an optimizer step or load_state_dict() resets them"""
-    __slots__ = ("unsafe", "no_fold", "trips", "gen", "verdicts")
+    __slots__ = ("unsafe", "no_fold", "trips", "gen", "verdicts", "hybrid", "calls")
 
     def __init__(self):
         self.unsafe, self.no_fold, self.trips, self.gen = False, False, 0, _opt_generation
         self.verdicts = {}          # self-check verdicts (run_guarded): (probe key, batch size, no_fold) -> "ok" | "x3"
+        self.hybrid = frozenset()   # encoder layers whose attention half runs in split precision (their scores left PV_SCORE_LIMIT)
+        self.calls = {}             # verdict key -> guarded forwards since the last self-check probe (periodic re-probe)
 
 
 def guard_state(owner: nn.Module) -> GuardState:
@@ -194,6 +214,17 @@ fold_fallback_count = 0     # forwards repeated with LayerNorm folding off (stil
 # flag bits written by the kernels (include/peekvit_hip.h): 1 a 16-bit value overflowed fp16, 2 a folded row's mean is large against its
 # spread, 4 an attention score beyond PV_SCORE_LIMIT
 _FLAG_FOLD = 2
+_FLAG_SCORE = 4
+
+# LOCAL fallback of the score guard (round 5; rounds 3-4 repeated the WHOLE forward in FALLBACK_MODE - a third of the speed - for one score beyond
+# PV_SCORE_LIMIT anywhere in the batch).  A forward that raised nothing but score bits, in layers that run_layers numbered, is repeated on fp16
+# operands with the ATTENTION HALF of exactly those layers in split precision ("hybrid" layers, _attention_half_split: LayerNorm -> [hi|lo|hi] operands,
+# in-projection as three bf16 products with fp32 q|k|v, attention with split-operand scores) - what the large scores need: the rounding of q and k,
+# and the operand rounding of the GEMM that produces them, are what the softmax amplifies; everything else in the block stays as it is.  The set is
+# remembered per module (GuardState.hybrid) until its parameters change.  An overflow bit, or a score bit from an attention launch outside a
+# numbered layer, still sends the forward to FALLBACK_MODE.  PEEKVIT_AMD_LOCAL_FALLBACK=0 restores the round-4 behaviour.
+LOCAL_FALLBACK = os.environ.get("PEEKVIT_AMD_LOCAL_FALLBACK", "1") != "0"
+hybrid_fallback_count = 0   # forwards repeated with more hybrid layers (still fp16 operands everywhere else)
 
 
 # The contract SELF-CHECK of mode "auto" (round 4).  The flag-word guards catch what is known to break fp16 operands (overflow, folded rows
@@ -268,26 +299,29 @@ _DEFER_RING = 4
 def deferred_flags():
     old = getattr(_region, "defer", None)
     _region.defer = {"pending": {}, "slot": 0, "flags": {}}
+    ok = False
     try:
         yield
+        ok = True
     finally:
         st = _region.defer
         _region.defer = old
-        assert not st["pending"], "engine.deferred_flags(): resolve() every output before leaving the context"
+        if ok:                       # (an exception from the loop body must not be masked by this one)
+            assert not st["pending"], "engine.deferred_flags(): resolve() every output before leaving the context"
 
 
 def _deferred_slot(device):
     st = _region.defer
     if device not in st["flags"]:
         with torch.inference_mode(False):
-            st["flags"][device] = (torch.zeros(_DEFER_RING, dtype=torch.int32, device=device),
-                                   [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(_DEFER_RING)])
+            st["flags"][device] = (torch.zeros((_DEFER_RING, FLAG_WORDS), dtype=torch.int32, device=device),
+                                   [torch.zeros(FLAG_WORDS, dtype=torch.int32).pin_memory() for _ in range(_DEFER_RING)])
     dev_words, host_words = st["flags"][device]
     i = st["slot"] % _DEFER_RING
     st["slot"] += 1
     busy = [t for t in st["pending"].values() if t["i"] == i]
     assert not busy, f"more than {_DEFER_RING} unresolved forwards inside engine.deferred_flags()"
-    return i, dev_words[i:i + 1], host_words[i]
+    return i, dev_words[i], host_words[i]
 
 
 def resolve(out: torch.Tensor) -> torch.Tensor:
@@ -299,20 +333,83 @@ def resolve(out: torch.Tensor) -> torch.Tensor:
     if t is None:
         return out
     t["event"].synchronize()
-    bits = int(t["host"][0])
+    words = t["host"].tolist()
+    bits = _flag_bits(words)
     if bits == 0:
         t["guard"].trips = 0
         return out
     gs = t["guard"]
-    if bits == _FLAG_FOLD and not gs.no_fold:
-        gs.no_fold = True
-        fold_fallback_count += 1
+    # (the verdict is taken against what the forward was LAUNCHED with: batch i + 1 is already in flight when batch i's bits arrive, and a
+    # fold trip of batch i must not turn batch i + 1's identical fold trip into a data trip - round-4 review)
+    if bits == _FLAG_FOLD and not t["no_fold"]:
+        if not gs.no_fold:
+            gs.no_fold = True
+            fold_fallback_count += 1
+        return t["rerun"](False)
+    if _local_fallback(gs, words, bits, t["hybrid"]):
         return t["rerun"](False)
     gs.trips += 1
     if gs.trips >= 3:
         gs.unsafe = True
     fallback_count += 1
     return t["rerun"](True)
+
+
+# Periodic re-probe of the self-check (round 5): every SELFCHECK_EVERY-th guarded forward of a key with verdict "ok" measures again (8 images in
+# FALLBACK_MODE: < 0.5 % of 64 batches of 2048).  PEEKVIT_AMD_SELFCHECK_EVERY=0 keeps round 4's once-per-key check.
+SELFCHECK_EVERY = int(os.environ.get("PEEKVIT_AMD_SELFCHECK_EVERY", "64"))
+
+
+@contextlib.contextmanager
+def _hooks_held(owner: nn.Module):
+    """Run the self-check probe with the module / global forward hooks of `owner` held back: whoever watches the forward sees the whole batch once."""
+    import torch.nn.modules.module as _m
+    if not _observed(owner):
+        yield
+        return
+    saved = []
+    for mod in owner.modules():
+        for name in ("_forward_hooks", "_forward_pre_hooks"):
+            d = getattr(mod, name)
+            if d:
+                saved.append((mod, name, d))
+                object.__setattr__(mod, name, type(d)())
+    gsaved = [(name, getattr(_m, name)) for name in ("_global_forward_hooks", "_global_forward_pre_hooks") if getattr(_m, name)]
+    for name, d in gsaved:
+        setattr(_m, name, type(d)())
+    try:
+        yield
+    finally:
+        for mod, name, d in saved:
+            object.__setattr__(mod, name, d)
+        for name, d in gsaved:
+            setattr(_m, name, d)
+
+
+def _local_fallback(st: GuardState, words, bits: int, launched_hybrid) -> bool:
+    """A forward raised score bits only (bit 4, perhaps with the fold bit), all of them in numbered layers, at least one of which was not yet
+    hybrid when it was launched: add them to the module's hybrid set and tell the caller to repeat the forward.  False: not a case for the local
+    fallback (an overflow, a score bit from an unnumbered attention launch, nothing new to add, or switched off)."""
+    global hybrid_fallback_count
+    if not LOCAL_FALLBACK or bits & ~(_FLAG_SCORE | _FLAG_FOLD) or not bits & _FLAG_SCORE or int(words[0]) & _FLAG_SCORE:
+        return False
+    layers = _score_layers(words)
+    if not layers or layers <= set(launched_hybrid) or len(st.hybrid | layers) >= FLAG_WORDS - 1:
+        return False
+    if bits & _FLAG_FOLD:
+        st.no_fold = True
+    if not layers <= set(st.hybrid):
+        st.hybrid = frozenset(st.hybrid | layers)
+        hybrid_fallback_count += 1
+    _warn_once("hybrid", "peekvit_amd: an attention score beyond 32 in encoder layer(s) " + ", ".join(str(i) for i in sorted(layers)) + ": the forward was "
+               "repeated with the attention half of those layers in split precision (fp16 operands everywhere else); the module remembers the layers")
+    return True
+
+
+def layer_is_hybrid() -> bool:
+    """Is the encoder layer the calling thread is in (engine.run_layers) one whose attention half runs in split precision?"""
+    i = getattr(_region, "layer", None)
+    return i is not None and (i % (FLAG_WORDS - 1)) in getattr(_region, "hybrid", ())
 
 
 def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=None, probe_state=None):
@@ -337,21 +434,33 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                 flag = range_flag_for(x.device)
                 capturing = torch.cuda.is_current_stream_capturing()
                 ref = None
-                for attempt in range(2):
-                    vkey = (probe_key, int(x.shape[0]), st.no_fold)
+                for attempt in range(5):
+                    # the self-check verdict is per (what selects the arithmetic, batch size, input type and image shape, folding, hybrid layers)
+                    vkey = (probe_key, int(x.shape[0]), st.no_fold, x.dtype, tuple(x.shape[1:]), st.hybrid)
                     verdict = st.verdicts.get(vkey) if probe is not None else "ok"
                     if verdict == "x3":
                         break
+                    if verdict == "ok" and probe is not None and SELFCHECK_EVERY > 0 and not capturing:
+                        # periodic re-probe (round 5): an "ok" measured on the first batch says little about batch 500 of a real dataset
+                        n_calls = st.calls.get(vkey, 0) + 1
+                        st.calls[vkey] = n_calls
+                        if n_calls >= SELFCHECK_EVERY:
+                            st.calls[vkey] = 0
+                            verdict = None
                     deferred = getattr(_region, "defer", None) is not None and probe is not None and verdict == "ok" and not capturing and attempt == 0
                     if deferred:
                         slot, flag, host_word = _deferred_slot(x.device)
-                    if verdict is None and ref is None and SELFCHECK_IMAGES > 0 and not capturing and not _observed(owner):
+                    if verdict is None and ref is None and SELFCHECK_IMAGES > 0 and not capturing:
                         # BEFORE the forward proper, so that what the modules remember of their last forward (block.mask, last_keep,
-                        # residual_gate.threshold) is the whole batch's
-                        ref = _probe_reference(x, probe, probe_state)
+                        # residual_gate.threshold) is the whole batch's.  While somebody watches the forward through module hooks the probe runs
+                        # with the hooks held back (round 5; round 4 skipped the check altogether): they fire once, on the whole batch.
+                        with _hooks_held(owner):
+                            ref = _probe_reference(x, probe, probe_state)
                     flag.zero_()
                     ops.set_range_flag(flag)
                     _region.no_fold = st.no_fold
+                    _region.hybrid = st.hybrid
+                    launched_hybrid, launched_no_fold = st.hybrid, st.no_fold
                     out = None
                     try:
                         with precision("f16"):
@@ -363,6 +472,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                     finally:
                         ops.set_range_flag(None)
                         _region.no_fold = False
+                        _region.hybrid = frozenset()
                     if out is None:
                         break
                     _region.last = "guarded"
@@ -383,9 +493,11 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                                     finally:
                                         _region.active = False
                             return run_guarded(_owner, _x, lambda: _probe(_x))
-                        _region.defer["pending"][id(out)] = {"i": slot, "host": host_word, "event": ev, "guard": st, "rerun": rerun, "out": out}
+                        _region.defer["pending"][id(out)] = {"i": slot, "host": host_word, "event": ev, "guard": st, "rerun": rerun, "out": out,
+                                                             "no_fold": launched_no_fold, "hybrid": launched_hybrid}
                         return out
-                    bits = int(flag.item())
+                    words = flag.tolist()                 # the forward's one host synchronisation
+                    bits = _flag_bits(words)
                     if bits == 0:
                         st.trips = 0
                         if verdict is None and ref is not None:
@@ -398,12 +510,19 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                                     agree &= (a[:ref.shape[0]] == b).reshape(ref.shape[0], -1).all(dim=1)
                                 flips = int(ref.shape[0] - int(agree.sum()))
                                 got, ref = got[agree], ref[agree]
+                            if flips and flips == probed:
+                                # every probed image resolved a ranking tie differently: nothing was compared - no verdict, probe again next time
+                                selfcheck_last = (float("nan"), probed, flips)
+                                _warn_once(f"flips:{id(owner)}", f"peekvit_amd: all {probed} self-check images kept a different token set than the "
+                                           f"{FALLBACK_MODE} arithmetic (ranking near-ties): the fp16 logits of this setting were not compared")
+                                return out
                             den = float(ref.norm()) if ref.numel() else 0.0
-                            err = float((got - ref).norm()) / den if den > 0 else 0.0       # (a zero-initialised head / no image left: nothing to compare)
+                            err = float((got - ref).norm()) / den if den > 0 else 0.0       # (a zero-initialised head: nothing to compare)
                             selfcheck_count += 1
                             selfcheck_last = (err, probed, flips)
                             if len(st.verdicts) >= 64:
                                 st.verdicts.clear()
+                                st.calls.clear()
                             if not err <= SELFCHECK_LIMIT:
                                 st.verdicts[vkey] = "x3"
                                 selfcheck_trips += 1
@@ -420,6 +539,8 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                         _warn_once("fold", "peekvit_amd: a token row's mean is large against its spread (|mean| * rstd > 1): LayerNorm folding is "
                                            "switched off for this module (the raw row would lose its spread in 16 bits)")
                         continue
+                    if _local_fallback(st, words, bits, launched_hybrid):
+                        continue                 # the same forward again, the tripped layers' attention half in split precision
                     st.trips += 1
                     _warn_once("data", "peekvit_amd: an activation left what fp16 operands can carry inside the 1e-3 contract (|v| > 65504, or an "
                                        f"attention score beyond 32); this forward was repeated in the {FALLBACK_MODE} mode")
@@ -831,6 +952,27 @@ def _act_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.T
     return ops.gemm(a, w, bias, out, PV_EPI_BIAS_GELU_BF16 if gelu else PV_EPI_BIAS_BF16, M=M, qcols=qcols, qscale=qscale)
 
 
+def _attention_half_split(blk: nn.Module, x: torch.Tensor, att: torch.Tensor, B: int, S: int, eps: float, row_scale: Optional[torch.Tensor]):
+    """[LayerNorm 1 -> in-projection -> attention] of one block in SPLIT precision, into the 16-bit `att` the ordinary out-projection reads (the
+    LOCAL fallback of the score guard, LOCAL_FALLBACK above): LN1(x) as [hi|lo|hi] bf16 planes, the in-projection as three bf16 products with fp32
+    q|k|v (the kernels of mode "bf16x3", on the bf16 library whatever the calling thread's operand type is), then pv_attention_split_bf16 of the
+    thread's own library: scores from split operands, probabilities and P.V in 16 bits."""
+    mha = blk.self_attention.self_attention
+    D = x.shape[-1]
+    H = mha.num_heads
+    dh = D // H
+    R, dev = B * S, x.device
+    old = _lib.set_operand("bf16")
+    try:
+        h3 = workspace.get("h3", (R, 3 * D), torch.bfloat16, dev)
+        qkv32 = workspace.get("qkv32", (R, 3 * D), torch.float32, dev)
+        ops.layernorm_split(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h3, row_scale)
+        ops.gemm(h3, bf16x3_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv32, PV_EPI_BIAS_F32, M=R, qcols=D, qscale=float(dh) ** -0.5)
+    finally:
+        _lib.set_operand(old)
+    ops.attention_split(qkv32, att, B, S, H, dh)
+
+
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
                   next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None,
                   res_scaled: bool = False) -> torch.Tensor:
@@ -872,13 +1014,16 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     x1 = workspace.get("x1", (B, S, D), torch.float32, dev)
     out = torch.empty_like(x)
 
+    hyb = layer_is_hybrid()        # this layer's attention scores left PV_SCORE_LIMIT on an earlier forward: its attention half in split precision
     if row_scale is None and _fold_ok(R, D, M):
         # ---- LayerNorm folded into the GEMMs: no LayerNorm launch except for a block whose input has no producer hand-off ----
         nt = (D + 255) // 256
         fold_in = getattr(x, "_pv_fold", None)
         if fold_in is not None and fold_in[3] != _tver(x):           # someone modified the tensor in place: the 16-bit copy is stale
             fold_in = None
-        if fold_in is not None and fold_in[2] == _ln_key(blk.ln_1) and fold_in[0].shape == (R, D):
+        if hyb:
+            _attention_half_split(blk, x, att, B, S, eps, None)
+        elif fold_in is not None and fold_in[2] == _ln_key(blk.ln_1) and fold_in[0].shape == (R, D):
             wg, c1, c2 = _fold_weights(mha.in_proj_weight, mha.in_proj_bias, blk.ln_1)
             stat = ops.rowstat_finalize(fold_in[1], D, blk.ln_1.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
             ops.gemm(fold_in[0], wg, None, qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=float(dh) ** -0.5, fold=(stat, c1, c2))
@@ -886,7 +1031,8 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
             h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
             ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, None)
             ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=float(dh) ** -0.5)
-        ops.attention(qkv, att, B, S, H, dh)
+        if not hyb:
+            ops.attention(qkv, att, B, S, H, dh)
         x16 = workspace.get("fold_x16", (R, D), _lib.operand_dtype(), dev)
         part = workspace.get("fold_part", (nt, R, 2), torch.float32, dev)
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D),
@@ -906,16 +1052,21 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
             out._pv_rowsq = (rowsq, _tver(out))
         return out
 
-    if h1 is not None and h1.shape == (R, D):
-        h = h1
-    elif handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
-        h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue
+    if hyb:
+        if res_scaled:
+            raise PeekvitHipError("block_forward(res_scaled=True) cannot run a hybrid layer: pass the masked tokens")
+        _attention_half_split(blk, x, att, B, S, eps, row_scale)
     else:
-        h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
-        ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
-    ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
-             qcols=D, qscale=float(dh) ** -0.5)
-    ops.attention(qkv, att, B, S, H, dh)
+        if h1 is not None and h1.shape == (R, D):
+            h = h1
+        elif handoff is not None and row_scale is None and handoff[1] == _ln_key(blk.ln_1) and handoff[0].shape == (R, D):
+            h = handoff[0]                                   # LN1(x), emitted by the producer's fused epilogue
+        else:
+            h = workspace.get("h", (R, D), _lib.operand_dtype(), dev)
+            ops.layernorm_bf16(x, _f32(blk.ln_1.weight), _f32(blk.ln_1.bias), eps, h, row_scale)
+        ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
+                 qcols=D, qscale=float(dh) ** -0.5)
+        ops.attention(qkv, att, B, S, H, dh)
     fuse2 = _ln_fusable(D, D)
     if res_scaled and (h1 is None or row_scale is None or fuse2):
         raise PeekvitHipError("block_forward(res_scaled=True) needs row_scale, the caller's h1 and the tile GEMM (no full-row LayerNorm fusion)")
@@ -963,7 +1114,7 @@ def rows_only_ok(blk: nn.Module) -> bool:
     """May the LAST block of a model forward compute only the rows its consumer reads (block_forward_rows)?  Not in mode "bf16x3", and not
     when someone observes the block's output (or its gradient) through a module hook (they would see [B,nq,D] instead of [B,S,D])."""
     import torch.nn.modules.module as _m
-    if not _LAST_BLOCK_ROWS or _mode() == "bf16x3":
+    if not _LAST_BLOCK_ROWS or _mode() == "bf16x3" or layer_is_hybrid():       # (a hybrid layer runs all rows: block_forward has the split attention half)
         return False
     own = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
     glob = ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks")
@@ -1077,15 +1228,27 @@ def run_layers(layers: nn.Sequential, x: torch.Tensor, last_rows: int = 0) -> to
     last_rows = n > 0: the caller reads the first n rows of every image of the result only (a model forward: the class tokens), so a
     last block that knows how (`_pv_forward_rows`) returns [B,n,D] instead of [B,S,D]."""
     mods = list(layers)
+    hybrid = getattr(_region, "hybrid", ())
+    try:
+        return _run_layers(mods, x, last_rows, hybrid)
+    finally:
+        _region.layer = None
+        ops.set_flag_word(0)
+
+
+def _run_layers(mods, x: torch.Tensor, last_rows: int, hybrid) -> torch.Tensor:
     for i, layer in enumerate(mods):
+        # number the layer for the LOCAL fallback of the score guard: its attention launches raise their score bit in word 1 + i of the flag tensor
+        _region.layer = i
+        ops.set_flag_word(1 + i % (FLAG_WORDS - 1))
         if last_rows > 0 and i + 1 == len(mods) and x.shape[1] > last_rows and getattr(layer, "_pv_forward_rows", None) is not None:
             rows = layer._pv_forward_rows(x, last_rows)
             if rows is not None:
                 return rows
         nxt = mods[i + 1] if i + 1 < len(mods) else None
         hint = None
-        if nxt is not None and getattr(nxt, "_pv_plain_ln1", None) is not None and nxt._pv_plain_ln1():
-            hint = nxt.ln_1
+        if nxt is not None and getattr(nxt, "_pv_plain_ln1", None) is not None and nxt._pv_plain_ln1() and ((i + 1) % (FLAG_WORDS - 1)) not in hybrid:
+            hint = nxt.ln_1                  # (a hybrid consumer normalises its own input, in split precision: no hand-off for it)
         if hasattr(layer, "_pv_next_ln"):
             # a PLAIN attribute (nn.Module.__setattr__ would register the neighbour's LayerNorm as a submodule of this block and
             # leak `layers.{i}._pv_next_ln.*` into named_parameters() / state_dict())

@@ -161,7 +161,7 @@ class ResidualViTBlock(ResidualModule):
         thr = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
         # the gate kernel holds every row in registers: it also emits row_scale * LN1(masked row), the block's first step (residualvit.py:251)
         h1 = None
-        if engine._PRECISION != "bf16x3" and engine._GATE_LN1:
+        if engine._PRECISION != "bf16x3" and engine._GATE_LN1 and not engine.layer_is_hybrid():     # (a hybrid layer normalises the masked tokens itself, in split precision)
             engine._check_ln_range(self.ln_1)
             h1 = engine.workspace.get("h", (x.shape[0] * x.shape[1], x.shape[2]), engine._lib.operand_dtype(), x.device)
         # with h1 from the gate and a tile GEMM for out-proj the masked tokens themselves are never needed: the out-proj epilogue computes

@@ -120,6 +120,35 @@ def _flag(dev):
     return C.c_void_p(range_flag.data_ptr()) if range_flag is not None and range_flag.device == dev else C.c_void_p(0)
 
 
+def set_flag_word(k: int) -> int:
+    """Which word of the flag tensor the ATTENTION launches of the calling thread raise their score bit in (engine.run_layers: 1 + layer index,
+    so that a tripped forward knows WHICH layers to repeat in split precision); 0 = the common word.  Returns the previous value."""
+    old = getattr(_tls, "flag_word", 0)
+    _tls.flag_word = k
+    return old
+
+
+def _attn_flag(dev):
+    flag = current_range_flag()
+    if flag is None or flag.device != dev:
+        return C.c_void_p(0)
+    k = getattr(_tls, "flag_word", 0)
+    return C.c_void_p(flag.data_ptr() + 4 * (k if k < flag.numel() else 0))
+
+
+def workspace_bytes(use: int, *dims: int) -> int:
+    """Scratch bytes of a C-ABI entry point for the given sizes: the library's own formula (pv_workspace_size, include/peekvit_hip.h PV_WS_*)."""
+    arr = (C.c_int64 * len(dims))(*[int(d) for d in dims])
+    n = int(_lib.load().pv_workspace_size(int(use), arr, len(dims)))
+    if n < 0:
+        check(n, "pv_workspace_size")
+    return n
+
+
+def _scratch_f32(use: int, dev, *dims: int) -> torch.Tensor:
+    return torch.empty((workspace_bytes(use, *dims) // 4,), dtype=torch.float32, device=dev)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -223,7 +252,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, epilogue: in
                     rowsq_out=rowsq_out.data_ptr() if rowsq_out is not None else 0, res_scaled=int(res_scaled))
     part = None
     if colsum_out is not None and _lib.load().pv_gemm_tile_rows(C.byref(args)) == 256:
-        part = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=a.device)
+        part = _scratch_f32(_lib.PV_WS_GEMM_COLSUM_PARTIAL, a.device, M, N).view((M + 255) // 256, N)
         args.colsum_partial = part.data_ptr()
     # algorithmic bytes: both operands once, the output once (+ the residual rows it adds, + the 16-bit copies the fused / folded LayerNorm forms emit)
     nbytes = 2.0 * (M * K + N * K) + out.element_size() * M * N * (2 if res is not None else 1) + (2.0 * M * N if ln else 0.0) + (2.0 * M * N if x16_out is not None else 0.0)
@@ -265,7 +294,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, part: torch.Tensor, ksplit: int, t
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
     with _timed("pv_attention_bf16", qkv.device, 4.0 * B * H * S * S * dh, 8.0 * B * S * H * dh):
-        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _flag(qkv.device), _stream(qkv)), "pv_attention_bf16")
+        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _attn_flag(qkv.device), _stream(qkv)), "pv_attention_bf16")
     _count()
     return out
 
@@ -280,7 +309,7 @@ def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int,
         raise _lib.PeekvitHipError("attention_rows: shape mismatch")
     with _timed("pv_attention_rows_bf16", q.device, 4.0 * B * H * nq * S * dh, 4.0 * B * S * H * dh + 4.0 * B * nq * H * dh):
         check(_lib.load().pv_attention_rows_bf16(_ptr(q), q.stride(0), _ptr(kv), kv.stride(0), _ptr(out), out.stride(0),
-                                                 B, S, nq, H, dh, _flag(q.device), _stream(q)), "pv_attention_rows_bf16")
+                                                 B, S, nq, H, dh, _attn_flag(q.device), _stream(q)), "pv_attention_rows_bf16")
     _count()
     return out
 
@@ -365,8 +394,7 @@ def transpose(src: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int
     if out is None:
         out = torch.empty((Cc, ldd), dtype=_lib.operand_dtype(), device=src.device)
     assert out.shape == (Cc, ldd) and out.is_contiguous()
-    q = 64 if ldd <= 65536 else 1024                     # source rows per workgroup (include/peekvit_hip.h)
-    ws = torch.empty(((ldd + q - 1) // q, Cc), dtype=torch.float32, device=src.device) if colsum_out is not None else None
+    ws = _scratch_f32(_lib.PV_WS_TRANSPOSE_COLSUM, src.device, R, Cc, ldd) if colsum_out is not None else None
     with _timed("pv_transpose_bf16", src.device, 0.0, 4.0 * src.numel()):
         check(_lib.load().pv_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), R, Cc, ldd, _ptr(colsum_out), _ptr(ws), _stream(src)),
               "pv_transpose_bf16")
@@ -379,8 +407,7 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
     assert src.dtype in (_lib.operand_dtype(), torch.float32) and src.is_contiguous()
     _chk(out, torch.float32, "out")
     R, Cc = src.shape
-    q = 64 if R <= 65536 else 1024                       # chunk height of stage 1 (include/peekvit_hip.h)
-    ws = torch.empty(((R + q - 1) // q, Cc), dtype=torch.float32, device=src.device)
+    ws = _scratch_f32(_lib.PV_WS_COLSUM, src.device, R, Cc)
     with _timed("pv_colsum_f32", src.device, 0.0, float(src.element_size() * src.numel())):
         check(_lib.load().pv_colsum_f32(_ptr(src), int(src.dtype == _lib.operand_dtype()), _ptr(out), _ptr(ws), R, Cc, int(accumulate),
                                         _stream(src)), "pv_colsum_f32")
@@ -394,8 +421,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_i
     _chk(x, torch.float32, "x"); _chk(dy, _lib.operand_dtype(), "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
     D = x.shape[-1]
     rows = x.numel() // D
-    blocks = min((rows + 3) // 4, 1024)
-    ws = torch.empty((blocks, 3 * D), dtype=torch.float32, device=x.device)
+    ws = _scratch_f32(_lib.PV_WS_LAYERNORM_BWD, x.device, rows, D)
     with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0)) * x.numel()):
         check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dx_bf16), _ptr(dgb),
                                            _ptr(ws), ws.numel(), rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd")
@@ -411,8 +437,7 @@ def layernorm_bwd_masked(x, dy, gamma, beta, row_scale, dres_in, u, dx_out, dx_b
     _chk(dgb, torch.float32, "dgb"); _chk(dmask, torch.float32, "dmask"); _chk(row_scale, torch.float32, "row_scale")
     D = x.shape[-1]
     rows = x.numel() // D
-    blocks = min((rows + 3) // 4, 1024)
-    ws = torch.empty((blocks, 3 * D), dtype=torch.float32, device=x.device)
+    ws = _scratch_f32(_lib.PV_WS_LAYERNORM_BWD, x.device, rows, D)
     with _timed("pv_layernorm_bwd", x.device, 0.0, 16.0 * x.numel()):
         check(_lib.load().pv_layernorm_bwd_masked(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(row_scale), _ptr(dres_in), _ptr(u),
                                                   _ptr(dx_out), _ptr(dx_bf16), int(scale_copy), _ptr(dgb), _ptr(dmask), int(dmask_accumulate),
@@ -470,7 +495,7 @@ def wgrad(dy_t: torch.Tensor, x_t: torch.Tensor, out: torch.Tensor, accumulate: 
         ksplit = 1
         while tiles * ksplit < 512 and M % (ksplit * 2 * 128) == 0 and M // (ksplit * 2) >= 1024:
             ksplit *= 2
-    part = torch.empty((ksplit, No, Ni), dtype=torch.float32, device=out.device)
+    part = _scratch_f32(_lib.PV_WS_GEMM_SPLITK, out.device, No, Ni, ksplit).view(ksplit, No, Ni)
     gemm(dy_t, x_t, None, part, _lib.PV_EPI_BIAS_F32, ksplit=ksplit)
     return sum_slices(part, out, accumulate)
 
@@ -511,6 +536,15 @@ def attention_f32(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, 
     _chk(qkv, torch.float32, "qkv")
     with _timed("pv_attention_f32_split", qkv.device, 4.0 * B * H * S * S * dh, 18.0 * B * S * H * dh):
         check(_lib.load().pv_attention_f32_split(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_f32_split")
+    _count()
+    return out
+
+
+def attention_split(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
+    """Attention with split-operand scores (the local fallback of the score guard): qkv fp32 [B*S, 3*H*dh] (q pre-scaled) -> out 16-bit [B*S, H*dh]."""
+    _chk(qkv, torch.float32, "qkv"); _chk(out, _lib.operand_dtype(), "out")
+    with _timed("pv_attention_split_bf16", qkv.device, 8.0 * B * H * S * S * dh, 14.0 * B * S * H * dh):
+        check(_lib.load().pv_attention_split_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _stream(qkv)), "pv_attention_split_bf16")
     _count()
     return out
 

@@ -204,7 +204,26 @@ def hostile_variants(cfg: dict, seed: int = 0) -> Dict[str, Dict[str, np.ndarray
             logu[k][rows] = round_to_bf16(logu[k][rows] / 100.0)                 # the magnitudes alone, without the x100 rows
     gains = {k: (host[k] if k.endswith(("ln_1.weight", "ln_2.weight", "encoder.ln.weight")) else v) for k, v in base.items()}
     massive = dict(base, **{"encoder.pos_embedding": host["encoder.pos_embedding"]})
-    return {"hostile": host, "loguniform": logu, "ln_gain": gains, "massive_token": massive}
+    return {"hostile": host, "loguniform": logu, "ln_gain": gains, "massive_token": massive, "trained_like": trained_like_state_dict(cfg, seed)}
+
+
+def trained_like_state_dict(cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
+    """What TRAINED ViTs look like to a 16-bit path, without the x100 gains of the hostile set (round 5): in every third encoder
+    layer the q and k rows of the in-projection are scaled up so that the attention logits reach ~40 - 80 (sharp heads), and two channels of the
+    residual stream carry massive activations (a constant ~40 x the typical magnitude on every token, through the positional embedding - the
+    'massive activation' channels of pretrained ViTs).  Everything else is the benign synthetic model.  bf16-representable like the rest."""
+    sd = {k: v.copy() for k, v in synth_state_dict(cfg, "vit", seed).items()}
+    D, L = cfg["hidden_dim"], cfg["num_layers"]
+    for i in range(L):
+        if i % 3 == 1:
+            w = sd[f"encoder.layers.{i}.self_attention.self_attention.in_proj_weight"]
+            b = sd[f"encoder.layers.{i}.self_attention.self_attention.in_proj_bias"]
+            w[:2 * D] = round_to_bf16(w[:2 * D] * 5.0)
+            b[:2 * D] = round_to_bf16(b[:2 * D] * 5.0)
+    pos = sd["encoder.pos_embedding"]
+    for c in (5 % D, (D // 2 + 13) % D):
+        pos[:, :, c] = round_to_bf16(pos[:, :, c] + 40.0)               # (the tokens themselves are ~1)
+    return sd
 
 
 def synth_images(batch: int, image_size: int, seed: int = 0, name: str = "images") -> np.ndarray:

@@ -515,3 +515,64 @@ def test_gemm_gelu_is_elementwise_exact_on_both_tile_kernels(ops, M, N, K, tile)
         err = (out.double() - ref).abs()
         bad = err > 0.006 * ref.abs() + 2e-5
         assert int(bad.sum()) == 0, f"{int(bad.sum())} of {M * N} elements off: worst {float(err.max()):.3e}"
+
+
+@pytest.mark.parametrize("B,S,H,dh,amp", [(2, 197, 12, 64, 1.0), (3, 197, 4, 64, 6.0), (2, 50, 3, 64, 10.0), (2, 99, 8, 32, 6.0), (1, 26, 2, 48, 8.0), (2, 5, 2, 64, 4.0)])
+def test_attention_split_scores(B, S, H, dh, amp):
+    """pv_attention_split_bf16 (the LOCAL fallback of the score guard): fp32 q|k|v in, scores from split operands.  Against fp64 softmax(q k^T) v
+    on the same fp32 inputs with scores up to several hundred (`amp` scales q and k): the split kernel stays at the 16-bit rounding of p and v
+    (~3e-4), while the ordinary fp16-operand kernel on the rounded q, k loses accuracy with the score (the reason for the guard)."""
+    from peekvit_amd import _lib, ops
+    D = H * dh
+    g = torch.Generator(device="cuda").manual_seed(S * 7 + dh)
+    qkv = torch.randn(B, S, 3 * D, generator=g, device="cuda")
+    qkv[..., :2 * D] *= amp
+    qkv[..., :D] *= dh ** -0.5                                     # (q arrives pre-scaled)
+    q, k, v = (t.reshape(B, S, H, dh).permute(0, 2, 1, 3).double() for t in qkv.split(D, dim=-1))
+    scores = q @ k.transpose(-1, -2)
+    ref = (torch.softmax(scores, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    old = _lib.set_operand("f16")
+    try:
+        out = torch.empty(B * S, D, device="cuda", dtype=torch.float16)
+        ops.attention_split(qkv.view(B * S, 3 * D), out, B, S, H, dh)
+        plain = torch.empty_like(out)
+        ops.attention(qkv.view(B * S, 3 * D).half(), plain, B, S, H, dh)
+    finally:
+        _lib.set_operand(old)
+    e_split, e_plain = rel_l2(out, ref), rel_l2(plain, ref)
+    print(f"max |score| {float(scores.abs().max()):.0f}: split {e_split:.2e}, plain fp16 {e_plain:.2e}")
+    assert torch.isfinite(out).all() and e_split < 4e-4, e_split
+    if float(scores.abs().max()) > 100:
+        assert torch.isfinite(plain).all() and e_plain > 2 * e_split
+    # the bf16 library's build of the same kernel (bf16 halves: 16 mantissa bits in the scores) is held to bf16's output rounding
+    outb = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
+    ops.attention_split(qkv.view(B * S, 3 * D), outb, B, S, H, dh)
+    assert rel_l2(outb, ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 99, 8, 32), (2, 80, 4, 64), (2, 48, 4, 48), (2, 96, 4, 48), (1, 272, 2, 64), (2, 197, 8, 32), (2, 197, 12, 64)])
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
+def test_attention_row_maximum_is_taken_from_finished_scores(B, S, H, dh, operand):
+    """Round 5 regression (tests/test_isa_audit.py has the static form): pv_attn_kernel's inline-asm row maxima ran 0 - 2 instructions behind the
+    MFMAs that write the scores in 16 instantiations (these sequence lengths / head sizes among them), i.e. on stale registers; with scores
+    spread over tens of units exp2(s - m) then overflowed the 16-bit probabilities: non-finite output rows (4 of 198 rows on N(0,1) scores, 70 at
+    scores ~50: scripts/dbg/attn_nonfinite.py).  Every row must be finite and match fp64 softmax(q k^T) v on the same 16-bit inputs."""
+    from peekvit_amd import _lib, ops
+    D = H * dh
+    dt = torch.float16 if operand == "f16" else torch.bfloat16
+    for amp in (1.0, 6.0):
+        g = torch.Generator(device="cuda").manual_seed(S + dh)
+        qkv = torch.randn(B, S, 3 * D, generator=g, device="cuda")
+        qkv[..., :2 * D] *= amp
+        qkv[..., :D] *= dh ** -0.5
+        q16 = qkv.view(B * S, 3 * D).to(dt)
+        q, k, v = (t.reshape(B, S, H, dh).permute(0, 2, 1, 3).double() for t in q16.view(B, S, 3 * D).split(D, dim=-1))
+        ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+        old = _lib.set_operand(operand)
+        try:
+            out = torch.empty(B * S, D, device="cuda", dtype=dt)
+            ops.attention(q16, out, B, S, H, dh)
+        finally:
+            _lib.set_operand(old)
+        assert torch.isfinite(out.float()).all(), (amp, int((~torch.isfinite(out.float())).any(1).sum()))
+        assert rel_l2(out, ref) < (2e-3 if operand == "f16" else 1.2e-2), (amp, rel_l2(out, ref))

@@ -167,7 +167,7 @@ def test_training_step_matches_the_reference(golden, name, batch):
 
 
 @pytest.mark.parametrize("name,variant", [("vit_tiny", "hostile"), ("vit_tiny", "loguniform"), ("vit_tiny", "ln_gain"), ("vit_tiny", "massive_token"),
-                                          ("vit_b_16", "hostile"), ("vit_b_16", "loguniform")])
+                                          ("vit_b_16", "hostile"), ("vit_b_16", "loguniform"), ("vit_tiny", "trained_like"), ("vit_b_16", "trained_like")])
 def test_hostile_weights_oracle_reproduces_the_reference(golden, name, variant):
     """tests/golden/hostile.npz (oracle/make_golden_hostile.py ran the REAL reference on heavy-tailed weights, outlier channels and a
     massive token): the fp32 oracle reproduces logits and per-block class rows to fp32 round-off - these models amplify a
