@@ -155,8 +155,10 @@ def extra_config(kind, dev, steps, warmup):
     from peekvit_amd.models.rankvit import RankVisionTransformer
     from peekvit_amd.models.vit import VisionTransformer
     name, batch, train, rank = {"vit_small_fwd": ("vit_small", 512, False, None), "rankvit_b16_fwd": ("vit_b_16", 2048, False, ([3, 6, 9], 0.5)),
-                                "vit_b_16_train_step": ("vit_b_16", 2048, True, None), "vit_b_16_hostile_weights_fwd": ("vit_b_16", 256, False, None)}[kind]
+                                "vit_b_16_train_step": ("vit_b_16", 2048, True, None), "vit_b_16_hostile_weights_fwd": ("vit_b_16", 256, False, None),
+                                "vit_b_16_trained_like_weights_fwd": ("vit_b_16", 2048, False, None)}[kind]
     hostile = kind == "vit_b_16_hostile_weights_fwd"
+    trained_like = kind == "vit_b_16_trained_like_weights_fwd"
     cfg = synth.MODEL_CONFIGS[name]
     seqs = None
     if rank:
@@ -176,6 +178,11 @@ def extra_config(kind, dev, steps, warmup):
         # weight magnitudes, x100 outlier channels, a massive token) raise the attention-score guard on every forward - after three trips the model
         # stays in the split-operand mode, which is what gets timed
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.hostile_variants(cfg)["hostile"].items()})
+    if trained_like:
+        # what a TRAINED ViT looks like to the guards (round 5; tests/golden/hostile.npz holds the real reference's logits for it): attention logits of
+        # 47 - 58 in every third layer, two massive-activation channels, no x100 gains: the score guard names layers 1, 4, 7, 10 on the first forward
+        # and only THEIR attention half runs in split precision from then on
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.hostile_variants(cfg)["trained_like"].items()})
     model = (model.train() if train else model.eval()).to(dev)
     gen = torch.Generator(device=dev).manual_seed(4321)
     x = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], generator=gen, device=dev).to(torch.bfloat16).to(torch.float32)
@@ -198,6 +205,16 @@ def extra_config(kind, dev, steps, warmup):
         import warnings
         warnings.simplefilter("ignore", RuntimeWarning)
         err = None
+    elif trained_like:
+        import warnings
+        warnings.simplefilter("ignore", RuntimeWarning)
+        from oracle import vit_oracle as O
+        sd = {k: torch.from_numpy(v.copy()) for k, v in synth.hostile_variants(cfg)["trained_like"].items()}
+        xc = torch.randn(16, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(0))
+        with torch.no_grad():
+            ref = O.vit_forward(xc, sd, cfg, "fp32")
+            got = model(xc.to(dev)).float().cpu()
+        err = float(f"{((got - ref).norm() / ref.norm()).item():.3e}")
     else:
         err = oracle_error(model, cfg, dev, 16 if rank else 64, train, rank)        # before the optimizer moves the weights
     engine.selfcheck_last = None
@@ -217,7 +234,7 @@ def extra_config(kind, dev, steps, warmup):
     flops_exec = sum(v["flops"] for v in ks.values()) / batch
     value = batch * steps / dt
     out = {"config": kind, "workload": (f"{name} train step (fwd, cross-entropy, bwd, clip 1.0, Adam)" if train else
-                                        f"rank{name} layers={rank[0]} budget={rank[1]} forward" if rank else f"{name} forward" + (" on the hostile-weights fixture" if hostile else "")) + f", batch {batch}, {cfg['image_size']}x{cfg['image_size']}",
+                                        f"rank{name} layers={rank[0]} budget={rank[1]} forward" if rank else f"{name} forward" + (" on the hostile-weights fixture" if hostile else " on the trained-like fixture" if trained_like else "")) + f", batch {batch}, {cfg['image_size']}x{cfg['image_size']}",
            "value": round(value, 1), "unit": "images/sec", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
            "dtype": _train_dtype(model) if train else ("bf16x3" if engine.fallback_count > f0 else "f16"),
            "gflop_per_image": round(synth.fwd_flops_per_image(cfg, seqs) * (3 if train else 1) / 1e9, 3), "gflop_per_image_executed": round(flops_exec / 1e9, 3),
@@ -227,9 +244,17 @@ def extra_config(kind, dev, steps, warmup):
            "top_kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:4]}}
     if hostile:
         out.pop("logits_rel_l2_vs_oracle"); out.pop("logits_sample_images")
-        out["guard"] = {"fallback_forwards": engine.fallback_count - f0, "sticky_split_operand_mode": bool(engine.guard_state(model).unsafe),
-                        "note": "the fp16 guards trip on these weights (attention scores ~1e3): mode auto answers from bf16x3 (1e-5 from the reference, tests/"
-                                "test_hip_precision.py::HOSTILE_CASES) at about a third of the fp16 rate - the price of a guard trip, next to the headline"}
+        out["guard"] = {"whole_forward_fallbacks": engine.fallback_count - f0, "sticky_split_operand_mode": bool(engine.guard_state(model).unsafe),
+                        "hybrid_layers": sorted(engine.guard_state(model).hybrid),
+                        "note": "the attention-score guard trips on these weights (scores ~1e3 in every layer): round 5 repeats the forward ONCE with the attention half "
+                                "of the tripped layers in split precision (LayerNorm -> [hi|lo|hi], in-projection as three bf16 products, split-operand scores) and remembers "
+                                "the layers; everything else stays fp16 (inside 1e-3: tests/test_hip_precision.py::HOSTILE_CASES).  Rounds 3-4 answered from bf16x3 for the "
+                                "whole forward (8.2 k img/s)"}
+    if trained_like:
+        st = engine.guard_state(model)
+        out["logits_sample_images"] = 16
+        out["guard"] = {"whole_forward_fallbacks": engine.fallback_count - f0, "hybrid_layers": sorted(st.hybrid), "local_fallbacks": engine.hybrid_fallback_count,
+                        "note": "attention logits ~50 in layers 1, 4, 7, 10 + massive-activation channels: those four layers' attention half runs in split precision, the rest on fp16 operands"}
     if not train and not hostile and engine.selfcheck_last is not None:
         sc = engine.selfcheck_last
         out["self_check"] = {"fp16_vs_bf16x3_logits_rel_l2": float(f"{sc[0]:.3e}"), "images_compared": sc[1] - sc[2], "limit": engine.SELFCHECK_LIMIT}
@@ -273,6 +298,93 @@ def reference_loop(model, cfg, batch, steps, dev):
     return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
             "definition": "validate/test.py:113-124: wall clock of the loop incl. a synchronous host-to-device copy of every fp32 batch (pinned, "
                           f"{host.numel() * 4 / 1e9:.2f} GB) and the argmax / accuracy update"}
+
+
+def pipeline_loop(model, cfg, batch, steps, dev):
+    """The same definition of images/sec (validate/test.py:113-124: wall clock around the loop, argmax + accuracy update per batch) over the loop
+    peekvit_amd.harness.test.evaluate runs: uint8 NHWC host batches (the normalisation is fused into the patch gather) through the DevicePrefetcher
+    - batch i + 1 is copied on a side stream while batch i is computed - and the guard word of batch i read after batch i + 1 has been launched
+    (engine.deferred_flags).  `steps` batches cycling through three pinned host batches.  Never `value`."""
+    from peekvit_amd import engine
+    from peekvit_amd.harness.pipeline import DevicePrefetcher
+    g = torch.Generator().manual_seed(7)
+    R = cfg["image_size"]
+    hosts = [torch.randint(0, 256, (batch, R, R, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    labels = [torch.randint(0, cfg["num_classes"], (batch,), generator=g).pin_memory() for _ in range(3)]
+
+    def loader(n):
+        for i in range(n):
+            yield hosts[i % 3], labels[i % 3]
+
+    def sweep(n):
+        hits = torch.zeros((), dtype=torch.int64, device=dev)
+        prev = None
+        with engine.deferred_flags():
+            for b, l in DevicePrefetcher(loader(n), dev, keep=1):
+                out = model(b)
+                if prev is not None:
+                    hits += (engine.resolve(prev[0]).argmax(1) == prev[1]).sum()
+                prev = (out, l)
+            hits += (engine.resolve(prev[0]).argmax(1) == prev[1]).sum()
+        return int(hits.item())                     # the loop's one read-back
+
+    with torch.no_grad():
+        sweep(3)                                    # (first forward of the uint8 key: its self-check runs here, outside the timing)
+        torch.cuda.synchronize(dev)
+        f0 = engine.fallback_count
+        t0 = time.perf_counter()
+        sweep(steps)
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "batches": steps,
+            "fallback_forwards": engine.fallback_count - f0,
+            "definition": "validate/test.py:113-124's wall clock over harness.test.evaluate's loop: uint8 NHWC host batches "
+                          f"({hosts[0].numel() / 1e9:.2f} GB each, pinned) copied one batch ahead on a side stream, normalisation fused into the patch gather, "
+                          "guard word read one batch late, one read-back at the end"}
+
+
+def small_model_entry(dev, steps=200):
+    """BASELINE config 1's model on the GPU: vit_tiny 160x160, batch 32 - launch-bound (~100 launches of a few microseconds): eager, and as ONE
+    hipGraph replay (peekvit_amd.graph.GraphedForward: capture once, bit-identical replays)."""
+    from peekvit_amd import engine, synth
+    from peekvit_amd.graph import GraphedForward
+    from peekvit_amd.models.vit import VisionTransformer
+    cfg = synth.MODEL_CONFIGS["vit_tiny"]
+    model = VisionTransformer(**cfg)
+    synth.load_synth_weights(model, cfg)
+    model = model.eval().to(dev)
+    B = 32
+    x = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator(device=dev).manual_seed(99), device=dev).to(torch.bfloat16).float()
+    err = oracle_error(model, cfg, dev, 32)
+    out = {"config": "vit_tiny_fwd_b32", "workload": f"vit_tiny forward, batch {B}, {cfg['image_size']}x{cfg['image_size']} (BASELINE config 1's model on the GPU)",
+           "gflop_per_image": round(synth.fwd_flops_per_image(cfg) / 1e9, 3), "logits_rel_l2_vs_oracle": err, "dtype": "f16"}
+    with torch.no_grad():
+        for _ in range(5):
+            ref = model(x)
+        f0 = engine.fallback_count
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(x)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out["eager"] = {"value": round(B * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4)}
+        if engine.fallback_count > f0:
+            out["dtype"] = "bf16x3"
+        g = GraphedForward(model, x)
+        for _ in range(5):
+            y = g(x)
+        same = bool(torch.equal(y, ref))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g(x)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out["hipgraph_replay"] = {"value": round(B * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4), "bit_identical_to_eager": same,
+                                  "model_mfma_roofline_frac": round(B * steps / dt * synth.fwd_flops_per_image(cfg) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)}
+    del model, g
+    torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(args) -> int:
@@ -583,6 +695,8 @@ def main():
             # (c) the reference's own images/sec definition as a second value; (b) BASELINE configs 2, 4 and config 3's training step in the same
             # invocation: the driver's one `bench.py --gpus 1` then times them too.  `value` above is untouched by these.
             line["reference_loop"] = reference_loop(infer_model, cfg, args.batch, args.steps, dev)
+            # ... and the same definition over the loop the harness runs: uint8 batches, prefetcher, deferred guard read (round 5)
+            line["pipeline_loop"] = pipeline_loop(infer_model, cfg, args.batch, args.steps, dev)
             del x, out
             infer_model.to("cpu")
             torch.cuda.empty_cache()
@@ -590,7 +704,8 @@ def main():
             ex_steps = {"vit_small_fwd": 5 * args.steps, "rankvit_b16_fwd": args.steps}
             ex_warm = {"vit_small_fwd": 4 * (min(args.warmup, 3) + 2)}
             line["extra_configs"] = [extra_config(k, dev, ex_steps.get(k, max(5, args.steps // 2)), ex_warm.get(k, min(args.warmup, 3) + 2))
-                                     for k in ("vit_small_fwd", "rankvit_b16_fwd", "vit_b_16_train_step", "vit_b_16_hostile_weights_fwd")]
+                                     for k in ("vit_small_fwd", "rankvit_b16_fwd", "vit_b_16_train_step", "vit_b_16_trained_like_weights_fwd", "vit_b_16_hostile_weights_fwd")]
+            line["extra_configs"].append(small_model_entry(dev))
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

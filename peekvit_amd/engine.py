@@ -797,6 +797,23 @@ def bf16_weight(p: torch.Tensor) -> torch.Tensor:
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
+_normcache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def norm_constants(model: nn.Module, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(mean, std) of the model's input normalisation as fp32 [1,3,1,1] DEVICE tensors, made once per (device, values): building them per forward
+    is a pageable host-to-device copy, which stream capture refuses (round-4 review: a GraphedForward on uint8 input whose model lands in the
+    split-operand mode raised during capture).  peekvit_amd.graph makes sure they exist before it captures."""
+    mean, std = tuple(getattr(model, "input_mean", IMAGENET_MEAN)), tuple(getattr(model, "input_std", IMAGENET_STD))
+    key = (torch.device(device), mean, std)
+    ent = _normcache.get(key)
+    if ent is None:
+        with torch.inference_mode(False):
+            ent = _normcache[key] = (torch.tensor(mean, dtype=torch.float32, device=device).view(1, -1, 1, 1),
+                                     torch.tensor(std, dtype=torch.float32, device=device).view(1, -1, 1, 1))
+    return ent
+
+
 _w3cache: Dict[int, Tuple["weakref.ref", int, int, torch.Tensor]] = {}
 
 
@@ -1290,9 +1307,7 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
     if u8 and _mode() == "bf16x3":
         # the split-operand mode exists to be 1e-5-accurate: the fused uint8 gather emits ONE 16-bit value per pixel (fine for fp16 / bf16
         # operands, 4e-3 / 5e-4 of rounding for this mode) - so here the image is normalised to fp32 first, as ToTensor + Normalize would
-        mean, std = getattr(model, "input_mean", IMAGENET_MEAN), getattr(model, "input_std", IMAGENET_STD)
-        mt = torch.tensor(mean, dtype=torch.float32, device=img.device).view(1, -1, 1, 1)
-        st = torch.tensor(std, dtype=torch.float32, device=img.device).view(1, -1, 1, 1)
+        mt, st = norm_constants(model, img.device)
         img = ((img.permute(0, 3, 1, 2).float().div(255.0) - mt) / st).contiguous()
         u8 = False
     x3 = _mode() == "bf16x3" and not u8

@@ -37,6 +37,8 @@ class GraphedForward:
         side.wait_stream(torch.cuda.current_stream())
         self.graph = torch.cuda.CUDAGraph()
         with engine.on_device(self.static_in), engine.use_workspace(self._ws), torch.no_grad():
+            if self.static_in.dtype == torch.uint8:
+                engine.norm_constants(self.model, self.static_in.device)       # (device constants of the split-operand mode's uint8 path: not creatable under capture)
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     self.model(self.static_in)

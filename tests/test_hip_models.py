@@ -430,6 +430,22 @@ def test_uint8_nhwc_input_is_bit_identical_to_normalised_fp32_nchw():
     assert rel_l2(b.numpy(), a.numpy()) < 1e-5
 
 
+def test_graph_capture_of_uint8_input_in_the_split_operand_mode():
+    """Round-4 review: a GraphedForward on uint8 NHWC input whose model runs in bf16x3 (a verdict of the self-check, a sticky guard) normalises
+    the image with device constants - building those per forward was a pageable host-to-device copy, which stream capture refuses."""
+    from peekvit_amd import engine
+    from peekvit_amd.graph import GraphedForward
+    cfg, m = _model("vit", "vit_tiny")
+    raw = torch.randint(0, 256, (4, cfg["image_size"], cfg["image_size"], 3), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).to(DEV)
+    engine._normcache.clear()
+    with torch.no_grad(), engine.precision("bf16x3"):
+        g = GraphedForward(m, raw)
+        y = g(raw).clone()
+        assert torch.equal(y, m(raw)) and torch.isfinite(y).all()
+        raw2 = torch.flip(raw, dims=[0])
+        assert torch.equal(g(raw2), m(raw2))
+
+
 def test_vit_384_long_sequence_forward():
     """384x384 at patch 16 -> S = 577 (> the 416 tokens the LDS-resident attention holds): whole forward vs the stock-op composite."""
     from peekvit_amd.models.vit import VisionTransformer
