@@ -334,3 +334,23 @@ def test_wgrad_slice_count_fills_whole_rounds():
         assert 1 <= s <= 32 and R // (2 * s) >= 256
         assert blocks / (256 * -(-blocks // 256)) > 0.95, (No, Ni, s)          # >= 95 % of the last round busy
     assert _tn_slices(394, 9, 768, 768) == 1                                   # tiny batch: nothing to split
+
+
+def test_workspace_size_matches_the_documented_formulas():
+    """pv_workspace_size (ABI v8, SURVEY 8b's export list) is a HOST function: the scratch sizes peekvit_amd/ops.py allocates, checked here against
+    the formulas written next to the entry points in include/peekvit_hip.h; bad arguments return a negative error code."""
+    import ctypes as C
+    from peekvit_amd import _lib
+    lib = _lib.load()
+
+    def ws(use, *dims):
+        return int(lib.pv_workspace_size(use, (C.c_int64 * len(dims))(*dims), len(dims)))
+    assert ws(_lib.PV_WS_COLSUM, 403456, 768) == -(-403456 // 1024) * 768 * 4 and ws(_lib.PV_WS_COLSUM, 1000, 128) == -(-1000 // 64) * 128 * 4
+    assert ws(_lib.PV_WS_TRANSPOSE_COLSUM, 3000, 768, 3072) == 3072 // 64 * 768 * 4 and ws(_lib.PV_WS_TRANSPOSE_COLSUM, 70000, 8, 70656) == 69 * 8 * 4
+    assert ws(_lib.PV_WS_LAYERNORM_BWD, 7, 128) == 2 * 3 * 128 * 4 and ws(_lib.PV_WS_LAYERNORM_BWD, 403456, 768) == 1024 * 3 * 768 * 4
+    assert ws(_lib.PV_WS_GEMM_COLSUM_PARTIAL, 403456, 3072) == 1576 * 3072 * 4
+    assert ws(_lib.PV_WS_GEMM_SPLITK, 768, 3072, 27) == 27 * 768 * 3072 * 4
+    assert ws(99, 1, 1) < 0 and ws(_lib.PV_WS_COLSUM, 5) < 0 and ws(_lib.PV_WS_COLSUM, 0, 8) < 0
+    assert lib.pv_workspace_size(_lib.PV_WS_COLSUM, None, 2) < 0
+    from peekvit_amd import ops
+    assert ops.workspace_bytes(_lib.PV_WS_LAYERNORM_BWD, 100, 384) == 25 * 3 * 384 * 4
