@@ -576,7 +576,7 @@ def main():
         # doubled per MI355X_MICROARCH.md "HBM"): profiles/rNN_kernel_summary.json, keyed by the rocprof kernel name - the 256^2 kernel's template
         # argument is the epilogue, so the in-projection (<0>) and fc1 (<1>) have their own rows, the two residual GEMMs share <2>
         try:
-            prof = next(f for f in ("r04_kernel_summary.json", "r03_kernel_summary.json", "r02_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            prof = next(f for f in ("r05_kernel_summary.json", "r04_kernel_summary.json", "r03_kernel_summary.json", "r02_kernel_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             summ = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
             if dom.startswith("pv_gemm_bf16") and args.model == "vit_b_16" and args.batch == 2048 and args.rank_budget is None and not args.train:
                 for m in roof["members"]:
