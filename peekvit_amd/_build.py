@@ -31,7 +31,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(LIB_F16):
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_F16))
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "peekvit_hip.h")]
+    # (this file too: FLAGS / FILE_FLAGS are part of what the libraries were built with - round-4 review: a checkout that only changed a flag kept its old .so)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "peekvit_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

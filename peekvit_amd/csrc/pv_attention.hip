@@ -49,8 +49,11 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #endif
 #define PV_P_UNSHIFT (1.0f / (float)(1 << (int)PV_P_SHIFT))       // 2^-PV_P_SHIFT, exact
 
+#ifndef PV_ATTN_NW
+#define PV_ATTN_NW 4         // waves per workgroup of pv_attn_kernel (A/B: 8 waves x 2 workgroups per CU instead of 4 x 3; scripts/attn_ab.py)
+#endif
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
-__global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
+__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
@@ -58,8 +61,9 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     constexpr int SP = NKT * 16;        // padded key count: LDS holds exactly SP rows of K and of V
     constexpr int NDT = DH / 16;        // 16-wide output d tiles
     constexpr int NCH = SP * CPR;       // 16-byte chunks per K (or V) image
-    constexpr int NIT = (NCH + 255) / 256;
-    constexpr int MAXQT = (NKT + 3) / 4;   // q tiles per wave (4 waves)
+    constexpr int NW = PV_ATTN_NW, NT = NW * 64;
+    constexpr int NIT = (NCH + NT - 1) / NT;
+    constexpr int MAXQT = (NKT + NW - 1) / NW;   // q tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + SP * DHP * 2;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     bf16x8 qf[MAXQT][KS];
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
-        int qr = (wid + 4 * t) * 16 + i16;
+        int qr = (wid + NW * t) * 16 + i16;
         qr = qr < S ? qr : S - 1;
         const uint16_t* qp = qb + (int64_t)qr * ld;
 #pragma unroll
@@ -103,11 +107,11 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     for (int kv = 0; kv < 2; ++kv) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) {
-                int row = it * (256 / CPR) + r_lane;
+            if (NCH % NT == 0 || it * NT + wid * 64 < NCH) {
+                int row = it * (NT / CPR) + r_lane;
                 row = row < S ? row : S - 1;
                 const uint16_t* src = kv_src + (int64_t)row * ld + kv * D;
-                const size_t dst = (size_t)(it * 256 + wid * 64) * 16;   // wave-uniform byte offset
+                const size_t dst = (size_t)(it * NT + wid * 64) * 16;   // wave-uniform byte offset
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)((kv ? Vs : Ks) + dst), 16, 0, 0);
             }
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
     // number of V pieces THIS wave issued (the youngest operations): waiting until only they remain retires Q and K
     int nv = 0;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) nv += (NCH % 256 == 0 || it * 256 + wid * 64 < NCH) ? 1 : 0;
+    for (int it = 0; it < NIT; ++it) nv += (NCH % NT == 0 || it * NT + wid * 64 < NCH) ? 1 : 0;
 
     // ---- LDS read bases: lane-constant swizzle terms hoisted, every read below is base + immediate ------------------------
     typedef __attribute__((address_space(3))) const char lds_cc;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void pv_attn_kernel(const uint16_t* __restrict
 
 #pragma unroll
     for (int t = 0; t < MAXQT; ++t) {
-        const int qt = wid + 4 * t;
+        const int qt = wid + NW * t;
         if (qt >= nqt) break;
         const int q0 = qt << 4;
         // ---- S^T tiles: sc[kt][r] = score(query q0+i16, key kt*16 + 4g + r) -----------------------------------
@@ -280,7 +284,7 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H, flag);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag);
     return pv_check_launch();
 }
 

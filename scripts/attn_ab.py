@@ -9,7 +9,7 @@ import ctypes as C, json, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from peekvit_amd import _build
-V = {"noflag": [], "g0": ["-DPV_SCORE_GUARD=0"], "noshift": ["-DPV_P_SHIFT=0.0f"]}
+V = {"nw8": ["-DPV_ATTN_NW=8"], "g0": ["-DPV_SCORE_GUARD=0"]}      # round 5: nw8 = 8 waves per workgroup (2 workgroups per CU) instead of 4 (3 per CU)
 path = lambda t: _build.LIB_F16 if t == "cur" else os.path.join(_build.HERE, "libpeekvit_hip_r2f16.so") if t == "r2" else os.path.join(_build.HERE, f"libpv_attn_{t}.so")
 if "--build" in sys.argv:
     src = os.path.join(_build.CSRC, "pv_attention.hip")
@@ -24,7 +24,7 @@ qkv = (torch.randn(B, S, 3 * H * dh, device=dev) * 0.7).to(torch.float16)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 libs, outs = {}, {}
 flagbuf = torch.zeros(1, dtype=torch.int32, device=dev)
-for t in ["r2", "noflag", "g0", "noshift", "cur"]:
+for t in ["r2", "nw8", "g0", "cur"]:
     if not os.path.exists(path(t)):
         continue
     lib = C.CDLL(path(t))

@@ -81,9 +81,23 @@ def _worker(rank, world, port, out_dir):
     reducer.zero_grad()
     nb_uniform = reducer.finish()
     reducer.remove()
+    # round 5: with `model=` the reducer all-reduces the fp16 training arithmetic's overflow verdict - a step dropped on ONE rank is dropped on all
+    from peekvit_amd import train_engine
+    red2 = dist.OverlappedGradReducer(model.parameters(), bucket_bytes=64 << 10, average=False, model=model)
+    red2.zero_grad()
+    (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    red2.finish()
+    skip_clean = red2.skip_step
+    red2.zero_grad()
+    (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    train_engine.train_state(model).last_skipped = rank == 1          # as if rank 1's gradients had overflowed
+    red2.finish()
+    skip_one = red2.skip_step
+    train_engine.train_state(model).last_skipped = False
+    red2.remove()
     if rank == 0:
         np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same, accum=accum, raised=raised,
-                 nb_uniform=nb_uniform, n_buckets=len(reducer._buckets),
+                 nb_uniform=nb_uniform, n_buckets=len(reducer._buckets), skip_clean=skip_clean, skip_one=skip_one,
                  **{"g_" + n: g.numpy() for n, g in reduced.items()})
     td.barrier()
     td.destroy_process_group()
@@ -110,5 +124,6 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert bool(got["same"])                                              # ... and produced bit-identical reduced gradients
     assert bool(got["accum"]) and bool(got["raised"])                     # no_sync() accumulation; a second backward outside it is refused
     assert int(got["nb_uniform"]) == int(got["n_buckets"])                # every bucket leaves on every rank
+    assert not bool(got["skip_clean"]) and bool(got["skip_one"])          # rank 0 learns that rank 1 dropped its step
     for n, p in model.named_parameters():
         assert np.allclose(got["g_" + n], p.grad.numpy(), rtol=1e-4, atol=1e-6), n
