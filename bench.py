@@ -221,6 +221,8 @@ def extra_config(kind, dev, steps, warmup):
     with (torch.enable_grad() if train else torch.no_grad()):
         for _ in range(warmup):
             step()
+        import gc
+        gc.collect()                  # (see the headline's warm-up)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -513,6 +515,10 @@ def main():
     with (torch.enable_grad() if args.train else torch.no_grad()), engine.precision(args.precision):
         for _ in range(args.warmup):
             out = model(x)
+        # (Python's first full garbage collection of the process - ~85 ms over the module trees and tensors built so far - otherwise lands somewhere
+        # in the first few dozen steps, i.e. inside a short timed region, instead of in start-up where it belongs: scripts/dbg/train_step_times.py)
+        import gc
+        gc.collect()
         # (1) the contract's timed region: exactly K steps between barrier + synchronize, nothing else on the stream
         barrier()
         t0 = time.perf_counter()

@@ -31,10 +31,12 @@ the last block, `block.mask` handed to auxiliary losses) or by 1/L (where one le
 token) - see enter() / leave() / _unscale() - so autograd and the optimizer only ever see true gradients: the reference's loop
 (train/train.py:112-121) runs unchanged.  L follows the entering gradient's measured maximum with one step's delay (the first step reads
 it synchronously).  An fp16 overflow anywhere in the chain turns into inf / NaN that propagates to the small per-block reductions every
-backward node adds to `TrainPass.chk`; the end-of-backward callback reads that word (one host synchronisation per step - the
-reference's loop synchronises right behind it for `loss.item()`), and on overflow SKIPS the step the way torch.cuda.amp.GradScaler does
-- every parameter's `.grad` is set to None, which torch optimizers pass over - and lowers the target.  An overflow of the FORWARD
-(a 16-bit activation beyond 65504: range flag bit 1) sends that model's training to bf16 operands for good.
+backward node adds to `TrainPass.chk`.  The verdict is formed ON THE DEVICE at the end of the backward pass (no host synchronisation: the host
+keeps queueing the next step) and applied where the step would be taken, by a global optimizer-step pre-hook, the way torch.cuda.amp.GradScaler
+does: a FUSED torch optimizer receives it as `found_inf` (its kernel skips the update), any other optimizer has every parameter's `.grad` set to
+None behind one event wait, which makes `step()` a no-op; the scale target is lowered when the host gets to read the verdict (at the latest when
+the next backward pass starts).  An overflow of the FORWARD (a 16-bit activation beyond 65504: range flag bit 1) sends that model's training to
+bf16 operands for good.
 Blocks called on their own under autograd (no model-level pass) keep bf16 operands and no scale, as in rounds 1-4.
 """
 from __future__ import annotations
@@ -68,7 +70,7 @@ forward_fallbacks = 0        # models sent to bf16-operand training because thei
 
 class TrainState:
     """What the training path has learnt about one model (plain attribute `_pv_train`)."""
-    __slots__ = ("operand", "target", "amax", "scale", "steps", "skipped", "last_skipped", "on_skip", "warned")
+    __slots__ = ("operand", "target", "amax", "scale", "steps", "skipped", "last_skipped", "on_skip", "warned", "pending")
 
     def __init__(self):
         self.operand = None            # None: decided per pass from the precision mode; "bf16": sticky (an fp16 forward overflowed / weights do not fit)
@@ -78,6 +80,7 @@ class TrainState:
         self.steps, self.skipped, self.last_skipped = 0, 0, False
         self.on_skip = None            # callable(model) -> None replacing the default "every .grad = None" (dist.OverlappedGradReducer)
         self.warned = False
+        self.pending = None            # the last backward pass whose verdict has not been read on the host yet
 
 
 def train_state(model: nn.Module) -> TrainState:
@@ -89,8 +92,16 @@ def train_state(model: nn.Module) -> TrainState:
 
 
 def last_step_skipped(model: nn.Module) -> bool:
-    """Did the last backward through `model` overflow fp16 (its gradients were dropped: skip optimizer.step() / it is a no-op)?"""
-    return train_state(model).last_skipped
+    """Did the last backward through `model` overflow fp16?  Waits for that pass's verdict (one event) and, if it is one to skip and no optimizer
+    step has taken care of it yet, drops its gradients (every .grad = None): call it right behind `loss.backward()`."""
+    st = train_state(model)
+    tp = st.pending
+    if tp is not None:
+        if tp.resolve() and not tp.applied:
+            tp.drop_gradients()
+            if tp in _pending_passes:
+                _pending_passes.remove(tp)
+    return st.last_skipped
 
 
 class TrainPass:
@@ -106,6 +117,7 @@ class TrainPass:
             self.chk = torch.zeros(1, dtype=torch.float32, device=device) if self.scaled else None
         self.fwd_flag = None
         self.amax = None
+        self.found, self.host, self.event, self.applied, self.skipped = None, None, None, True, False
 
     # -- backward side ---------------------------------------------------------------------------------------------------------
     def begin_backward(self, grad: torch.Tensor, primary: bool) -> float:
@@ -113,6 +125,8 @@ class TrainPass:
         if not self.active:
             self.active = True
             st = self.state
+            if st.pending is not None and st.pending is not self:
+                st.pending.resolve()           # the previous step's verdict and statistics (its event has long fired: the GPU is at least a forward further)
             amax = st.amax
             if amax is None and primary:
                 amax = float(grad.detach().abs().max())            # first pass of this model: one synchronous read
@@ -134,22 +148,50 @@ class TrainPass:
                 self.chk.add_(t.sum())
 
     def _finish(self):
-        global steps_skipped, forward_fallbacks
+        """End of a backward pass (autograd callback): NO host synchronisation here (round 5, second form - the first one read the check word on
+        the spot, which cost small models a third of their training throughput: the host could no longer queue the next step while this one
+        runs).  The verdict is formed ON THE DEVICE - `found` = 1.0 if the check word is not finite or the forward raised its overflow bit - and
+        copied with the statistics to pinned host memory behind the kernels; who needs it on the host waits for that one event (`resolve`).
+        It is APPLIED where the step would otherwise be taken: the global optimizer-step pre-hook below."""
         self.active = False
-        st = self.state
         with torch.no_grad():
-            words = [self.chk, (self.amax if self.amax is not None else self.chk.new_zeros(())).reshape(1),
-                     (self.fwd_flag if self.fwd_flag is not None else self.flag).float()]
-            chk, amax, fbits = torch.cat(words).tolist()                 # the step's one host synchronisation
-            self.chk.zero_()
+            fwd = (self.fwd_flag if self.fwd_flag is not None else self.flag)
+            self.found = torch.logical_or(~torch.isfinite(self.chk), (fwd & 1) != 0).float()          # [1] on the device
+            words = torch.cat([self.chk, (self.amax if self.amax is not None else self.chk.new_zeros(())).reshape(1), fwd.float(), self.found])
+            self.found = self.found.reshape(())            # (torch's fused optimizers take `found_inf` as a 0-dim tensor, like GradScaler's)
+            self.host = torch.empty(4, dtype=torch.float32).pin_memory()
+            self.host.copy_(words, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(self.chk.device))
+            self.chk = torch.zeros_like(self.chk)          # (a later backward pass through the same graph starts a fresh word)
         self.amax = None
+        st = self.state
+        if st.pending is not None and st.pending is not self:
+            st.pending.resolve()
+        st.pending = self
+        self.applied = False
+        _pending_passes.append(self)
+
+    def resolve(self) -> bool:
+        """Wait for this pass's verdict (one event) and book it: loss-scale statistics, skipped-step counters, the bf16 fallback after a forward
+        overflow.  Returns whether the step was one to skip.  Idempotent."""
+        global steps_skipped, forward_fallbacks
+        if self.host is None:
+            return self.skipped
+        self.event.synchronize()
+        chk, amax, fbits, found = self.host.tolist()
+        self.host = None
+        st = self.state
+        if st.pending is self:
+            st.pending = None
         fwd_over = (int(fbits) & 1) != 0
-        if math.isfinite(chk) and not fwd_over:
+        self.skipped = bool(found)
+        if not self.skipped:
             st.steps += 1
             st.last_skipped = False
             if amax > 0.0 and math.isfinite(amax):
                 st.amax = amax
-            return
+            return False
         st.skipped += 1
         st.last_skipped = True
         steps_skipped += 1
@@ -163,13 +205,67 @@ class TrainPass:
             st.amax = amax if amax > 0.0 and math.isfinite(amax) else st.amax
             if not st.warned:
                 st.warned = True
-                warnings.warn(f"peekvit_amd: an fp16 gradient overflowed at loss scale {self.L:g}; this step's gradients were dropped (every .grad "
-                              "is None: optimizer.step() passes over them) and the scale target was lowered", RuntimeWarning, stacklevel=2)
-        if st.on_skip is not None:
-            st.on_skip(self.model)
+                warnings.warn(f"peekvit_amd: an fp16 gradient overflowed at loss scale {self.L:g}; this step's gradients were dropped (the optimizer "
+                              "step is skipped) and the scale target was lowered", RuntimeWarning, stacklevel=2)
+        return True
+
+    def drop_gradients(self):
+        """The skip, host form: every .grad = None (torch optimizers and clip_grad_norm_ pass over such parameters), or the owner's own way
+        (dist.OverlappedGradReducer: its gradients alias the all-reduce buckets)."""
+        if self.applied:
+            return
+        self.applied = True
+        if self.state.on_skip is not None:
+            self.state.on_skip(self.model)
         else:
             for p in self.model.parameters():
                 p.grad = None
+
+
+# Passes whose verdict has not been applied to an optimizer step yet.  The global optimizer-step pre-hook applies them: a FUSED torch optimizer
+# (`_step_supports_amp_scaling`: the interface torch.cuda.amp.GradScaler uses) is handed the device-side verdict as `found_inf` - its kernel skips
+# the update and takes the step count back, no host synchronisation; any other optimizer gets the host form: wait for the verdict, and if the
+# step is one to skip set every .grad to None, which makes `step()` a no-op (what GradScaler does for such optimizers, synchronisation included).
+_pending_passes: list = []
+
+
+def _optimizer_pre_hook(opt, args, kwargs):
+    if not _pending_passes:
+        return None
+    mine = {id(p) for g in opt.param_groups for p in g["params"]}
+    todo = [tp for tp in _pending_passes if not tp.applied and any(id(p) in mine for p in tp.model.parameters())]
+    if not todo:
+        return None
+    for tp in todo:
+        _pending_passes.remove(tp)
+    if getattr(opt, "_step_supports_amp_scaling", False) and all(tp.state.on_skip is None for tp in todo):
+        found = todo[0].found if len(todo) == 1 else torch.stack([tp.found for tp in todo]).amax(0)
+        prev = getattr(opt, "found_inf", None)
+        opt._pv_prev_found = prev
+        opt.found_inf = found if prev is None else torch.maximum(prev.to(found.device).reshape(()).float(), found)
+        opt._pv_found_set = True
+        for tp in todo:
+            tp.applied = True
+        return None
+    for tp in todo:
+        if tp.resolve():
+            tp.drop_gradients()
+        tp.applied = True
+    return None
+
+
+def _optimizer_post_hook(opt, args, kwargs):
+    if getattr(opt, "_pv_found_set", False):
+        opt.found_inf = opt._pv_prev_found
+        opt._pv_found_set = False
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post, register_optimizer_step_pre_hook as _reg_pre
+    _reg_pre(_optimizer_pre_hook)
+    _reg_post(_optimizer_post_hook)
+except ImportError:                    # pragma: no cover - torch < 2.0
+    pass
 
 
 def current_pass() -> Optional[TrainPass]:

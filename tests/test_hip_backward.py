@@ -688,7 +688,8 @@ def test_fp16_training_is_the_default_and_scales_its_gradients():
     assert train_engine.pass_operand(m16) == "f16"
     torch.nn.functional.cross_entropy(m16(x), y).backward()
     st = train_engine.train_state(m16)
-    assert st.scale >= 2.0 and st.steps == 1 and st.skipped == 0 and not train_engine.last_step_skipped(m16)
+    assert not train_engine.last_step_skipped(m16)              # (waits for the pass's verdict: it is formed on the device and read lazily)
+    assert st.scale >= 2.0 and st.steps == 1 and st.skipped == 0
     assert abs(st.scale * st.amax - train_engine.SCALE_TARGET) <= 0.5 * train_engine.SCALE_TARGET          # a power of two: within a factor 2 below the target
     with engine.precision("bf16"):
         assert train_engine.pass_operand(mbf) == "bf16"
@@ -716,7 +717,7 @@ def test_fp16_training_overflow_skips_the_step_like_a_grad_scaler():
     skipped0 = train_engine.steps_skipped
     with pytest.warns(RuntimeWarning, match="overflowed"):
         torch.nn.functional.cross_entropy(m(x), y).backward()
-    assert train_engine.last_step_skipped(m) and st.skipped == 1 and train_engine.steps_skipped == skipped0 + 1
+        assert train_engine.last_step_skipped(m) and st.skipped == 1 and train_engine.steps_skipped == skipped0 + 1
     assert all(p.grad is None for p in m.parameters())
     assert float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)) == 0.0          # the reference's loop: clip, then step - both no-ops
     opt.step()
@@ -737,7 +738,8 @@ def test_fp16_training_forward_overflow_falls_back_to_bf16_operands():
         m.encoder.layers[0].mlp.fc1.bias.fill_(3.0e5)        # gelu(3e5) = 3e5 does not fit fp16
     with pytest.warns(RuntimeWarning, match="fp16 range"):
         torch.nn.functional.cross_entropy(m(x), y).backward()
-    assert train_engine.last_step_skipped(m) and all(p.grad is None for p in m.parameters())
+        assert train_engine.last_step_skipped(m)
+    assert all(p.grad is None for p in m.parameters())
     assert train_engine.pass_operand(m) == "bf16"
     torch.nn.functional.cross_entropy(m(x), y).backward()
     assert not train_engine.last_step_skipped(m) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
@@ -786,3 +788,42 @@ def test_fp16_training_with_a_stock_op_block_in_the_middle(monkeypatch):
         if b.grad is not None and float(b.grad.norm()) > 0:
             one_number = a.numel() == 1 or "budget_token_gate" in n
             assert rel_l2(a.grad, b.grad) < (6e-2 if one_number else 3e-2), (n, rel_l2(a.grad, b.grad))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fp16_training_overflow_inside_the_unchanged_loop(fused):
+    """The reference's loop verbatim (train/train.py:112-121: zero_grad, forward, backward, clip_grad_norm_, optimizer.step) never asks whether a step
+    overflowed.  The verdict is applied by the optimizer-step pre-hook: a FUSED optimizer gets it as the device-side `found_inf` of torch's AMP
+    interface (its kernel skips the update, no host synchronisation), any other optimizer gets every .grad set to None behind one event wait.
+    Either way the overflowed step leaves the weights and Adam's moments untouched and the next step trains."""
+    from peekvit_amd import train_engine
+    cfg, (m, _), x, y = _train_pair("vit_micro", 6)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=fused)
+    st = train_engine.train_state(m)
+
+    def step():
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    step()
+    before = [p.detach().clone() for p in m.parameters()]
+    moments = [opt.state[p]["exp_avg"].clone() for p in m.parameters()]
+    steps0 = [float(opt.state[p]["step"]) for p in m.parameters()]
+    st.target = 2.0 ** 30
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step()                                                   # overflows: must be a no-op for the weights and the optimizer state
+        assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+        assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(moments, m.parameters()))
+        assert [float(opt.state[p]["step"]) for p in m.parameters()] == steps0
+        st.target = train_engine.SCALE_TARGET
+        step()
+    assert not train_engine.last_step_skipped(m)                 # (reads the last pass's verdict: the counters below are booked lazily)
+    assert st.skipped == 1 and st.steps == 2
+    assert not all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    assert all(torch.isfinite(p).all() for p in m.parameters())
