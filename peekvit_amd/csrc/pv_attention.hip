@@ -1333,7 +1333,10 @@ __global__ __launch_bounds__(256, WGS) void pv_attn_bwd2_kernel(const uint16_t* 
                 dw[t] = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
             }
         };
-#pragma unroll 1
+#ifndef PV_ABW2_P2_UNROLL
+#define PV_ABW2_P2_UNROLL 1
+#endif
+#pragma unroll PV_ABW2_P2_UNROLL
         for (int tt = 0; tt < NKT / 2; ++tt) {
             u32x2 p0[KPW], d0[KPW], p1[KPW], d1[KPW];
             pds(2 * tt, p0, d0);

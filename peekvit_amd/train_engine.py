@@ -171,6 +171,10 @@ class TrainPass:
         st.pending = self
         self.applied = False
         _pending_passes.append(self)
+        while len(_pending_passes) > 16:           # (backward passes that no optimizer step ever consumes - gradients taken for their own sake - must not pile up)
+            old = _pending_passes.pop(0)
+            old.resolve()
+            old.applied = True
 
     def resolve(self) -> bool:
         """Wait for this pass's verdict (one event) and book it: loss-scale statistics, skipped-step counters, the bf16 fallback after a forward

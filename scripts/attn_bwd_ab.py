@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 # round 3: "shipped" = two key tiles per wave in pass 2 (rolled q-pair loop); kpw1 = round 2's one key tile per wave with three q-tile pairs per trip;
 # kpw2u2 / kpw2u3 = two key tiles with two / three pairs per trip
 # round 5: "shipped" = pv_attn_bwd2_kernel (two images in LDS at a time, 4 waves, 2-3 workgroups per CU); v1 = the round 1-4 kernel (four images, 8 waves, one per CU)
-VARIANTS = {"v1": ["-DPV_ABW_V2=0"]}
+VARIANTS = {"v1": ["-DPV_ABW_V2=0"], "u2": ["-DPV_ABW2_P2_UNROLL=2"]}       # u2: pass 2 of the round-5 kernel with two query-tile pairs per loop trip
 from peekvit_amd import _build
 if "--build" in sys.argv:
     _build.build()
