@@ -18,6 +18,28 @@ __device__ __forceinline__ int pv_swz(int row, int chunk) {
     return ((line << 3) + (pos ^ (line & 7))) << 4;
 }
 
+// (image, head) of workgroup i, XCD-aware (round 5).  The hardware deals consecutive workgroups to the eight XCDs in turn, each with its own L2, and
+// blockIdx -> (b = i / H, h = i % H) therefore spreads the heads of ONE image over all eight L2s.  A head's slice of a token row is 2 * dh bytes:
+// at dh = 64 exactly one 128-byte line, but at dh = 48 (vit_small) 96 bytes that straddle lines and at dh = 32 (vit_tiny) half a line, so every L2
+// fetched the lines it shares with its neighbours' heads again: rocprofv3 FETCH_SIZE 465 MB per launch against 232 MB of q|k|v at vit_small, batch 512
+// (profiles/r05_vit_small_kernel_summary.json) - the kernel ran at 5.5 TB/s of fabric traffic, half of it redundant.  Here workgroups 8q + x, q = k H ..
+// k H + H - 1, are the H heads of image 8k + x: one image's heads share an XCD and are dispatched back to back.  `PV_BH_XCD=0` restores i / H, i % H.
+#ifndef PV_BH_XCD
+#define PV_BH_XCD 1
+#endif
+__device__ __forceinline__ void pv_bh_map(int i, int B, int H, int& b, int& h) {
+    const int nfull = PV_BH_XCD ? (B >> 3) * 8 * H : 0;        // workgroups of complete groups of eight images
+    if (i < nfull) {
+        const int q = i >> 3, k = q / H;
+        b = k * 8 + (i & 7);
+        h = q - k * H;
+    } else {
+        const int r = i - nfull;
+        b = (nfull / H) + r / H;
+        h = r % H;
+    }
+}
+
 #ifdef PV_STAMPS
 __device__ unsigned long long* d_pv_adbg;     // diagnostic build only: stamps go to a buffer no kernel reads
 extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_pv_adbg), &p, sizeof(p)); }
@@ -53,7 +75,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #define PV_ATTN_NW 4         // waves per workgroup of pv_attn_kernel (A/B: 8 waves x 2 workgroups per CU instead of 4 x 3; scripts/attn_ab.py)
 #endif
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
-__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag) {
+__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
@@ -71,7 +93,8 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    int b, h;
+    pv_bh_map(blockIdx.x, B, H, b, h);
     PV_ASTAMP(0);
     const int D = H * DH;
     const int64_t ld = 3 * (int64_t)D;
@@ -284,7 +307,7 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B);
     return pv_check_launch();
 }
 
@@ -579,7 +602,7 @@ __device__ __forceinline__ void pv_split8(const float4 a, const float4 b, u32x4&
 }
 
 template <int DH, int NKT>
-__global__ __launch_bounds__(256, 2) void pv_attn_split_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H) {
+__global__ __launch_bounds__(256, 2) void pv_attn_split_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int B) {
     constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, KS = DHP / 32, NKT32 = NKT / 2, SP = NKT * 16, NDT = DH / 16, IMG = SP * DHP * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Kh = smem;
@@ -588,7 +611,8 @@ __global__ __launch_bounds__(256, 2) void pv_attn_split_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    int b, h;
+    pv_bh_map(blockIdx.x, B, H, b, h);
     const int D = H * DH;
     const int64_t ld = 3 * (int64_t)D;
     const float* qb = qkv + (int64_t)b * S * ld + h * DH;
@@ -732,7 +756,7 @@ static int pv_launch_attn_split(const float* qkv, uint16_t* out, int64_t B, int 
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_split_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_split_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H);
+    PV_LAUNCH((pv_attn_split_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, out, S, H, (int)B);
     return pv_check_launch();
 }
 
@@ -1096,7 +1120,7 @@ __global__ __launch_bounds__(NW * 64) void pv_attn_bwd_kernel(const uint16_t* __
 #endif
 template <int DH, int NKT, int WGS>     // WGS: workgroups per CU the register budget is set for (launch bounds)
 __global__ __launch_bounds__(256, WGS) void pv_attn_bwd2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                  uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H, float qscale) {
+                                                                  uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H, float qscale, int B) {
     constexpr int NW = 4;
     constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;
     constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
@@ -1110,7 +1134,8 @@ __global__ __launch_bounds__(256, WGS) void pv_attn_bwd2_kernel(const uint16_t* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    int b, h;
+    pv_bh_map(blockIdx.x, B, H, b, h);
     const int D = H * DH;
     const int64_t ld = 3 * (int64_t)D;
     const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
@@ -1426,7 +1451,7 @@ static int pv_launch_attn_bwd2(const uint16_t* qkv, const uint16_t* dout, uint16
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd2_kernel<DH, NKT, WGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_bwd2_kernel<DH, NKT, WGS>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, dout, dqkv, dbp, S, H, qscale);
+    PV_LAUNCH((pv_attn_bwd2_kernel<DH, NKT, WGS>), dim3((unsigned)(B * H)), dim3(256), lds, stream, qkv, dout, dqkv, dbp, S, H, qscale, (int)B);
     return pv_check_launch();
 }
 
