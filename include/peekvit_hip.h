@@ -264,6 +264,10 @@ int pv_transpose_bf16(const uint16_t* src, int64_t lds, uint16_t* dst, int64_t R
  * ws: fp32 scratch of >= min(ceil(rows/4),1024)*3*D floats.  D % 4 == 0, D <= 1024. */
 int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, float* dx_out, uint16_t* dx_bf16,
                      float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
+/* The same with the residual gradient handed over in 16 BITS between the two LayerNorms of a block (ABI v8, an option of the training path): dres16
+ * (16-bit [rows,D], optional) instead of the fp32 dres_in (at most one of them), and dx_out may be NULL when only dx_bf16 is wanted. */
+int pv_layernorm_bwd16(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, const uint16_t* dres16, float* dx_out,
+                       uint16_t* dx_bf16, float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream);
 /* Masked form for ResidualViT training (models/residualvit.py:249-260): the forward was y = row_scale[row] * LayerNorm(x).
  * dmask fp32 [rows] (+)= sum_d dy * LayerNorm(x) (+ sum_d dx_out * u when u, the bf16 branch output of x1 = x + m*u, is given);
  * dy is then scaled by row_scale and the plain backward follows.  scale_copy != 0 writes dx_bf16 = row_scale * dx_out (the gradient

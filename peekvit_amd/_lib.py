@@ -63,6 +63,7 @@ SIGNATURES = {
     "pv_sum_slices_add_ln_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p]),
     "pv_transpose_bf16": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
     "pv_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, C.c_int, _p]),
+    "pv_layernorm_bwd16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, C.c_int, _p]),
     "pv_layernorm_bwd_masked": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, C.c_int, _p, _i64, _i64, _i64, _f32, _p]),
     "pv_masked_residual": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "pv_gelu_bf16": (C.c_int, [_p, _p, _i64, _p]),

@@ -558,7 +558,8 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
                                                                float* __restrict__ dx_out, uint16_t* __restrict__ dx_bf16, float* __restrict__ ws,
                                                                int64_t rows, int D, float eps, const float* __restrict__ beta,
                                                                const float* __restrict__ row_scale, float* __restrict__ dmask,
-                                                               const uint16_t* __restrict__ u, int scale_copy, int dmask_accumulate) {
+                                                               const uint16_t* __restrict__ u, int scale_copy, int dmask_accumulate,
+                                                               const uint16_t* __restrict__ dres16 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvec = D >> 2;
     float4 ag[NCH], ab[NCH], ac[NCH], gm[NCH];
 #pragma unroll
@@ -618,11 +619,15 @@ __global__ __launch_bounds__(256) void pv_layernorm_bwd_kernel(const float* __re
             const int idx = lane + 64 * j;
             if (idx < nvec) {
                 float4 o = dres_in ? reinterpret_cast<const float4*>(dres_in + row * D)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!MASKED && dres16) {           // the residual gradient handed over in 16 bits (pv_layernorm_bwd16)
+                    const u32x2 rw = reinterpret_cast<const u32x2*>(dres16 + row * D)[idx];
+                    o = make_float4(pv_unpack_lo(rw[0]), pv_unpack_hi(rw[0]), pv_unpack_lo(rw[1]), pv_unpack_hi(rw[1]));
+                }
                 o.x += rstd * (d[j].x - s1 - r.v[j].x * s2);
                 o.y += rstd * (d[j].y - s1 - r.v[j].y * s2);
                 o.z += rstd * (d[j].z - s1 - r.v[j].z * s2);
                 o.w += rstd * (d[j].w - s1 - r.v[j].w * s2);
-                reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
+                if (MASKED || dx_out) reinterpret_cast<float4*>(dx_out + row * D)[idx] = o;
                 if (MASKED && u) {
                     const u32x2 uw = reinterpret_cast<const u32x2*>(u + row * D)[idx];
                     mdot += (o.x * pv_unpack_lo(uw[0]) + o.y * pv_unpack_hi(uw[0])) + (o.z * pv_unpack_lo(uw[1]) + o.w * pv_unpack_hi(uw[1]));
@@ -673,6 +678,27 @@ extern "C" int pv_layernorm_bwd(const float* x, const uint16_t* dy, const float*
     dim3 grid((unsigned)blocks);
 #define LNB_LAUNCH(N) PV_LAUNCH((pv_layernorm_bwd_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps, \
                                 (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const uint16_t*)nullptr, 0, 0)
+    { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
+#undef LNB_LAUNCH
+    if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;
+    PV_LAUNCH(pv_colsum_stage2_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgb, blocks, (int)(3 * D), accumulate);
+    return pv_check_launch();
+}
+
+// The same backward with the residual gradient travelling in 16 bits between the two LayerNorms of a block (round 5, an OPTION of the training
+// path): dres16 (optional) replaces the fp32 dres_in, and dx_out may be NULL when only the 16-bit copy dx_bf16 is wanted.
+extern "C" int pv_layernorm_bwd16(const float* x, const uint16_t* dy, const float* gamma, const float* dres_in, const uint16_t* dres16, float* dx_out,
+                                  uint16_t* dx_bf16, float* dgb, float* ws, int64_t ws_floats, int64_t rows, int64_t D, float eps, int accumulate, void* stream) {
+    if (!x || !dy || !gamma || (!dx_out && !dx_bf16) || !dgb || !ws || rows <= 0 || D <= 0 || (dres_in && dres16)) return PV_ERR_INVALID_ARG;
+    if (D % 4 || D > 1024) return PV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 7) || ((uintptr_t)gamma & 15) || (dx_out && ((uintptr_t)dx_out & 15)) || ((uintptr_t)dgb & 15) ||
+        ((uintptr_t)ws & 15) || (dres_in && ((uintptr_t)dres_in & 15)) || (dres16 && ((uintptr_t)dres16 & 7)) || (dx_bf16 && ((uintptr_t)dx_bf16 & 7))) return PV_ERR_INVALID_ARG;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (ws_floats < blocks * 3 * D) return PV_ERR_INVALID_ARG;
+    dim3 grid((unsigned)blocks);
+#define LNB_LAUNCH(N) PV_LAUNCH((pv_layernorm_bwd_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dres_in, dx_out, dx_bf16, ws, rows, (int)D, eps, \
+                                (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const uint16_t*)nullptr, 0, 0, dres16)
     { int nch_ = (int)((D / 4 + 63) / 64); if (nch_ <= 1) { LNB_LAUNCH(1); } else if (nch_ == 2) { LNB_LAUNCH(2); } else if (nch_ == 3) { LNB_LAUNCH(3); } else { LNB_LAUNCH(4); } }
 #undef LNB_LAUNCH
     if (pv_check_launch() != PV_OK) return PV_ERR_LAUNCH;

@@ -415,13 +415,27 @@ def colsum(src: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> to
     return out
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: torch.Tensor, dgb: torch.Tensor, eps: float,
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, dres_in, dx_out: Optional[torch.Tensor], dgb: torch.Tensor, eps: float,
                   accumulate: bool = False, dx_bf16: Optional[torch.Tensor] = None):
-    """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [3,D] (+)= (dgamma, dbeta, colsum(dx)).  x fp32 [rows,D], dy bf16 [rows,D]."""
-    _chk(x, torch.float32, "x"); _chk(dy, _lib.operand_dtype(), "dy"); _chk(dx_out, torch.float32, "dx_out"); _chk(dgb, torch.float32, "dgb")
+    """dx_out = (dres_in or 0) + LN'(x)^T dy;  dgb [3,D] (+)= (dgamma, dbeta, colsum(dx)).  x fp32 [rows,D], dy bf16 [rows,D].
+    dres_in may be a 16-BIT tensor and dx_out None (only the 16-bit copy dx_bf16 is written): the residual gradient handed over in 16 bits
+    between the two LayerNorms of a block (pv_layernorm_bwd16; an option of the training path)."""
+    _chk(x, torch.float32, "x"); _chk(dy, _lib.operand_dtype(), "dy"); _chk(dgb, torch.float32, "dgb")
     D = x.shape[-1]
     rows = x.numel() // D
     ws = _scratch_f32(_lib.PV_WS_LAYERNORM_BWD, x.device, rows, D)
+    if dx_out is None or (dres_in is not None and dres_in.dtype != torch.float32):
+        d16 = dres_in if dres_in is not None and dres_in.dtype != torch.float32 else None
+        d32 = dres_in if dres_in is not None and dres_in.dtype == torch.float32 else None
+        if d16 is not None:
+            _chk(d16, _lib.operand_dtype(), "dres16")
+        nb = 4.0 + 2.0 + (4.0 if dx_out is not None else 0.0) + (4.0 if d32 is not None else 0.0) + (2.0 if d16 is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0)
+        with _timed("pv_layernorm_bwd", x.device, 0.0, nb * x.numel()):
+            check(_lib.load().pv_layernorm_bwd16(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(d32), _ptr(d16), _ptr(dx_out), _ptr(dx_bf16), _ptr(dgb), _ptr(ws), ws.numel(),
+                                                 rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd16")
+        _count()
+        return dx_out
+    _chk(dx_out, torch.float32, "dx_out")
     with _timed("pv_layernorm_bwd", x.device, 0.0, (4.0 + 2.0 + 4.0 + (4.0 if dres_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0)) * x.numel()):
         check(_lib.load().pv_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dres_in) if dres_in is not None else 0, _ptr(dx_out), _ptr(dx_bf16), _ptr(dgb),
                                            _ptr(ws), ws.numel(), rows, D, float(eps), int(accumulate), _stream(x)), "pv_layernorm_bwd")

@@ -494,6 +494,13 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, tag: str, bias_grad: bool = True):
 
 
 _NO_TN = os.environ.get("PEEKVIT_AMD_WGRAD", "tn") != "tn"
+# The residual gradient at x1 (between the two LayerNorm backward kernels of a block) travels in 16 bits in an fp16 pass: LayerNorm 2's backward
+# writes only the 16-bit copy the data / weight-gradient GEMMs read anyway, LayerNorm 1's backward reads that copy as its residual term - 26
+# instead of 32 bytes per element through the two kernels that sit at the HBM roofline: 235.2 -> 232.0 ms per ViT-B/16 step (8.71 -> 8.83 k img/s).
+# Cost: one fp16 rounding (2^-11, in scaled space) of the residual gradient per block - complete gradients 0.88 - 1.21e-3 from the reference's training
+# step instead of 0.36 - 0.98e-3 (asserted 2e-3), gradient norms unchanged (2 - 4e-4).  The block-to-block stream stays fp32.  bf16 passes keep the
+# fp32 hand-off (a bf16 rounding per block is 1 %).  PEEKVIT_AMD_TRAIN_DX1=f32 restores it everywhere.
+_DX1_16 = os.environ.get("PEEKVIT_AMD_TRAIN_DX1", "16") == "16"
 
 
 def _bf16_grad(dout: torch.Tensor, buf: torch.Tensor):
@@ -576,7 +583,9 @@ class BlockFn(torch.autograd.Function):
         dw1 = _wgrad(dpre, h2, "fc1", bias_grad=False)[0] if need["w1"] else None
         dhid = ws.get("bw_dh", (R, D), bf, dev)
         ops.gemm(dpre, bf16_weight_t(blk.mlp.fc1.weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
-        dx1 = ws.get("bw_dx1", (R, D), torch.float32, dev)
+        # (fp16 pass: the residual gradient at x1 travels to LayerNorm 1's backward as the 16-bit copy the GEMMs read anyway: _DX1_16 above)
+        dx1_16 = _DX1_16 and bf == torch.float16
+        dx1 = None if dx1_16 else ws.get("bw_dx1", (R, D), torch.float32, dev)
         dgb2 = torch.empty((3, D), dtype=torch.float32, device=dev)
         d1 = ws.get("bw_d1", (R, D), bf, dev)
         ops.layernorm_bwd(x1.view(R, D), dhid, _f32(blk.ln_2.weight), dout, dx1, dgb2, blk.ln_2.eps, dx_bf16=d1)
@@ -594,7 +603,7 @@ class BlockFn(torch.autograd.Function):
         dx = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         dgb1 = torch.empty((3, D), dtype=torch.float32, device=dev)
         dxb = torch.empty((B, S, D), dtype=bf, device=dev)
-        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), dx1, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
+        ops.layernorm_bwd(x.view(R, D), dhid, _f32(blk.ln_1.weight), d1 if dx1_16 else dx1, dx.view(R, D), dgb1, blk.ln_1.eps, dx_bf16=dxb)
         if debug_amax is not None:           # diagnostics (scripts/train_f16_probe.py): the largest 16-bit gradient of every kind in this block, in scaled units
             debug_amax.append({k: float(v.float().abs().max()) for k, v in (("d2", d2), ("dpre", dpre), ("d1", d1), ("datt", datt), ("dqkv", dqkv), ("dh1", dhid), ("dx", dxb))})
         if ctx.tp is not None:

@@ -22,6 +22,7 @@ def rel(a, b):
 
 def run(name, batch, operand, g):
     train_engine._TRAIN_OPERAND = operand
+    train_engine._DX1_16 = os.environ.get("PEEKVIT_AMD_TRAIN_DX1", "16") == "16"
     if name.startswith("rankvit"):
         cfg = synth.MODEL_CONFIGS[name.replace("rankvit", "vit")]
         m = RankVisionTransformer(**cfg, rankvit_layers=[3, 6, 9] if name.endswith("b_16") else [1])

@@ -494,7 +494,8 @@ def test_training_step_vs_reference_golden(golden, name, batch):
     # Round 5: the training arithmetic is the inference path's - IEEE fp16 operands, with a loss scale for the 16-bit gradients (train_engine
     # docstring) - so the training FORWARD is inside north_star's 1e-3 (5.0e-4 .. 6.7e-4 measured; bf16 operands, rounds 1-4: 4 - 6e-3, asserted
     # at 1.2e-2), and the gradients follow: complete gradients 3.6e-4 .. 9.8e-4 from the reference's (bf16: 3 - 8e-3, asserted at 3e-2), gradient
-    # norms 2 - 4e-4 (profiles/r05_train_f16_probe.txt).  Asserted at 1e-3 (logits), 2e-3 (gradients), 1e-3 (norms).
+    # norms 2 - 4e-4 (profiles/r05_train_f16_probe.txt); with the 16-bit residual-gradient hand-off between the LayerNorm backward kernels of a block
+    # (train_engine._DX1_16, the default): complete gradients 0.88 - 1.21e-3.  Asserted at 1e-3 (logits), 2e-3 (gradients), 1e-3 (norms).
     from peekvit_amd import train_engine
     assert train_engine.pass_operand(m) == "f16" and train_engine.train_state(m).scale > 1.0 and not train_engine.last_step_skipped(m)
     assert rel_l2(logits.detach().float().cpu().numpy(), g[f"{name}/logits"]) < 1e-3
@@ -827,3 +828,24 @@ def test_fp16_training_overflow_inside_the_unchanged_loop(fused):
     assert st.skipped == 1 and st.steps == 2
     assert not all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("rows,D", [(1000, 192), (3940, 768)])
+def test_layernorm_backward_with_a_16_bit_residual_gradient(ops, rows, D):
+    """pv_layernorm_bwd16 (round 5): the residual gradient arrives as a 16-bit tensor and / or only the 16-bit copy of the result is written - the two
+    forms the fp16 training pass chains between the LayerNorms of a block.  Bit-identical to the fp32 entry point on the same values."""
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, D, generator=g, device="cuda") * 2 + 0.5
+    gamma = torch.randn(D, generator=g, device="cuda") * 0.3 + 1
+    dy = _bf(rows, D, seed=rows + 1, scale=0.05)
+    dres16 = _bf(rows, D, seed=rows + 2, scale=0.05)
+    # (a) 16-bit residual in: equals the fp32 entry point fed with the same values
+    dx_a, dxb_a, dgb_a = torch.empty_like(x), torch.empty(rows, D, device="cuda", dtype=torch.bfloat16), torch.empty(3, D, device="cuda")
+    ops.layernorm_bwd(x, dy, gamma, dres16, dx_a, dgb_a, 1e-5, dx_bf16=dxb_a)
+    dx_r, dxb_r, dgb_r = torch.empty_like(x), torch.empty_like(dxb_a), torch.empty(3, D, device="cuda")
+    ops.layernorm_bwd(x, dy, gamma, dres16.float(), dx_r, dgb_r, 1e-5, dx_bf16=dxb_r)
+    assert torch.equal(dx_a, dx_r) and torch.equal(dxb_a, dxb_r) and torch.equal(dgb_a, dgb_r)
+    # (b) no fp32 output: the 16-bit copy and the column sums are the same bits
+    dxb_b, dgb_b = torch.empty_like(dxb_a), torch.empty(3, D, device="cuda")
+    ops.layernorm_bwd(x, dy, gamma, dres16.float(), None, dgb_b, 1e-5, dx_bf16=dxb_b)
+    assert torch.equal(dxb_b, dxb_r) and torch.equal(dgb_b, dgb_r)
