@@ -242,8 +242,15 @@ def _optimizer_pre_hook(opt, args, kwargs):
         return None
     for tp in todo:
         _pending_passes.remove(tp)
+    # The verdict of a pass covers ITS backward.  Whoever sums gradients across ranks afterwards (torch's DistributedDataParallel, a hand-written
+    # all-reduce) hands a rank whose own verdict says "clean" the inf / NaN of a rank that overflowed: the gradients this step is about to consume
+    # are therefore checked as well (one multi-tensor norm over them - the pass clip_grad_norm_ makes too), on the device for fused optimizers.
+    grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None and p.grad.is_cuda]
     if getattr(opt, "_step_supports_amp_scaling", False) and all(tp.state.on_skip is None for tp in todo):
         found = todo[0].found if len(todo) == 1 else torch.stack([tp.found for tp in todo]).amax(0)
+        if grads:
+            with torch.no_grad():
+                found = torch.maximum(found, (~torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum())).float().to(found.device))
         prev = getattr(opt, "found_inf", None)
         opt._pv_prev_found = prev
         opt.found_inf = found if prev is None else torch.maximum(prev.to(found.device).reshape(()).float(), found)
@@ -251,10 +258,22 @@ def _optimizer_pre_hook(opt, args, kwargs):
         for tp in todo:
             tp.applied = True
         return None
+    skipped = False
     for tp in todo:
         if tp.resolve():
             tp.drop_gradients()
+            skipped = True
         tp.applied = True
+    if not skipped and grads:
+        with torch.no_grad():
+            if not bool(torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum())):       # (non-finite gradients from somewhere else: see above)
+                global steps_skipped
+                for tp in todo:
+                    tp.state.skipped += 1
+                    tp.state.last_skipped = True
+                    tp.applied = False
+                    tp.drop_gradients()
+                steps_skipped += 1
     return None
 
 

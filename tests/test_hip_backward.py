@@ -849,3 +849,30 @@ def test_layernorm_backward_with_a_16_bit_residual_gradient(ops, rows, D):
     dxb_b, dgb_b = torch.empty_like(dxb_a), torch.empty(3, D, device="cuda")
     ops.layernorm_bwd(x, dy, gamma, dres16.float(), None, dgb_b, 1e-5, dx_bf16=dxb_b)
     assert torch.equal(dxb_b, dxb_r) and torch.equal(dgb_b, dgb_r)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fp16_training_skips_a_step_whose_gradients_arrive_non_finite_from_elsewhere(fused):
+    """The overflow verdict of a pass covers its own backward; a gradient all-reduce that is not this package's (torch DDP) can hand a clean rank the
+    inf of another one.  The optimizer-step pre-hook therefore also checks the gradients the step is about to consume: here an inf is written
+    into one gradient between backward and step - the step must leave weights and optimizer state untouched, with either kind of optimizer."""
+    from peekvit_amd import train_engine
+    cfg, (m, _), x, y = _train_pair("vit_micro", 6)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=fused)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        opt.step()
+    before = [p.detach().clone() for p in m.parameters()]
+    steps0 = [float(opt.state[p]["step"]) for p in m.parameters()]
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    with torch.no_grad():
+        m.head.weight.grad[0, 0] = float("inf")            # "another rank overflowed"
+    opt.step()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    assert [float(opt.state[p]["step"]) for p in m.parameters()] == steps0
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    opt.step()
+    assert not all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters())) and all(torch.isfinite(p).all() for p in m.parameters())
