@@ -38,7 +38,7 @@ __device__ __forceinline__ void pv_bh_map(int i, int B, int H, int& b, int& h) {
         b = (nfull / H) + r / H;
         h = r % H;
     }
-#ifdef PV_BH_HOT       // experiment (scripts/attn_bwd4_ab.py): every workgroup works on one of eight images, whose operands stay in the L2s - what the kernels cost without HBM
+#ifdef PV_BH_HOT       // experiment (scripts/attn_hot.py): every workgroup works on one of eight images, whose operands stay in the L2s - what the kernels cost without HBM
     b &= 7;
 #endif
 }
@@ -54,17 +54,8 @@ extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbo
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         if ((threadIdx.x & 63) == 0 && d_pv_adbg) d_pv_adbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = t_;   \
     } while (0)
-#define PV_BSTAMP(i)       /* eight-wave kernels (pv_attn_bwd4_kernel; scripts/stamp_attn_bwd.py) */                      \
-    do {                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        unsigned long long t_;                                                                             \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if ((threadIdx.x & 63) == 0 && d_pv_adbg) d_pv_adbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = t_;   \
-    } while (0)
 #else
 #define PV_ASTAMP(i)
-#define PV_BSTAMP(i)
 #endif
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
@@ -87,7 +78,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #define PV_ATTN_NW 4         // waves per workgroup of pv_attn_kernel (A/B: 8 waves x 2 workgroups per CU instead of 4 x 3; scripts/attn_ab.py)
 #endif
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
-__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B, float* __restrict__ lse) {
+__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
@@ -261,10 +252,6 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
         }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        // training forward (round 5): the row's log-sum-exp in the exp2 domain, m log2(e) + log2(sum exp(s - m)): the backward kernel
-        // (pv_attn_bwd4_kernel) forms p = exp2(s log2(e) - lse) without the row maximum and sum.  (l carries 2^PV_P_SHIFT in the fp16 build.)
-        if (lse != nullptr && g == 0 && q0 + i16 < S)
-            lse[((int64_t)b * H + h) * S + q0 + i16] = m * 1.44269504088896340736f + (__builtin_amdgcn_logf(l) - PV_P_SHIFT);
         if (!v_ready) {            // first tile of the wave: V must have landed (for every wave) before the first PV product
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -316,14 +303,14 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
 }
 
 template <int DH, int NKT>
-static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse = nullptr) {
+static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int lds = 2 * NKT * 16 * DHP * 2;
     static PvPerDevice attr_set;
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B, lse);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B);
     return pv_check_launch();
 }
 
@@ -454,15 +441,15 @@ static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, 
 }
 
 template <int DH>
-static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse = nullptr) {
+static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
     switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream, lse);
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
         PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13) PV_ATTN_CASE(14)
         PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20) PV_ATTN_CASE(21)
         PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
-        default: return lse ? PV_ERR_UNSUPPORTED : pv_launch_attn_stream<DH>(qkv, out, B, S, H, flag, stream);      // (the streaming kernel keeps no statistics)
+        default: return pv_launch_attn_stream<DH>(qkv, out, B, S, H, flag, stream);
     }
 }
 
@@ -1485,399 +1472,6 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
     return pv_check_launch();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Attention backward from the forward's row statistics (round 5, `pv_attn_bwd4_kernel`, entry pv_attention_bwd_lse_bf16).  The two-pass kernels above
-// recompute the softmax statistics in pass 1, which forces a wave to hold a whole row block of scores AND of dP at once (104 registers at 13 key
-// tiles: 246 per wave, two waves per SIMD), and both passes are bound by the SIMD's vector ISSUE (an MFMA holds it for 8 of its 16 cycles, every
-// other vector instruction for 4 - 8), not by the matrix pipe or by HBM (with operands in L2 the kernel is only 14 % faster:
-// profiles/r05_attn_bwd4_ab.txt).  With lse = log2(sum_k exp(s[q,k])) from the forward (pv_attention_lse_bf16) and D = rowsum(dO o O) from a
-// prologue over the saved output, pass 1 STREAMS over pairs of key tiles - S^T, dP^T - D (the accumulator starts at -D), p = exp2(s log2e - lse),
-// dS = p (dP - D), dQ^T += K^T.dS^T - with two score tiles live instead of thirteen: no row maximum, no row sum, no rescale, no second sweep.
-// Pass 2 as before minus what the statistics make unnecessary (key padding needs no mask there: a padded key only feeds its own, unstored,
-// dK / dV rows).  In-projection bias gradient (per-image column sums of dqkv), without 48 accumulator registers:
-//   q third:  column sums of the stored dQ tiles, 16 registers in pass 1 only, reduced through DPP + LDS where pass 1 ends;
-//   k third:  0 - sum_k dK[k,:] = sum_q (sum_k dS[q,k]) Q[q,:] and sum_k dS[q,k] = sum_k p (dP - D) = D - D: softmax is invariant under a shift of
-//             all keys (the reference's autograd returns rounding noise around 0 there);
-//   v third:  sum_k dV[k,:] = sum_q (sum_k p[q,k]) dO[q,:] = the column sums of dO, taken in the prologue from the rows it reads for D anyway.
-// Same two phases otherwise (no atomics, bit-reproducible): 8 waves, K | V images for pass 1 and Q | dO images for pass 2 in the same 52 KiB
-// (pv_attn_bwd2_kernel's staging), < 128 registers: two workgroups per CU = FOUR waves per SIMD.
-// ------------------------------------------------------------------------------------------------
-#ifndef PV_ABW4_NW
-#define PV_ABW4_NW 8       // waves per workgroup (A/B: 7 - thirteen tiles in rounds of 7 + 6 instead of 8 + 5)
-#endif
-template <int DH, int NKT, int KPW>
-__global__ __launch_bounds__(PV_ABW4_NW * 64, 4) void pv_attn_bwd4_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const uint16_t* __restrict__ att,
-                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H,
-                                                              float qscale, int B) {
-    constexpr int NW = PV_ABW4_NW, NT = NW * 64;
-    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;
-    constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
-    constexpr int NCH = SP * CPR, NIT = (NCH + NT - 1) / NT;
-    constexpr float LOG2E = 1.44269504088896340736f;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const A_ = smem;                 // phase 1: K, phase 2: Q
-    char* const B_ = smem + IMG;           // phase 1: V, phase 2: dO
-    float* const st_m = reinterpret_cast<float*>(smem + 2 * IMG);      // PV_P_SHIFT - lse: p 2^PV_P_SHIFT = exp2(s log2e + st_m); -inf for a padded query
-    float* const st_d = st_m + SP;                                       // -D = -rowsum(dO o O): the dP accumulators start there
-    float* const red_v = st_d + SP;                                      // [NW][DH] column sums of dO per wave
-    float* const red_q = red_v + NW * DH;                                // [NW][DH] column sums of dQ per wave
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i16 = lane & 15;
-    int b, h;
-    pv_bh_map(blockIdx.x, B, H, b, h);
-    PV_BSTAMP(0);
-    const int D = H * DH;
-    const int64_t ld = 3 * (int64_t)D;
-    const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
-    const uint16_t* ob = dout + (int64_t)b * S * D + h * DH;
-    const uint16_t* ab = att + (int64_t)b * S * D + h * DH;
-    uint16_t* gb = dqkv + (int64_t)b * S * ld + h * DH;
-
-    const int lsw = (tid & 7) ^ ((tid >> 3) & 7);
-    const int r_lane = CPR == 8 ? (tid >> 3) : 2 * (tid >> 3) + (lsw >> 2);
-    int c_lane = CPR == 8 ? lsw : (lsw & 3);
-    if (c_lane * 8 >= DH) c_lane = 0;
-    auto stage = [&](const uint16_t* a, int64_t lda_, const uint16_t* bsrc, int64_t ldb_) __attribute__((always_inline)) {
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (NCH % NT == 0 || it * NT + wid * 64 < NCH) {
-                    int row = it * (NT / CPR) + r_lane;
-                    row = row < S ? row : S - 1;
-                    const uint16_t* src = (which ? bsrc + (int64_t)row * ldb_ : a + (int64_t)row * lda_) + c_lane * 8;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)((which ? B_ : A_) + (size_t)(it * NT + wid * 64) * 16), 16, 0, 0);
-                }
-            }
-        }
-    };
-    stage(qb + D, ld, qb + 2 * D, ld);                         // K | V
-    // row statistics: PV_P_SHIFT - lse from the forward, -D = -rowsum(dO o O) (eight lanes per row, 16 bytes of each operand per lane), column sums of dO
-    for (int q = tid; q < SP; q += NT) st_m[q] = q < S ? PV_P_SHIFT - lse[((int64_t)b * H + h) * S + q] : -INFINITY;
-    {
-        // (all rows of a thread are loaded before the first is used: one memory latency for the prologue instead of one per row)
-        constexpr int NR = (SP + NT / 8 - 1) / (NT / 8);
-        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int c = tid & 7;
-        u32x4 dvv[NR], ovv[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int row = i * (NT / 8) + (tid >> 3);
-            dvv[i] = (u32x4){0u, 0u, 0u, 0u};
-            ovv[i] = dvv[i];
-            if (row < S && c * 8 < DH) {
-                dvv[i] = *reinterpret_cast<const u32x4*>(ob + (int64_t)row * D + c * 8);
-                ovv[i] = *reinterpret_cast<const u32x4*>(ab + (int64_t)row * D + c * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int row = i * (NT / 8) + (tid >> 3);
-            float dsum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d0 = pv_unpack_lo(dvv[i][j]), d1 = pv_unpack_hi(dvv[i][j]);
-                dsum = fmaf(d0, pv_unpack_lo(ovv[i][j]), fmaf(d1, pv_unpack_hi(ovv[i][j]), dsum));
-                cs[2 * j] += d0;
-                cs[2 * j + 1] += d1;
-            }
-            dsum += __shfl_xor(dsum, 1, 64);
-            dsum += __shfl_xor(dsum, 2, 64);
-            dsum += __shfl_xor(dsum, 4, 64);
-            if (c == 0 && row < SP) st_d[row] = -dsum;
-        }
-        if (dbp) {             // lanes c, c + 8, .. c + 56 of a wave hold the same eight columns of eight different rows
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                cs[i] += __shfl_xor(cs[i], 8, 64);
-                cs[i] += __shfl_xor(cs[i], 16, 64);
-                cs[i] += __shfl_xor(cs[i], 32, 64);
-            }
-            if (lane < 8 && lane * 8 < DH) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) red_v[wid * DH + lane * 8 + i] = cs[i];
-            }
-        }
-    }
-    int foff[KS], toff[NDT];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
-    {
-        const int tq_ = i16 >> 2, tp_ = i16 & 3;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
-    }
-    auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
-        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * TB);
-    };
-    auto tfrag = [&](const char* X, int tile, int dt) __attribute__((always_inline)) {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(X + toff[dt] + tile * TB));
-    };
-    auto gfrag = [&](const uint16_t* X, int64_t ldx, int tile, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
-        int r = tile * 16 + i16;
-        r = r < S ? r : S - 1;
-        const uint16_t* rp = X + (int64_t)r * ldx;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int dcol = ks * 32 + 8 * g;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (dcol < DH) v = *reinterpret_cast<const u32x4*>(rp + dcol);
-            f[ks] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    const int nqt = (S + 15) >> 4;
-    bf16x8 qf[KS], of[KS];
-    if (wid < nqt) { gfrag(qb, ld, wid, qf); gfrag(ob, D, wid, of); }
-    PV_BSTAMP(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (dbp && tid < DH) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += red_v[w * DH + tid];
-        float* o = dbp + (int64_t)b * 3 * D + h * DH + tid;
-        o[D] = 0.f;                        // (see the header: the key third is identically zero)
-        o[2 * D] = t;
-    }
-
-    PV_BSTAMP(2);
-    // =============================== pass 1: dQ, streaming over pairs of key tiles (K | V in LDS) ===============================
-    {
-        f32x4 cq[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) cq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int qt = wid; qt < nqt; qt += NW) {
-            const int q0 = qt << 4;
-            // lane (g, i16) = four keys of query q0 + i16: the row statistics are one value each per lane
-            const float mq = st_m[q0 + i16] - PV_P_SHIFT, nd = st_d[q0 + i16];
-            f32x4 dq[NDT];
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            auto tile_ds = [&](int kt, bool masked) __attribute__((always_inline)) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {nd, nd, nd, nd};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    a = PV_MFMA_16x16x32(frag(A_, kt, ks), qf[ks], a, 0, 0, 0);
-                    c = PV_MFMA_16x16x32(frag(B_, kt, ks), of[ks], c, 0, 0, 0);
-                }
-                float ds[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(a[r], LOG2E, mq));
-                    if (masked) p = kt * 16 + 4 * g + r < S ? p : 0.f;          // (only the last tile holds padded keys)
-                    ds[r] = p * c[r];
-                }
-                return (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
-            };
-            auto pair = [&](int k0_, bool masked) __attribute__((always_inline)) {
-                const u32x2 d0 = tile_ds(k0_, false), d1 = tile_ds(k0_ + 1, masked);
-                const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const s16x8 kk = __builtin_shufflevector(tfrag(A_, k0_, dt), tfrag(A_, k0_ + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
-                    dq[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, kk), dsf, dq[dt], 0, 0, 0);
-                }
-            };
-            // (two pairs per trip where the trip count allows it; left to itself hipcc unrolls the odd counts completely and spills 30 - 180 registers)
-#pragma unroll((NKT - 1) / 2 % 2 == 0 && NKT >= 9 ? 2 : 1)
-            for (int tt = 0; tt < (NKT - 1) / 2; ++tt) pair(2 * tt, false);
-            if (NKT & 1) {
-                const s16x4 dsf = __builtin_bit_cast(s16x4, tile_ds(NKT - 1, true));
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(tfrag(A_, NKT - 1, dt), dsf, dq[dt], 0, 0, 0);
-            } else {
-                pair(NKT - 2, true);
-            }
-            const bool more = qt + NW < nqt;
-            if (more) { gfrag(qb, ld, qt + NW, qf); gfrag(ob, D, qt + NW, of); }
-            if (q0 + i16 < S) {
-                uint16_t* op = gb + (int64_t)(q0 + i16) * ld + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const u32x2 ov = {pv_pack_bf16x2(dq[dt][0] * qscale, dq[dt][1] * qscale), pv_pack_bf16x2(dq[dt][2] * qscale, dq[dt][3] * qscale)};
-                    *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
-                    cq[dt] += (f32x4){pv_unpack_lo(ov[0]), pv_unpack_hi(ov[0]), pv_unpack_lo(ov[1]), pv_unpack_hi(ov[1])};
-                }
-            }
-        }
-        if (dbp) {
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = pv_row16_sum(cq[dt][r]);
-                    if (i16 == 0) red_q[wid * DH + dt * 16 + 4 * g + r] = t;
-                }
-        }
-    }
-    PV_BSTAMP(3);
-    __syncthreads();                       // every wave has left pass 1: the K | V images are free
-    PV_BSTAMP(4);
-    if (dbp && tid < DH) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += red_q[w * DH + tid];
-        dbp[(int64_t)b * 3 * D + h * DH + tid] = t;
-    }
-
-    // =============================== phase 2: Q | dO images, pass 2 per unit of KPW key tiles (as pv_attn_bwd2_kernel) ===============================
-    stage(qb, ld, ob, D);
-    bf16x8 kf[KPW][KS], vf[KPW][KS];
-    auto load_unit = [&](int ku) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < KPW; ++t) {
-            const int kt = ku * KPW + t, ktc = kt < NKT ? kt : NKT - 1;
-            gfrag(qb + D, ld, ktc, kf[t]);
-            gfrag(qb + 2 * D, ld, ktc, vf[t]);
-        }
-    };
-    if (wid * KPW < nqt) load_unit(wid);
-    PV_BSTAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    PV_BSTAMP(6);
-    for (int ku = wid; ku * KPW < nqt; ku += NW) {
-        f32x4 dv[KPW][NDT], dk[KPW][NDT];
-#pragma unroll
-        for (int t = 0; t < KPW; ++t)
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) { dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[t][dt] = dv[t][dt]; }
-        // lane (g, i16) = key i16 of the tile, queries 4g .. 4g + 3.  No key mask: a padded key (a duplicate of key S - 1) only feeds its own dK / dV
-        // rows, which are not stored; a padded query has st_m = -inf -> p = 0.
-        auto pds = [&](int qt, u32x2 (&pw)[KPW], u32x2 (&dw)[KPW]) __attribute__((always_inline)) {
-            bf16x8 qq_[KS], oo_[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { qq_[ks] = frag(A_, qt, ks); oo_[ks] = frag(B_, qt, ks); }
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + qt * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(st_d + qt * 16 + 4 * g);
-#pragma unroll
-            for (int t = 0; t < KPW; ++t) {
-                f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, c = d4;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    s_ = PV_MFMA_16x16x32(qq_[ks], kf[t][ks], s_, 0, 0, 0);
-                    c = PV_MFMA_16x16x32(oo_[ks], vf[t][ks], c, 0, 0, 0);
-                }
-                float p[4], ds[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(fmaf(s_[r], LOG2E, m4[r]));          // p 2^PV_P_SHIFT
-#ifdef PV_OPERAND_F16
-                    ds[r] = p[r] * (c[r] * PV_P_UNSHIFT);
-#else
-                    ds[r] = p[r] * c[r];
-#endif
-                }
-                pw[t] = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
-                dw[t] = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
-            }
-        };
-#pragma unroll 1
-        for (int tt = 0; tt < NKT / 2; ++tt) {
-            u32x2 p0[KPW], d0[KPW], p1[KPW], d1[KPW];
-            pds(2 * tt, p0, d0);
-            pds(2 * tt + 1, p1, d1);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const s16x8 oo = __builtin_shufflevector(tfrag(B_, 2 * tt, dt), tfrag(B_, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
-                const s16x8 qq = __builtin_shufflevector(tfrag(A_, 2 * tt, dt), tfrag(A_, 2 * tt + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int t = 0; t < KPW; ++t) {
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[t][0], p0[t][1], p1[t][0], p1[t][1]});
-                    const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[t][0], d0[t][1], d1[t][0], d1[t][1]});
-                    dv[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, oo), pf, dv[t][dt], 0, 0, 0);
-                    dk[t][dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, qq), dsf, dk[t][dt], 0, 0, 0);
-                }
-            }
-        }
-        if (NKT & 1) {
-            u32x2 pw[KPW], dw[KPW];
-            pds(NKT - 1, pw, dw);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const s16x4 oo = tfrag(B_, NKT - 1, dt), qq = tfrag(A_, NKT - 1, dt);
-#pragma unroll
-                for (int t = 0; t < KPW; ++t) {
-                    dv[t][dt] = PV_MFMA_16x16x16(oo, __builtin_bit_cast(s16x4, pw[t]), dv[t][dt], 0, 0, 0);
-                    dk[t][dt] = PV_MFMA_16x16x16(qq, __builtin_bit_cast(s16x4, dw[t]), dk[t][dt], 0, 0, 0);
-                }
-            }
-        }
-        const int ku_now = ku;
-        if ((ku + NW) * KPW < nqt) load_unit(ku + NW);
-#pragma unroll
-        for (int t = 0; t < KPW; ++t) {
-            const int key = (ku_now * KPW + t) * 16 + i16;
-            if (key < S) {
-                uint16_t* op = gb + (int64_t)key * ld + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-#ifdef PV_OPERAND_F16
-                    dv[t][dt] = dv[t][dt] * PV_P_UNSHIFT;
-#endif
-                    *reinterpret_cast<u32x2*>(op + D + dt * 16) = (u32x2){pv_pack_bf16x2(dk[t][dt][0], dk[t][dt][1]), pv_pack_bf16x2(dk[t][dt][2], dk[t][dt][3])};
-                    *reinterpret_cast<u32x2*>(op + 2 * D + dt * 16) = (u32x2){pv_pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pv_pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
-                }
-            }
-        }
-    }
-    PV_BSTAMP(7);
-}
-
-#ifndef PV_ABW4_KPW
-#define PV_ABW4_KPW 1
-#endif
-template <int DH, int NKT>
-static int pv_launch_attn_bwd4(const uint16_t* qkv, const uint16_t* dout, const uint16_t* att, const float* lse, uint16_t* dqkv, float* dbp, int64_t B, int S, int H,
-                               float qscale, hipStream_t stream) {
-    constexpr int DHP = (DH + 31) / 32 * 32;
-    constexpr int lds = 2 * NKT * 16 * DHP * 2 + 2 * NKT * 16 * 4 + 2 * PV_ABW4_NW * DH * 4;
-    static PvPerDevice attr_set;
-    if (attr_set.first_use()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd4_kernel<DH, NKT, PV_ABW4_KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
-    PV_LAUNCH((pv_attn_bwd4_kernel<DH, NKT, PV_ABW4_KPW>), dim3((unsigned)(B * H)), dim3(PV_ABW4_NW * 64), lds, stream, qkv, dout, att, lse, dqkv, dbp, S, H, qscale, (int)B);
-    return pv_check_launch();
-}
-
-template <int DH>
-static int pv_dispatch_attn_bwd4(const uint16_t* qkv, const uint16_t* dout, const uint16_t* att, const float* lse, uint16_t* dqkv, float* dbp, int64_t B, int S,
-                                 int H, float qscale, hipStream_t s) {
-    switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd4<DH, N>(qkv, dout, att, lse, dqkv, dbp, B, S, H, qscale, s);
-        PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
-        PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
-#undef PV_ATTN_CASE
-        default: break;
-    }
-    if constexpr (DH == 32) {
-        switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd4<DH, N>(qkv, dout, att, lse, dqkv, dbp, B, S, H, qscale, s);
-            PV_ATTN_CASE(14) PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20)
-            PV_ATTN_CASE(21) PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
-#undef PV_ATTN_CASE
-            default: break;
-        }
-    }
-    return PV_ERR_UNSUPPORTED;
-}
-
-extern "C" int pv_attention_bwd_lse_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, uint16_t* dqkv,
-                                         float* dbias_partial, int64_t B, int64_t S, int64_t H, int64_t dh, float qscale, void* stream) {
-    if (!qkv || !dout || !out || !lse || !dqkv || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dqkv & 15) || ((uintptr_t)lse & 3)) return PV_ERR_INVALID_ARG;
-    if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    switch (dh) {          // S <= 208 at dh = 48 / 64, S <= 416 at dh = 32
-        case 32: return pv_dispatch_attn_bwd4<32>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
-        case 48: return pv_dispatch_attn_bwd4<48>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
-        case 64: return pv_dispatch_attn_bwd4<64>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
-        default: return PV_ERR_UNSUPPORTED;
-    }
-}
-
 template <int DH>
 static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t s) {
     switch ((S + 15) / 16) {
@@ -2184,19 +1778,6 @@ extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B
         case 32: return pv_dispatch_attn_f32<32>(qkv, out, B, (int)S, (int)H, s);
         case 48: return pv_dispatch_attn_f32<48>(qkv, out, B, (int)S, (int)H, s);
         case 64: return pv_dispatch_attn_f32<64>(qkv, out, B, (int)S, (int)H, s);
-        default: return PV_ERR_UNSUPPORTED;
-    }
-}
-
-extern "C" int pv_attention_lse_bf16(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag, void* stream) {
-    if (!qkv || !out || !lse || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)lse & 3) || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
-    if (B * H > 0x7fffffff || S > 416) return PV_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    switch (dh) {
-        case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
-        case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
-        case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
         default: return PV_ERR_UNSUPPORTED;
     }
 }
