@@ -17,7 +17,7 @@ libs = {"shipped": C.CDLL(_build.LIB_F16), "operands in L2": C.CDLL(os.path.join
 for lib in libs.values():
     lib.pv_attention_bf16.argtypes = [P, P] + [I] * 4 + [P, P]
     lib.pv_attention_bwd_bf16.argtypes = [P] * 4 + [I] * 4 + [F, P]
-for H, dh, B, S in ((12, 64, 2048, 197), (6, 64, 512, 197), (12, 64, 2048, 99), (12, 64, 2048, 50)):
+for H, dh, B, S in ((12, 64, 2048, 197), (8, 48, 512, 197), (6, 64, 512, 197), (3, 64, 512, 197), (12, 64, 2048, 99), (12, 64, 2048, 50)):
     D = H * dh
     qkv = (torch.randn(B, S, 3 * D, device=dev) * 0.7).to(torch.float16)
     dout = (torch.randn(B, S, D, device=dev) * 0.1).to(torch.float16)
