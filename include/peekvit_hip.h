@@ -296,6 +296,19 @@ int pv_scatter_tokens(const float* dy, const int32_t* keep, float* dx, int64_t B
  * in-proj bias gradient.  dh in {32, 48, 64}; S <= 208 (S <= 416 at dh = 32): Q, K, V and dO of one head live in the LDS. */
 int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbias_partial, int64_t B, int64_t S,
                           int64_t H, int64_t dh, float qscale, void* stream);
+/* The same backward as ONE persistent workgroup per CU that walks over its (image, head) items, from the forward's row statistics (ABI v9; the
+ * training path's choice where it applies):
+ *   pv_attention_lse_bf16     = pv_attention_bf16 that also writes lse fp32 [B,H,S] = log2(sum_k exp(s[q,k])) (base-2 log-sum-exp of the scaled scores);
+ *                               S <= 416 (the resident-K/V kernel), PV_ERR_UNSUPPORTED beyond.
+ *   pv_attention_bwd_lse_bf16 : `out` = the forward's 16-bit output [B,S,D], `lse` as above.  p = exp2(s log2(e) - lse) and D = rowsum(dO o out) replace the
+ *                               recomputed row maximum / sum / sum(P o dP); K | V of the next item land while pass 2 of this one runs, every operand is fetched
+ *                               once.  dbias_partial as above, in closed form where there is one: the key third is identically 0 (softmax is invariant under a
+ *                               shift of all keys; autograd returns rounding noise there), the value third is the per-image column sums of dout (rows of this
+ *                               head), the query third the column sums of the stored dQ.  dh in {48, 64}, 113 <= S <= 208; PV_ERR_UNSUPPORTED otherwise. */
+int pv_attention_lse_bf16(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag,
+                          void* stream);
+int pv_attention_bwd_lse_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, uint16_t* dqkv,
+                              float* dbias_partial, int64_t B, int64_t S, int64_t H, int64_t dh, float qscale, void* stream);
 
 /* Final LayerNorm on the class-token rows only + sum over class tokens:
  *   models/vit.py:95 `self.ln(input)` restricted to the rows models/vit.py:242-243 consume.

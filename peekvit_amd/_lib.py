@@ -71,6 +71,8 @@ SIGNATURES = {
     "pv_colsum_f32": (C.c_int, [_p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p]),
     "pv_scatter_tokens": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_attention_bwd_bf16": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
+    "pv_attention_lse_bf16": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "pv_attention_bwd_lse_bf16": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p]),
     "pv_token_prologue": (C.c_int, [_p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p]),
     "pv_layernorm_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f32, _p]),
     "pv_operand_type": (C.c_int, []),
@@ -90,7 +92,7 @@ SIGNATURES = {
     "pv_residual_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lock = threading.Lock()
 _libs: dict = {}
 

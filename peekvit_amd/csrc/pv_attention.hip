@@ -9,6 +9,7 @@
 // in a permuted-but-consistent k order (key slot j of lane group g: j<4 -> key 32t+4g+j, j>=4 -> key 32t+16+4g+j-4).
 // LDS images are XOR-swizzled per 128-byte line (chunk ^ (line & 7)): conflict-free for both read kinds.
 #include "pv_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -54,8 +55,17 @@ extern "C" void pv_debug_set_attn_stamp_buffer(void* p) { (void)hipMemcpyToSymbo
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         if ((threadIdx.x & 63) == 0 && d_pv_adbg) d_pv_adbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = t_;   \
     } while (0)
+#define PV_CSTAMP(i)       /* sixteen-wave persistent kernel (pv_attn_bwd5_kernel; scripts/stamp_attn_bwd5.py): the last-but-one item of every workgroup */  \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        unsigned long long t_;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((threadIdx.x & 63) == 0 && d_pv_adbg && pv_stamp_on) d_pv_adbg[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (i)] = t_;   \
+    } while (0)
 #else
 #define PV_ASTAMP(i)
+#define PV_CSTAMP(i)
 #endif
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
@@ -78,7 +88,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #define PV_ATTN_NW 4         // waves per workgroup of pv_attn_kernel (A/B: 8 waves x 2 workgroups per CU instead of 4 x 3; scripts/attn_ab.py)
 #endif
 template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
-__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B) {
+__global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B, float* __restrict__ lse) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
     constexpr int KS = DHP / 32;        // k-steps of the QK^T product
@@ -252,6 +262,10 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
         }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        // training forward (round 5): the row's log-sum-exp in the exp2 domain, m log2(e) + log2(sum exp(s - m)): the persistent backward kernel
+        // (pv_attn_bwd5_kernel) forms p = exp2(s log2(e) - lse) without the row maximum and sum.  (l carries 2^PV_P_SHIFT in the fp16 build.)
+        if (lse != nullptr && g == 0 && q0 + i16 < S)
+            lse[((int64_t)b * H + h) * S + q0 + i16] = m * 1.44269504088896340736f + (__builtin_amdgcn_logf(l) - PV_P_SHIFT);
         if (!v_ready) {            // first tile of the wave: V must have landed (for every wave) before the first PV product
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -303,14 +317,14 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
 }
 
 template <int DH, int NKT>
-static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
+static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse = nullptr) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int lds = 2 * NKT * 16 * DHP * 2;
     static PvPerDevice attr_set;
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B);
+    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B, lse);
     return pv_check_launch();
 }
 
@@ -441,15 +455,15 @@ static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, 
 }
 
 template <int DH>
-static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream) {
+static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse = nullptr) {
     switch ((S + 15) / 16) {
-#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream);
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream, lse);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)
         PV_ATTN_CASE(8) PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13) PV_ATTN_CASE(14)
         PV_ATTN_CASE(15) PV_ATTN_CASE(16) PV_ATTN_CASE(17) PV_ATTN_CASE(18) PV_ATTN_CASE(19) PV_ATTN_CASE(20) PV_ATTN_CASE(21)
         PV_ATTN_CASE(22) PV_ATTN_CASE(23) PV_ATTN_CASE(24) PV_ATTN_CASE(25) PV_ATTN_CASE(26)
 #undef PV_ATTN_CASE
-        default: return pv_launch_attn_stream<DH>(qkv, out, B, S, H, flag, stream);
+        default: return lse ? PV_ERR_UNSUPPORTED : pv_launch_attn_stream<DH>(qkv, out, B, S, H, flag, stream);      // (the streaming kernel keeps no statistics)
     }
 }
 
@@ -1472,6 +1486,551 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
     return pv_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent attention backward from the forward's row statistics (round 5, `pv_attn_bwd5_kernel`, entry pv_attention_bwd_lse_bf16).
+// What the measurements on the two-pass kernels above say (profiles/r05_attn_bwd4_experiment.txt): their arithmetic fills half of the SIMD
+// cycles, their traffic half of the HBM time, and 58 % of the wave cycles are spent waiting - load and compute ALTERNATE inside a workgroup,
+// two workgroups are all the LDS holds, and every buffer has an owner that idles while it fills; operands are fetched twice (as LDS images
+// for one pass, as register fragments for the other).  Here ONE workgroup of 16 waves per CU walks over its (image, head) items:
+//   * wave w < ceil(S / 16) owns query tile w in pass 1 and key tile w in pass 2 (one tile each: no tile switch, no prefetch registers);
+//   * pass 1 streams over key-tile pairs with p = exp2(s log2e - lse), dS = p (dP - D) (lse from the forward, the dP accumulator starts
+//     at -D): two score tiles live, < 128 registers, four waves per SIMD;
+//   * K | V of item j sit in buffer X for pass 1 while Q | dO of item j land in buffer Y; the wave's own K / V fragments for pass 2 are
+//     read from X as pass 1 ends, so X is free for K | V of item j + 1 while pass 2 runs on Y: every LDS-DMA has a whole pass to land,
+//     every operand byte is fetched once;
+//   * the three waves without a tile do the item's side work while the others compute: D = rowsum(dO o O) and lse -> LDS for the NEXT
+//     item (pass 2), the bias-gradient column sums (query third: the stored dQ tiles transposed through a private LDS scratch and summed
+//     by an MFMA against ones; key third: 0 identically - sum_k dS[q,k] = D - D; value third: column sums of dO by MFMAs over the image).
+// Two raw barriers per item; counted vmcnt waits (loads, stores and LDS-DMA retire in issue order).  No atomics: bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+#ifdef PV_OPERAND_F16
+#define PV_ONE16 0x3C00
+#else
+#define PV_ONE16 0x3F80
+#endif
+template <int DH, int NKT>
+__global__ __launch_bounds__(1024) void pv_attn_bwd5_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const uint16_t* __restrict__ att,
+                                                            const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ dbp, int S, int H,
+                                                            float qscale, int B, int n_items) {
+    constexpr int NW = 16, NT = NW * 64;
+    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;
+    constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32;
+    constexpr int NCH = SP * CPR, NIT = (NCH + NT - 1) / NT;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    static_assert(CPR == 8, "row images of 128 bytes (dh = 48 / 64)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const X0 = smem;                 // K
+    char* const X1 = smem + IMG;           // V
+    char* const Y0 = smem + 2 * IMG;       // Q
+    char* const Y1 = smem + 3 * IMG;       // dO
+    float* const st = reinterpret_cast<float*>(smem + 4 * IMG);         // [2 parities][m | d][SP]: PV_P_SHIFT - lse (-inf: padded query), -D
+    float* const red_q = st + 4 * SP;                                     // [NW][DH] column sums of the dQ tiles
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const scr = reinterpret_cast<char*>(red_q + NW * DH) + wid * TB;    // this wave's 16 x DHP scratch tile (dQ, transposed read)
+    const int D = H * DH;
+    const int64_t ld = 3 * (int64_t)D;
+    const int nqt = (S + 15) >> 4;
+    const bool tile_wave = wid < nqt;
+    // Everything that depends on the lane alone is recomputed at the top of every item from an opaque copy of the thread index: left loop-invariant,
+    // hipcc hoists ~40 such offsets and masks out of the item loop, spills them, and reloads them under the LDS-DMA (= s_waitcnt vmcnt(0) in pass 1).
+    int lane, g, i16, foff[KS], toff[NDT];
+    unsigned off3[NIT], off1[NIT];         // per-lane BYTE offsets of the staged rows for the two row strides (q | k | v rows: 3D elements, dO rows: D)
+    auto relane = [&]() __attribute__((always_inline)) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        lane = t & 63;
+        g = lane >> 4;
+        i16 = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
+        const int tq_ = i16 >> 2, tp_ = i16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
+        const int lsw = (t & 7) ^ ((t >> 3) & 7);
+        const int c_lane = lsw * 8 >= DH ? 0 : lsw;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int row = i * (NT / CPR) + (t >> 3);
+            row = row < S ? row : S - 1;
+            off3[i] = (unsigned)(row * 3 * D + c_lane * 8) * 2u;
+            off1[i] = (unsigned)(row * D + c_lane * 8) * 2u;
+        }
+    };
+    relane();
+    auto stage = [&](char* d0, char* d1, const uint16_t* a, bool a3, const uint16_t* bsrc, bool b3) __attribute__((always_inline)) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                if (NCH % NT == 0 || i * NT + wid * 64 < NCH) {
+                    const char* src = reinterpret_cast<const char*>(which ? bsrc : a) + ((which ? b3 : a3) ? off3[i] : off1[i]);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)((which ? d1 : d0) + (size_t)(i * NT + wid * 64) * 16), 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * TB);
+    };
+    // transposed reads as inline asm: hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of every ds_read_tr BUILTIN while an LDS-DMA is in flight (it
+    // cannot see that the image being filled is not the one being read) - which would park pass 1 until Q | dO have landed.  trN reads NDT fragments of one
+    // tile (tr2N: of two consecutive tiles, joined for the K = 32 MFMA); the s_waitcnt that follows names them as operands, so every consumer depends on it.
+    typedef __attribute__((address_space(3))) char lds_c;
+    auto tr_issue = [&](const char* X, int tile, s16x4 (&f)[NDT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt]) : "v"((lds_c*)(X + toff[dt] + tile * TB)));
+    };
+    // ... and so are the plain fragment reads of the two passes: any LDS read hipcc can see after an LDS-DMA was issued waits for that DMA (its wait-count
+    // pass has no alias information to tell the image being filled from the one being read).
+    auto fr_issue = [&](const char* X, int tile, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(f[ks]) : "v"((lds_c*)(X + foff[ks] + tile * TB)));
+    };
+    // the same with the tile and image offsets as INSTRUCTION immediates: `base[ks]` = image 0 + foff[ks] + (first tile of the loop trip) * TB, one add per trip
+    auto fr_issue_i = [&](lds_c* const (&base)[KS], auto off_c, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
+        constexpr int OFF = decltype(off_c)::value;
+        static_assert(OFF >= 0 && OFF < 65536, "DS offset field");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[ks]) : "v"(base[ks]), "n"(OFF));
+    };
+    auto tr_issue_i = [&](lds_c* const (&base)[NDT], auto off_c, s16x4 (&f)[NDT]) __attribute__((always_inline)) {
+        constexpr int OFF = decltype(off_c)::value;
+        static_assert(OFF >= 0 && OFF < 65536, "DS offset field");
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[dt]) : "v"(base[dt]), "n"(OFF));
+    };
+    auto fr_wait = [&](bf16x8 (&f)[KS]) __attribute__((always_inline)) {
+        if constexpr (KS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0])::"memory");
+    };
+    auto tr_wait = [&](s16x4 (&f)[NDT]) __attribute__((always_inline)) {
+        if constexpr (NDT == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2])::"memory");
+    };
+    // global addresses are a uniform base + a 32-bit per-lane byte offset throughout (64-bit per-lane pointers kept across the item loop cost two registers each)
+    auto gfrag = [&](const uint16_t* Xg, int ldx, int tile, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
+        int r = tile * 16 + i16;
+        r = r < S ? r : S - 1;
+        const unsigned o = (unsigned)(r * ldx + 8 * g) * 2u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ks * 32 + 8 * g < DH) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Xg) + o + ks * 64);
+            f[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    int it = blockIdx.x, par = 0;
+    bf16x8 qf[KS], of[KS], af[KS];       // this wave's rows of Q, dO and of the forward's output O (for D = rowsum(dO o O)), prefetched one item ahead
+    float lse_v = 0.f;                   // lse of query wid * 16 + i16
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { qf[ks] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u}); of[ks] = qf[ks]; af[ks] = qf[ks]; }
+    auto own_rows = [&](int bn, int hn) __attribute__((always_inline)) {
+        gfrag(qkv + (int64_t)bn * S * ld + hn * DH, 3 * D, wid, qf);
+        gfrag(dout + (int64_t)bn * S * D + hn * DH, D, wid, of);
+        gfrag(att + (int64_t)bn * S * D + hn * DH, D, wid, af);
+        int r = wid * 16 + i16;
+        r = r < S ? r : S - 1;
+        lse_v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lse + ((int64_t)bn * H + hn) * S) + (unsigned)r * 4u);
+    };
+    {
+        int b, h;
+        pv_bh_map(it, B, H, b, h);
+        const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
+        stage(X0, X1, qb + D, true, qb + 2 * D, true);
+        if (tile_wave) own_rows(b, h);
+    }
+
+    for (;;) {
+        relane();
+#ifdef PV_STAMPS
+        const bool pv_stamp_on = it + (int)gridDim.x < n_items;          // (a steady-state item: the last one has no side work for a successor)
+#endif
+        int b, h;
+        pv_bh_map(it, B, H, b, h);
+        const uint16_t* const qb = qkv + (int64_t)b * S * ld + h * DH;
+        const uint16_t* const ob = dout + (int64_t)b * S * D + h * DH;
+        uint16_t* const gb = dqkv + (int64_t)b * S * ld + h * DH;
+        // ---- [A] K | V of this item, this wave's fragments and (LDS) the row statistics are in place ----
+        PV_CSTAMP(0);
+        // hipcc's own wait for the prefetched fragments goes HERE, on every path (its wait-count pass is path-insensitive: pinned under `if (tile_wave)` only,
+        // the fragments still count as in flight where pass 1 first uses them, and the wait it puts there - vmcnt(0) - would hold pass 1 until Q | dO have landed)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(of[ks]), "+v"(af[ks]));
+        asm volatile("" : "+v"(lse_v));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        float* const sm = st + par * 2 * SP;
+        float* const sd = sm + SP;
+        float mq = 0.f, nd = 0.f;
+        if (tile_wave) {
+            // this tile's row statistics: D = rowsum(dO o O) over the lane's 16 columns, then over the four lanes of the query; to LDS for pass 2 of every wave
+            float dsum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 dv_ = __builtin_bit_cast(u32x4, of[ks]), ov_ = __builtin_bit_cast(u32x4, af[ks]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dsum = fmaf(pv_unpack_lo(dv_[j]), pv_unpack_lo(ov_[j]), fmaf(pv_unpack_hi(dv_[j]), pv_unpack_hi(ov_[j]), dsum));
+            }
+            dsum += __shfl_xor(dsum, 16, 64);
+            dsum += __shfl_xor(dsum, 32, 64);
+            const bool okq = wid * 16 + i16 < S;
+            mq = okq ? -lse_v : -INFINITY;
+            nd = okq ? -dsum : 0.f;
+            if (g == 0) { sm[wid * 16 + i16] = mq + PV_P_SHIFT; sd[wid * 16 + i16] = nd; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PV_CSTAMP(1);
+        __builtin_amdgcn_s_barrier();
+        PV_CSTAMP(2);
+        stage(Y0, Y1, qb, true, ob, false);                  // Q | dO land while pass 1 runs
+        bf16x8 kf[KS], vf[KS];
+        // =============================== pass 1: dQ of query tile `wid`, streaming over pairs of key tiles (K | V in X) ===============================
+        if (tile_wave) {
+            const int q0 = wid << 4;
+            f32x4 dq[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto tile_ds = [&](const bf16x8 (&kx)[KS], const bf16x8 (&vx)[KS], int kt, bool masked) __attribute__((always_inline)) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {nd, nd, nd, nd};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    a = PV_MFMA_16x16x32(kx[ks], qf[ks], a, 0, 0, 0);
+                    c = PV_MFMA_16x16x32(vx[ks], of[ks], c, 0, 0, 0);
+                }
+                float ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(a[r], LOG2E, mq));
+                    if (masked) p = kt * 16 + 4 * g + r < S ? p : 0.f;          // (only the last tile holds padded keys)
+                    ds[r] = p * c[r];
+                }
+                return (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+            };
+            auto pair = [&](int k0_, bool masked) __attribute__((always_inline)) {
+                bf16x8 k0f[KS], v0f[KS], k1f[KS], v1f[KS];
+                s16x4 ka[NDT], kb[NDT];
+                lds_c* fb[KS];
+                lds_c* tb[NDT];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fb[ks] = (lds_c*)(X0 + foff[ks] + k0_ * TB);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) tb[dt] = (lds_c*)(X0 + toff[dt] + k0_ * TB);
+                fr_issue_i(fb, std::integral_constant<int, 0>{}, k0f);
+                fr_issue_i(fb, std::integral_constant<int, IMG>{}, v0f);
+                fr_issue_i(fb, std::integral_constant<int, TB>{}, k1f);
+                fr_issue_i(fb, std::integral_constant<int, IMG + TB>{}, v1f);
+                tr_issue_i(tb, std::integral_constant<int, 0>{}, ka);
+                tr_issue_i(tb, std::integral_constant<int, TB>{}, kb);
+                fr_wait(k0f); fr_wait(v0f); fr_wait(k1f); fr_wait(v1f);
+                const u32x2 d0 = tile_ds(k0f, v0f, k0_, false), d1 = tile_ds(k1f, v1f, k0_ + 1, masked);
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
+                tr_wait(ka);
+                tr_wait(kb);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const s16x8 kk = __builtin_shufflevector(ka[dt], kb[dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dq[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, kk), dsf, dq[dt], 0, 0, 0);
+                }
+            };
+#pragma unroll 1
+            for (int tt = 0; tt < (NKT - 1) / 2; ++tt) pair(2 * tt, false);
+            if (NKT & 1) {
+                bf16x8 k0f[KS], v0f[KS];
+                s16x4 ka[NDT];
+                fr_issue(X0, NKT - 1, k0f);
+                fr_issue(X1, NKT - 1, v0f);
+                tr_issue(X0, NKT - 1, ka);
+                fr_wait(k0f); fr_wait(v0f);
+                const s16x4 dsf = __builtin_bit_cast(s16x4, tile_ds(k0f, v0f, NKT - 1, true));
+                tr_wait(ka);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dq[dt] = PV_MFMA_16x16x16(ka[dt], dsf, dq[dt], 0, 0, 0);
+            } else {
+                pair(NKT - 2, true);
+            }
+            const bool okq = q0 + i16 < S;
+            char* const op = reinterpret_cast<char*>(gb) + (unsigned)((q0 + i16) * 3 * D + 4 * g) * 2u;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const u32x2 ov = {pv_pack_bf16x2(dq[dt][0] * qscale, dq[dt][1] * qscale), pv_pack_bf16x2(dq[dt][2] * qscale, dq[dt][3] * qscale)};
+                if (okq) *reinterpret_cast<u32x2*>(op + dt * 32) = ov;
+                if (dbp) *reinterpret_cast<u32x2*>(scr + pv_swz<CPR>(i16, dt * 2 + (g >> 1)) + ((g & 1) << 3)) = okq ? ov : (u32x2){0u, 0u};
+            }
+            // this wave's K / V fragments for pass 2, from the images that pass 1 is done with
+            fr_issue(X0, wid, kf);
+            fr_issue(X1, wid, vf);
+            fr_wait(kf); fr_wait(vf);
+            if (DH % 32 != 0 && 32 * (KS - 1) + 8 * g >= DH) {         // dh = 48: the images' pad columns hold copies of chunk 0, and pass 2 multiplies these fragments with image rows
+                kf[KS - 1] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                vf[KS - 1] = kf[KS - 1];
+            }
+            if (dbp) {             // column sums of the stored dQ tile: its transpose against ones
+                const s16x4 ones = {(short)PV_ONE16, (short)PV_ONE16, (short)PV_ONE16, (short)PV_ONE16};
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the scratch tile is written (LDS operations of a wave execute in order; the read below is asm)
+                s16x4 sa[NDT];
+                tr_issue(scr, 0, sa);
+                tr_wait(sa);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f32x4 t = PV_MFMA_16x16x16(sa[dt], ones, ((f32x4){0.f, 0.f, 0.f, 0.f}), 0, 0, 0);
+                    if (i16 == 0) *reinterpret_cast<f32x4*>(red_q + wid * DH + dt * 16 + 4 * g) = t;
+                }
+            }
+        }
+        PV_CSTAMP(3);
+        // ---- [E] Q | dO landed (issued before this wave's NDT stores of dQ), every wave is done with X ----
+        if (tile_wave) {
+            if (NDT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        PV_CSTAMP(4);
+        __builtin_amdgcn_s_barrier();
+        PV_CSTAMP(5);
+        const int itn = it + gridDim.x;
+        const bool more = itn < n_items;
+        int bn = b, hn = h;
+        if (more) pv_bh_map(itn, B, H, bn, hn);
+        const uint16_t* const qbn = qkv + (int64_t)bn * S * ld + hn * DH;
+        const uint16_t* const obn = dout + (int64_t)bn * S * D + hn * DH;
+        if (more) {
+            stage(X0, X1, qbn + D, true, qbn + 2 * D, true);      // K | V of the next item land while pass 2 runs
+            if (tile_wave) {
+                // this wave's Q / dO rows of the next item: pass 2 has no 16 registers to hold them, so they are only TOUCHED here (one dword per 128-byte
+                // line, result discarded: the lines come to the L2) and loaded where the pass-2 loop ends, from the L2
+                int r = wid * 16 + i16;
+                r = r < S ? r : S - 1;
+                // (as LDS-DMA into this wave's scratch tile, which is idle in pass 2: an inline-asm load into a register returns LATE, and a register hipcc
+                //  believes dead - it spilled the three touch destinations at once - is reused while the load is still in flight)
+                typedef const __attribute__((address_space(1))) void* gptr;
+                typedef __attribute__((address_space(3))) void* lptr;
+                __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(qbn) + (unsigned)(r * 3 * D + g * 16) * 2u), (lptr)(scr), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(obn) + (unsigned)(r * D + g * 16) * 2u), (lptr)(scr + 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(att + (int64_t)bn * S * D + hn * DH) + (unsigned)(r * D + g * 16) * 2u),
+                                                 (lptr)(scr + 512), 4, 0, 0);
+            }
+        }
+        if (tile_wave) {
+            // =============================== pass 2: dK, dV of key tile `wid` over all query tiles (Q | dO in Y) ===============================
+            f32x4 dv[NDT], dk[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = dv[dt]; }
+            // lane (g, i16) = key i16 of the tile, queries 4g .. 4g + 3.  No key mask: a padded key (a duplicate of key S - 1) only feeds its own dK / dV
+            // rows, which are not stored; a padded query has st_m = -inf -> p = 0.
+            // (fb / sb: Y0 + foff + qt0 * TB and the statistics row of query tile qt0; OFF_T = 0 or TB: the tile of the pair)
+            auto pds = [&](lds_c* const (&fb)[KS], lds_c* sb, auto off_t, u32x2& pw, u32x2& dw) __attribute__((always_inline)) {
+                constexpr int OFF_T = decltype(off_t)::value;
+                bf16x8 qx[KS], ox[KS];
+                f32x4 c, m4;
+                fr_issue_i(fb, std::integral_constant<int, OFF_T>{}, qx);
+                fr_issue_i(fb, std::integral_constant<int, IMG + OFF_T>{}, ox);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c) : "v"(sb), "n"(SP * 4 + (OFF_T ? 64 : 0)));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m4) : "v"(sb), "n"(OFF_T ? 64 : 0));
+                fr_wait(qx); fr_wait(ox);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(m4)::"memory");
+                f32x4 s_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s_ = PV_MFMA_16x16x32(qx[ks], kf[ks], s_, 0, 0, 0);
+                    c = PV_MFMA_16x16x32(ox[ks], vf[ks], c, 0, 0, 0);
+                }
+                float p[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(fmaf(s_[r], LOG2E, m4[r]));          // p 2^PV_P_SHIFT
+#ifdef PV_OPERAND_F16
+                    ds[r] = p[r] * (c[r] * PV_P_UNSHIFT);
+#else
+                    ds[r] = p[r] * c[r];
+#endif
+                }
+                pw = (u32x2){pv_pack_bf16x2(p[0], p[1]), pv_pack_bf16x2(p[2], p[3])};
+                dw = (u32x2){pv_pack_bf16x2(ds[0], ds[1]), pv_pack_bf16x2(ds[2], ds[3])};
+            };
+#pragma unroll 1
+            for (int tt = 0; tt < NKT / 2; ++tt) {
+                u32x2 p0, d0, p1, d1;
+                lds_c* fb[KS];
+                lds_c* tb[NDT];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fb[ks] = (lds_c*)(Y0 + foff[ks] + 2 * tt * TB);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) tb[dt] = (lds_c*)(Y0 + toff[dt] + 2 * tt * TB);
+                lds_c* const sb = (lds_c*)reinterpret_cast<const char*>(sm + 2 * tt * 16 + 4 * g);
+                pds(fb, sb, std::integral_constant<int, 0>{}, p0, d0);
+                pds(fb, sb, std::integral_constant<int, TB>{}, p1, d1);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){p0[0], p0[1], p1[0], p1[1]});
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
+                {
+                    s16x4 oa[NDT], ob_[NDT];
+                    tr_issue_i(tb, std::integral_constant<int, IMG>{}, oa);
+                    tr_issue_i(tb, std::integral_constant<int, IMG + TB>{}, ob_);
+                    tr_wait(oa);
+                    tr_wait(ob_);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+                        dv[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(oa[dt], ob_[dt], 0, 1, 2, 3, 4, 5, 6, 7)), pf, dv[dt], 0, 0, 0);
+                }
+                {
+                    s16x4 qa[NDT], qb_[NDT];
+                    tr_issue_i(tb, std::integral_constant<int, 0>{}, qa);
+                    tr_issue_i(tb, std::integral_constant<int, TB>{}, qb_);
+                    tr_wait(qa);
+                    tr_wait(qb_);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+                        dk[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(qa[dt], qb_[dt], 0, 1, 2, 3, 4, 5, 6, 7)), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+            if (NKT & 1) {
+                u32x2 pw, dw;
+                lds_c* fb[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fb[ks] = (lds_c*)(Y0 + foff[ks] + (NKT - 1) * TB);
+                pds(fb, (lds_c*)reinterpret_cast<const char*>(sm + (NKT - 1) * 16 + 4 * g), std::integral_constant<int, 0>{}, pw, dw);
+                s16x4 oa[NDT], qa[NDT];
+                tr_issue(Y1, NKT - 1, oa);
+                tr_issue(Y0, NKT - 1, qa);
+                tr_wait(oa);
+                tr_wait(qa);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    dv[dt] = PV_MFMA_16x16x16(oa[dt], __builtin_bit_cast(s16x4, pw), dv[dt], 0, 0, 0);
+                    dk[dt] = PV_MFMA_16x16x16(qa[dt], __builtin_bit_cast(s16x4, dw), dk[dt], 0, 0, 0);
+                }
+            }
+            if (more) own_rows(bn, hn);
+            const int key = wid * 16 + i16;
+            if (key < S) {
+                char* const opk = reinterpret_cast<char*>(gb + D) + (unsigned)(key * 3 * D + 4 * g) * 2u;
+                char* const opv = reinterpret_cast<char*>(gb + 2 * D) + (unsigned)(key * 3 * D + 4 * g) * 2u;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+#ifdef PV_OPERAND_F16
+                    dv[dt] = dv[dt] * PV_P_UNSHIFT;
+#endif
+                    *reinterpret_cast<u32x2*>(opk + dt * 32) = (u32x2){pv_pack_bf16x2(dk[dt][0], dk[dt][1]), pv_pack_bf16x2(dk[dt][2], dk[dt][3])};
+                    *reinterpret_cast<u32x2*>(opv + dt * 32) = (u32x2){pv_pack_bf16x2(dv[dt][0], dv[dt][1]), pv_pack_bf16x2(dv[dt][2], dv[dt][3])};
+                }
+            }
+        } else {
+            // ---- the waves without a tile: this item's bias-gradient thirds, the next item's row statistics ----
+            if (dbp && wid == NW - 2 && lane < DH) {                  // query third: the tile waves' column sums (written before the barrier above)
+                float t = 0.f;
+                for (int w = 0; w < nqt; ++w) t += red_q[w * DH + lane];
+                dbp[(int64_t)b * 3 * D + h * DH + lane] = t;
+            }
+            if (dbp && wid == NW - 1) {                               // value third: column sums of dO (rows < S) by MFMAs over the image; key third: 0
+                f32x4 acc[NDT];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const s16x4 ones = {(short)PV_ONE16, (short)PV_ONE16, (short)PV_ONE16, (short)PV_ONE16};
+                const bf16x8 ones8 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(ones, ones, 0, 1, 2, 3, 4, 5, 6, 7));
+                // four query tiles per trip: their sixteen transposed reads are issued before the first is waited for (one tile per trip, each behind its own
+                // lgkmcnt(0), took this wave 16 k ticks - longer than pass 2, with every other wave waiting at the next barrier)
+                constexpr int NQ4 = (NKT - 1) / 4;
+#pragma unroll 1
+                for (int q4 = 0; q4 < NQ4; ++q4) {
+                    lds_c* tb[NDT];
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) tb[dt] = (lds_c*)(Y1 + toff[dt] + q4 * 4 * TB);
+                    s16x4 t0_[NDT], t1_[NDT], t2_[NDT], t3_[NDT];
+                    tr_issue_i(tb, std::integral_constant<int, 0>{}, t0_);
+                    tr_issue_i(tb, std::integral_constant<int, TB>{}, t1_);
+                    tr_issue_i(tb, std::integral_constant<int, 2 * TB>{}, t2_);
+                    tr_issue_i(tb, std::integral_constant<int, 3 * TB>{}, t3_);
+                    tr_wait(t0_); tr_wait(t1_); tr_wait(t2_); tr_wait(t3_);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        acc[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(t0_[dt], t1_[dt], 0, 1, 2, 3, 4, 5, 6, 7)), ones8, acc[dt], 0, 0, 0);
+                        acc[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(t2_[dt], t3_[dt], 0, 1, 2, 3, 4, 5, 6, 7)), ones8, acc[dt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int qt = NQ4 * 4; qt < NKT; ++qt) {              // the last one to four tiles, one at a time (only the last can hold padded rows)
+                    s16x4 msk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) msk[j] = qt * 16 + 4 * g + j < S ? (short)PV_ONE16 : (short)0;
+                    s16x4 oa[NDT];
+                    tr_issue(Y1, qt, oa);
+                    tr_wait(oa);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) acc[dt] = PV_MFMA_16x16x16(oa[dt], qt == NKT - 1 ? msk : ones, acc[dt], 0, 0, 0);
+                }
+                if (i16 == 0) {
+                    float* o = dbp + (int64_t)b * 3 * D + h * DH + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        *reinterpret_cast<f32x4*>(o + D + dt * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(o + 2 * D + dt * 16) = acc[dt];
+                    }
+                }
+            }
+        }
+        PV_CSTAMP(6);
+        if (!more) break;
+        it = itn;
+        par ^= 1;
+    }
+}
+
+static int pv_attn_cu_count() {              // per device (the current one = the stream's)
+    static int cached[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 0;
+    if (cached[d] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0;
+        cached[d] = n > 0 ? n : -1;
+    }
+    return cached[d] > 0 ? cached[d] : 0;
+}
+
+template <int DH, int NKT>
+static int pv_launch_attn_bwd5(const uint16_t* qkv, const uint16_t* dout, const uint16_t* att, const float* lse, uint16_t* dqkv, float* dbp, int64_t B, int S, int H,
+                               float qscale, hipStream_t stream) {
+    constexpr int DHP = (DH + 31) / 32 * 32;
+    constexpr int lds = 4 * NKT * 16 * DHP * 2 + 4 * NKT * 16 * 4 + 16 * DH * 4 + 16 * 16 * DHP * 2;
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    static PvPerDevice attr_set;
+    if (attr_set.first_use()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_bwd5_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    const int cus = pv_attn_cu_count();
+    if (cus <= 0) return PV_ERR_LAUNCH;
+    const int64_t items = B * H;
+    const unsigned grid = (unsigned)(items < cus ? items : cus);
+    PV_LAUNCH((pv_attn_bwd5_kernel<DH, NKT>), dim3(grid), dim3(1024), lds, stream, qkv, dout, att, lse, dqkv, dbp, S, H, qscale, (int)B, (int)items);
+    return pv_check_launch();
+}
+
+template <int DH>
+static int pv_dispatch_attn_bwd5(const uint16_t* qkv, const uint16_t* dout, const uint16_t* att, const float* lse, uint16_t* dqkv, float* dbp, int64_t B, int S,
+                                 int H, float qscale, hipStream_t s) {
+    switch ((S + 15) / 16) {             // sequences of 113 .. 208 tokens: one tile per wave, at least three waves for the side work
+#define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd5<DH, N>(qkv, dout, att, lse, dqkv, dbp, B, S, H, qscale, s);
+        PV_ATTN_CASE(13)
+#undef PV_ATTN_CASE
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pv_attention_bwd_lse_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, uint16_t* dqkv,
+                                         float* dbias_partial, int64_t B, int64_t S, int64_t H, int64_t dh, float qscale, void* stream) {
+    if (!qkv || !dout || !out || !lse || !dqkv || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dqkv & 15) || ((uintptr_t)lse & 3) || ((uintptr_t)dbias_partial & 15))
+        return PV_ERR_INVALID_ARG;
+    if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {          // 113 <= S <= 208 at dh = 48 / 64; other shapes: pv_attention_bwd_bf16
+        case 48: return pv_dispatch_attn_bwd5<48>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
+        case 64: return pv_dispatch_attn_bwd5<64>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
 template <int DH>
 static int pv_dispatch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_t* dqkv, float* dbp, int64_t B, int S, int H, float qscale, hipStream_t s) {
     switch ((S + 15) / 16) {
@@ -1778,6 +2337,19 @@ extern "C" int pv_attention_f32_split(const float* qkv, uint16_t* out, int64_t B
         case 32: return pv_dispatch_attn_f32<32>(qkv, out, B, (int)S, (int)H, s);
         case 48: return pv_dispatch_attn_f32<48>(qkv, out, B, (int)S, (int)H, s);
         case 64: return pv_dispatch_attn_f32<64>(qkv, out, B, (int)S, (int)H, s);
+        default: return PV_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pv_attention_lse_bf16(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag, void* stream) {
+    if (!qkv || !out || !lse || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return PV_ERR_INVALID_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)lse & 3) || ((uintptr_t)range_flag & 3)) return PV_ERR_INVALID_ARG;
+    if (B * H > 0x7fffffff || S > 416) return PV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dh) {
+        case 32: return pv_dispatch_attn<32>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
+        case 48: return pv_dispatch_attn<48>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
+        case 64: return pv_dispatch_attn<64>(qkv, out, B, (int)S, (int)H, range_flag, s, lse);
         default: return PV_ERR_UNSUPPORTED;
     }
 }

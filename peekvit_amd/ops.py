@@ -292,11 +292,23 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, part: torch.Tensor, ksplit: int, t
     return part
 
 
-def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int):
+def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: int, lse: Optional[torch.Tensor] = None):
+    """lse (fp32 [B, H, S], optional; training forward): also receives log2(sum_k exp(s[q,k])) per row, for attention_bwd_lse."""
     with _timed("pv_attention_bf16", qkv.device, 4.0 * B * H * S * S * dh, 8.0 * B * S * H * dh):
-        check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _attn_flag(qkv.device), _stream(qkv)), "pv_attention_bf16")
+        if lse is None:
+            check(_lib.load().pv_attention_bf16(_ptr(qkv), _ptr(out), B, S, H, dh, _attn_flag(qkv.device), _stream(qkv)), "pv_attention_bf16")
+        else:
+            _chk(lse, torch.float32, "lse")
+            if lse.numel() != B * H * S:
+                raise _lib.PeekvitHipError("attention: lse must hold B * H * S values")
+            check(_lib.load().pv_attention_lse_bf16(_ptr(qkv), _ptr(out), _ptr(lse), B, S, H, dh, _attn_flag(qkv.device), _stream(qkv)), "pv_attention_lse_bf16")
     _count()
     return out
+
+
+def attention_bwd_lse_ok(S: int, dh: int) -> bool:
+    """Shapes the persistent backward (pv_attention_bwd_lse_bf16) serves: 13 query tiles of 16, dh = 48 / 64."""
+    return dh in (48, 64) and 193 <= S <= 208
 
 
 def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int, S: int, nq: int, H: int, dh: int):
@@ -496,6 +508,17 @@ def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, B: 
     with _timed("pv_attention_bwd_bf16", qkv.device, 14.0 * B * H * S * S * dh, 14.0 * B * S * H * dh):
         check(_lib.load().pv_attention_bwd_bf16(_ptr(qkv), _ptr(dout), _ptr(dqkv), _ptr(dbias_partial), B, S, H, dh, float(qscale),
                                                 _stream(qkv)), "pv_attention_bwd_bf16")
+    _count()
+    return dqkv
+
+
+def attention_bwd_lse(qkv: torch.Tensor, dout: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dqkv: torch.Tensor, B: int, S: int, H: int, dh: int,
+                      qscale: float, dbias_partial: Optional[torch.Tensor] = None):
+    """attention_bwd from the forward's output `out` (16-bit [B, S, H*dh]) and row statistics `lse` (attention(..., lse=)): one persistent workgroup per CU."""
+    _chk(lse, torch.float32, "lse")
+    with _timed("pv_attention_bwd_bf16", qkv.device, 14.0 * B * H * S * S * dh, 16.0 * B * S * H * dh):
+        check(_lib.load().pv_attention_bwd_lse_bf16(_ptr(qkv), _ptr(dout), _ptr(out), _ptr(lse), _ptr(dqkv), _ptr(dbias_partial), B, S, H, dh,
+                                                    float(qscale), _stream(qkv)), "pv_attention_bwd_lse_bf16")
     _count()
     return dqkv
 

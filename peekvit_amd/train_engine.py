@@ -462,6 +462,16 @@ def _wgrad_transposed(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, accu
     return ops.sum_slices(part, out, accumulate)
 
 
+_ATTN_BWD = os.environ.get("PEEKVIT_AMD_ATTN_BWD", "lse")          # "lse": the persistent kernel from the forward's row statistics where it applies | "recompute"
+
+
+def _attn_lse(B: int, S: int, H: int, dh: int, dev):
+    """fp32 [B, H, S] for the forward's log-sum-exp rows when the persistent backward kernel serves the shape (ops.attention_bwd_lse_ok), else None."""
+    if _ATTN_BWD != "lse" or not ops.attention_bwd_lse_ok(S, dh):
+        return None
+    return torch.empty((B, H, S), dtype=torch.float32, device=dev)
+
+
 _SPLITK_MODE = os.environ.get("PEEKVIT_AMD_WGRAD_SPLIT", "balanced")      # "balanced" (r2) | "pow2" (r1)
 
 
@@ -556,13 +566,15 @@ class BlockFn(torch.autograd.Function):
         qscale = float(dh) ** -0.5
         ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), eps, h1)
         ops.gemm(h1, bf16_weight(mha.in_proj_weight), _f32(inb), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=qscale)
-        ops.attention(qkv, att, B, S, H, dh)
+        lse = _attn_lse(B, S, H, dh, dev)                    # row statistics for the persistent backward kernel (None: the two-pass kernel recomputes them)
+        ops.attention(qkv, att, B, S, H, dh, lse=lse)
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D))
         ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2)
         ops.gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(b1), pair, PV_EPI_BIAS_GELU_PAIR_BF16, M=R)
         ops.gemm(gl, bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
         ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
+        ctx.lse = lse
         ctx.save_for_backward(x, h1, qkv, att, x1, h2, pair)
         return out
 
@@ -615,7 +627,10 @@ class BlockFn(torch.autograd.Function):
         ops.gemm(d1, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
         dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev) if need["inb"] else None
-        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        if ctx.lse is not None:
+            ops.attention_bwd_lse(qkv, datt, att, ctx.lse, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        else:
+            ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
         dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev)) if need["inb"] else None    # sum of the per-image column sums
         dwin = _wgrad(dqkv, h1, "qkv", bias_grad=False)[0] if need["inw"] else None
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
@@ -665,7 +680,8 @@ class MaskedBlockFn(torch.autograd.Function):
         else:
             ops.layernorm_bf16(x, _f32(ln1w), _f32(ln1b), blk.ln_1.eps, h1, mrow)
         ops.gemm(h1, bf16_weight(mha.in_proj_weight), _f32(inb), qkv, PV_EPI_BIAS_BF16, M=R, qcols=D, qscale=qscale)
-        ops.attention(qkv, att, B, S, H, dh)
+        lse = _attn_lse(B, S, H, dh, dev)                    # row statistics for the persistent backward kernel (None: the two-pass kernel recomputes them)
+        ops.attention(qkv, att, B, S, H, dh, lse=lse)
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(ob), u, PV_EPI_BIAS_BF16, M=R)
         ops.masked_residual(x.view(R, D), u, mrow, x1.view(R, D))
         ops.layernorm_bf16(x1, _f32(ln2w), _f32(ln2b), blk.ln_2.eps, h2, mrow)
@@ -673,6 +689,7 @@ class MaskedBlockFn(torch.autograd.Function):
         ops.gemm(pair[:, :Mh], bf16_weight(blk.mlp.fc2.weight), _f32(b2), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
         ctx.blk, ctx.dims = blk, (B, S, D, H, dh, Mh, qscale)
         ctx.tp, ctx.operand = current_pass(), _lib.current_operand()
+        ctx.lse = lse
         ctx.save_for_backward(x, mrow, h1, qkv, att, u, x1, h2, pair)
         return out
 
@@ -721,7 +738,10 @@ class MaskedBlockFn(torch.autograd.Function):
         ops.gemm(du, bf16_weight_t(mha.out_proj.weight), None, datt, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")
         dqkv = ws.get("bw_dqkv", (R, 3 * D), bf, dev)
         dbp = ws.get("bw_dbp", (B, 3 * D), torch.float32, dev) if need["inb"] else None
-        ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        if ctx.lse is not None:
+            ops.attention_bwd_lse(qkv, datt, att, ctx.lse, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+        else:
+            ops.attention_bwd(qkv, datt, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
         dbin = ops.colsum(dbp, torch.empty((3 * D,), dtype=torch.float32, device=dev)) if need["inb"] else None
         dwin = _wgrad(dqkv, h1, "qkv", bias_grad=False)[0] if need["inw"] else None
         ops.gemm(dqkv, bf16_weight_t(mha.in_proj_weight), None, dhid, PV_EPI_BIAS_BF16, M=R, tag="[dgrad]")

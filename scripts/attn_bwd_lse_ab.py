@@ -1,0 +1,74 @@
+"""The persistent attention backward from the forward's row statistics (pv_attention_bwd_lse_bf16) against the two-pass kernel that recomputes them
+(pv_attention_bwd_bf16): fp64 check on a few images, bias-gradient thirds, bitwise repeatability, timing.   python scripts/attn_bwd_lse_ab.py [f16|bf16]"""
+import os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from peekvit_amd import _lib, ops, engine
+dev = "cuda:0"
+
+
+def ref64(qkv, dout, B, S, H, dh, qscale):
+    D = H * dh
+    x = qkv.double().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    q, k, v = x[0], x[1], x[2]
+    o = torch.softmax(q @ k.transpose(-1, -2), -1) @ v
+    o.permute(0, 2, 1, 3).reshape(B, S, D).backward(dout.double())
+    g = x.grad.clone()
+    g[0] *= qscale
+    return g.permute(1, 3, 0, 2, 4).reshape(B, S, 3 * D)
+
+
+for mode in (sys.argv[1:] or ["f16", "bf16"]):
+    with engine.precision(mode):
+        dt = _lib.operand_dtype()
+        for H, dh, B, S in ((12, 64, 1, 200), (3, 64, 64, 193), (12, 64, 37, 197), (12, 64, 2048, 197), (6, 64, 512, 197), (8, 48, 512, 197), (12, 64, 300, 208)):
+            D = H * dh
+            g = torch.Generator(device=dev).manual_seed(0)
+            qkv = (torch.randn(B, S, 3 * D, generator=g, device=dev) * 0.7).to(dt)
+            dout = (torch.randn(B, S, D, generator=g, device=dev) * 0.1).to(dt)
+            att = torch.empty(B, S, D, dtype=dt, device=dev)
+            att0 = torch.empty_like(att)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+            ops.attention(qkv, att0, B, S, H, dh)
+            ops.attention(qkv, att, B, S, H, dh, lse=lse)
+            assert torch.equal(att, att0)
+            n2 = min(B, 2)
+            s64 = (qkv[:n2, :, :D].double().view(n2, S, H, dh).permute(0, 2, 1, 3) @ qkv[:n2, :, D:2 * D].double().view(n2, S, H, dh).permute(0, 2, 3, 1))
+            lse_err = float((lse[:n2].double() - torch.logsumexp(s64, -1) / 0.6931471805599453).abs().max())
+            outs, dbps, times = {}, {}, {"two-pass": [], "persistent": []}
+            for rnd in range(3):
+                for k in times:
+                    dqkv = torch.full_like(qkv, float("nan"))
+                    dbp = torch.full((B, 3 * D), float("nan"), device=dev)
+                    def run():
+                        if k == "two-pass":
+                            ops.attention_bwd(qkv, dout, dqkv, B, S, H, dh, dh ** -0.5, dbias_partial=dbp)
+                        else:
+                            ops.attention_bwd_lse(qkv, dout, att, lse, dqkv, B, S, H, dh, dh ** -0.5, dbias_partial=dbp)
+                    run(); run()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        run()
+                    e1.record(); torch.cuda.synchronize()
+                    times[k].append(e0.elapsed_time(e1) / 10)
+                    if k in outs and k == "persistent" and not (torch.equal(outs[k], dqkv) and torch.equal(dbps[k], dbp)):
+                        dd = (outs[k].float() - dqkv.float()).abs()
+                        bad = dd.view(B, S, 3, H, dh).amax((1, 4))          # [B, 3, H]
+                        idx = bad.nonzero()
+                        print(f"NOT bit-reproducible: finite {bool(torch.isfinite(dqkv.float()).all())}, {idx.shape[0]} (image, third, head) differ, first {idx[:6].tolist()}, "
+                              f"max diff {float(dd.max()):.3e}; dbp differs: {not torch.equal(dbps[k], dbp)}; rows differing in the first bad item: "
+                              f"{dd[idx[0][0]].view(S, 3, H, dh)[:, idx[0][1], idx[0][2]].amax(-1).nonzero().flatten().tolist()[:40] if idx.shape[0] else []}", flush=True)
+                    outs[k], dbps[k] = dqkv.clone(), dbp.clone()
+            nb = min(B, 6)
+            r = ref64(qkv[:nb], dout[:nb], nb, S, H, dh, dh ** -0.5)
+            line = f"{mode} H={H} dh={dh} B={B} S={S}: lse err {lse_err:.1e};"
+            for k in times:
+                o = outs[k][:nb].double()
+                errs = [float((o[..., i * D:(i + 1) * D] - r[..., i * D:(i + 1) * D]).norm() / r[..., i * D:(i + 1) * D].norm()) for i in range(3)]
+                db_ref = outs[k].float().sum(1)
+                db_err = float((dbps[k] - db_ref).abs().max() / db_ref.abs().max())
+                line += f"  {k} {statistics.median(times[k]):.3f} ms dq/dk/dv " + "/".join(f"{e:.1e}" for e in errs) + f" db {db_err:.1e} finite {bool(torch.isfinite(outs[k].float()).all() and torch.isfinite(dbps[k]).all())};"
+            line += f"  last image agrees: {float((outs['persistent'][-1].float() - outs['two-pass'][-1].float()).norm() / outs['two-pass'][-1].float().norm()):.1e}"
+            print(line, flush=True)

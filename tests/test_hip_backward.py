@@ -97,6 +97,52 @@ def test_attention_backward(ops, B, S, H, dh):
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("B,S,H,dh", [(2, 197, 12, 64), (70, 197, 12, 64), (1, 193, 1, 64), (5, 208, 3, 64), (40, 197, 8, 48), (3, 200, 2, 48)])
+def test_attention_backward_from_the_forward_statistics(ops, B, S, H, dh, mode):
+    """pv_attention_lse_bf16 + pv_attention_bwd_lse_bf16 (one persistent workgroup per CU, several (image, head) items each at the larger batches): the
+    forward is bit-identical with and without the statistics, lse = log2 sum exp, gradients against fp32 autograd like the two-pass kernel's, the
+    bias-gradient thirds in closed form (key third exactly 0, value third = column sums of dout), two launches bit-identical."""
+    from peekvit_amd import engine, _lib
+    D = H * dh
+    qscale = dh ** -0.5
+    with engine.precision(mode):
+        dt = _lib.operand_dtype()
+        assert ops.attention_bwd_lse_ok(S, dh)
+        qkv = _bf(B, S, 3 * D, seed=S).float()
+        qkv[..., :D] *= qscale
+        qkv = qkv.to(dt)
+        dout = _bf(B, S, D, seed=S + 1, scale=0.1).to(dt)
+        att0, att = torch.empty(B, S, D, dtype=dt, device="cuda"), torch.empty(B, S, D, dtype=dt, device="cuda")
+        lse = torch.full((B, H, S), float("nan"), device="cuda")
+        ops.attention(qkv, att0, B, S, H, dh)
+        ops.attention(qkv, att, B, S, H, dh, lse=lse)
+        assert torch.equal(att, att0)
+        s64 = qkv[..., :D].double().view(B, S, H, dh).permute(0, 2, 1, 3) @ qkv[..., D:2 * D].double().view(B, S, H, dh).permute(0, 2, 3, 1)
+        assert (lse.double() - torch.logsumexp(s64, -1) / np.log(2.0)).abs().max() < 1e-4
+        outs = []
+        for _ in range(2):
+            dqkv = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=dt)
+            dbp = torch.full((B, 3 * D), float("nan"), device="cuda")
+            ops.attention_bwd_lse(qkv, dout, att, lse, dqkv, B, S, H, dh, qscale, dbias_partial=dbp)
+            outs.append((dqkv, dbp))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert torch.isfinite(dqkv.float()).all() and torch.isfinite(dbp).all()
+        ref = _attn_ref(qkv, dout, B, S, H, dh, qscale)
+        two_pass = torch.empty_like(dqkv)
+        ops.attention_bwd(qkv, dout, two_pass, B, S, H, dh, qscale)
+        for i, name in enumerate("qkv"):
+            err = rel_l2(dqkv[..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
+            base = rel_l2(two_pass[..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
+            assert err < (1e-2 if mode == "bf16" else 1.5e-3) and err < 2.0 * base + 1e-4, (name, err, base)
+        assert rel_l2(dbp[:, :D], dqkv[..., :D].double().sum(1)) < 2e-6            # query third: column sums of exactly the stored values
+        assert float(dbp[:, D:2 * D].abs().max()) == 0.0                             # key third: sum_k dS[q, k] = D - D
+        assert rel_l2(dbp[:, 2 * D:], dout.double().sum(1)) < 2e-6                   # value third: sum_k P[q, k] = 1
+        scale = float(dqkv[..., 2 * D:].double().sum(1).abs().max())
+        assert float((dbp[:, 2 * D:].double() - dqkv[..., 2 * D:].double().sum(1)).abs().max()) < 3e-3 * scale     # ... which the stored dV rows sum to, up to their rounding
+        assert float(dqkv[..., D:2 * D].double().sum(1).abs().max()) < 3e-3 * float(dqkv[..., D:2 * D].double().abs().sum(1).max())
+
+
 @pytest.mark.parametrize("B,S,H,dh", [(3, 197, 12, 64), (2, 26, 12, 64), (2, 1, 2, 64), (2, 5, 2, 32), (2, 401, 8, 32), (3, 99, 8, 48), (1, 50, 3, 96),
                                       (2, 130, 2, 128)])
 def test_attention_rows_backward(ops, B, S, H, dh):

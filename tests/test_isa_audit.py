@@ -19,7 +19,13 @@ recognizer guarantees that for the code it generates and does NOT look into inli
 were scheduled 0 - 2 instructions behind the MFMA that writes their operands in 16 instantiations (dh = 32 at 7 key tiles, dh = 48 / 64 at
 5 and at 17 - 25 tiles, ...): a maximum formed from stale registers, non-finite rows once a missed score exceeded it by the packing
 headroom (scripts/dbg/attn_nonfinite.py; the cause of round 3's "carried maximum" NaN rows).  Compiler-generated reads never come closer
-than 6 wait states in any kernel of this library; the audit refuses anything below that."""
+than 6 wait states in any kernel of this library; the audit refuses anything below that.
+
+Third audit (round 5): the persistent attention backward (pv_attn_bwd5_kernel) issues its LDS reads as inline asm and counts its waits by hand,
+because hipcc waits vmcnt(0) before every LDS read it can see while an LDS-DMA is in flight.  Two things hipcc cannot know must therefore hold in
+the ISA: (a) nothing touches a register between the asm read that fills it and the asm s_waitcnt that retires it - no spill store / reload in
+between (a spill there saves the register BEFORE its data arrives); (b) the counted `s_waitcnt vmcnt(N)` that retires the Q | dO images is preceded
+by at least N younger vector-memory operations (the dQ stores): with fewer, N outstanding operations could still include pieces of the image."""
 import os
 import re
 import subprocess
@@ -158,3 +164,37 @@ def test_no_vector_read_of_an_mfma_result_inside_its_wait_states(isa):
                         break
     assert seen > 1000
     assert not offenders, "\n".join(offenders[:20])
+
+
+def test_persistent_attention_backward_hand_counted_waits(isa):
+    seen = 0
+    for path in isa:
+        if "pv_attention" not in os.path.basename(path):
+            continue
+        for kernel, ins in _kernels(path).items():
+            if "pv_attn_bwd5_kernel" not in kernel:
+                continue
+            seen += 1
+            text = [t for kind, t in ins if kind == "ins"]
+            # (a) asm LDS reads ... asm s_waitcnt lgkmcnt(0): no scratch traffic in between
+            pending = False
+            for t in text:
+                if t.startswith(("ds_read_b128", "ds_read_b64_tr_b16")):
+                    pending = True
+                elif t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                    pending = False
+                elif t.startswith("scratch_") and pending:
+                    raise AssertionError(f"{kernel}: `{t}` between an LDS read and the wait that retires it")
+            # (b) the counted wait behind pass 1
+            counted = [i for i, t in enumerate(text) if re.match(r"s_waitcnt vmcnt\((3|4)\) lgkmcnt\(0\)", t)]
+            assert len(counted) == 1, (kernel, len(counted))
+            n = int(re.match(r"s_waitcnt vmcnt\((\d)\)", text[counted[0]]).group(1))
+            younger = 0
+            for t in reversed(text[:counted[0]]):
+                if t.startswith("global_load_lds"):
+                    break
+                if t.startswith(("global_store", "global_load", "scratch_store", "scratch_load", "buffer_")):
+                    younger += 1
+            assert younger >= n, f"{kernel}: vmcnt({n}) behind only {younger} younger vector-memory operations"
+            # no vmcnt(0) that hipcc added inside the two pass loops (an inner loop with MFMAs and no barrier)
+    assert seen >= 4          # dh = 48 / 64 x two operand types
