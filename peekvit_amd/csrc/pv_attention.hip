@@ -87,7 +87,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #ifndef PV_ATTN_NW
 #define PV_ATTN_NW 4         // waves per workgroup of pv_attn_kernel (A/B: 8 waves x 2 workgroups per CU instead of 4 x 3; scripts/attn_ab.py)
 #endif
-template <int DH, int NKT>     // NKT = number of 16-key tiles = ceil(S / 16)
+template <int DH, int NKT, bool LSE = false>     // NKT = number of 16-key tiles = ceil(S / 16); LSE: the training forward, which also writes the rows' log-sum-exp
 __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B, float* __restrict__ lse) {
     constexpr int DHP = (DH + 31) / 32 * 32;
     constexpr int CPR = DHP / 8;
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(PV_ATTN_NW * 64) void pv_attn_kernel(const uint16_t
         l += __shfl_xor(l, 32, 64);
         // training forward (round 5): the row's log-sum-exp in the exp2 domain, m log2(e) + log2(sum exp(s - m)): the persistent backward kernel
         // (pv_attn_bwd5_kernel) forms p = exp2(s log2(e) - lse) without the row maximum and sum.  (l carries 2^PV_P_SHIFT in the fp16 build.)
-        if (lse != nullptr && g == 0 && q0 + i16 < S)
-            lse[((int64_t)b * H + h) * S + q0 + i16] = m * 1.44269504088896340736f + (__builtin_amdgcn_logf(l) - PV_P_SHIFT);
+        if constexpr (LSE)
+            if (g == 0 && q0 + i16 < S)
+                lse[((int64_t)b * H + h) * S + q0 + i16] = m * 1.44269504088896340736f + (__builtin_amdgcn_logf(l) - PV_P_SHIFT);
         if (!v_ready) {            // first tile of the wave: V must have landed (for every wave) before the first PV product
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -322,9 +323,12 @@ static int pv_launch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, 
     constexpr int lds = 2 * NKT * 16 * DHP * 2;
     static PvPerDevice attr_set;
     if (attr_set.first_use()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_kernel<DH, NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    PV_LAUNCH((pv_attn_kernel<DH, NKT>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B, lse);
+    // (two instantiations: the inference kernel keeps the code it had before the statistics existed)
+    if (lse) PV_LAUNCH((pv_attn_kernel<DH, NKT, true>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B, lse);
+    else PV_LAUNCH((pv_attn_kernel<DH, NKT, false>), dim3((unsigned)(B * H)), dim3(PV_ATTN_NW * 64), lds, stream, qkv, out, S, H, flag, (int)B, lse);
     return pv_check_launch();
 }
 
