@@ -1507,6 +1507,9 @@ static int pv_launch_attn_bwd(const uint16_t* qkv, const uint16_t* dout, uint16_
 //     by an MFMA against ones; key third: 0 identically - sum_k dS[q,k] = D - D; value third: column sums of dO by MFMAs over the image).
 // Two raw barriers per item; counted vmcnt waits (loads, stores and LDS-DMA retire in issue order).  No atomics: bit-reproducible.
 // ------------------------------------------------------------------------------------------------
+#ifndef PV_ABW5_PRIO
+#define PV_ABW5_PRIO 0          // wave priority by age in the persistent backward (A/B: -DPV_ABW5_PRIO=1; see the kernel)
+#endif
 #ifdef PV_OPERAND_F16
 #define PV_ONE16 0x3C00
 #else
@@ -1625,6 +1628,18 @@ __global__ __launch_bounds__(1024) void pv_attn_bwd5_kernel(const uint16_t* __re
             f[ks] = __builtin_bit_cast(bf16x8, v);
         }
     };
+#if PV_ABW5_PRIO
+    // Experiment (off): the SIMD's instruction arbiter serves the OLDEST ready wave first - of the four waves of a SIMD (w, w + 4, w + 8, w + 12) the youngest
+    // finishes every pass last (stamps: pass 2 takes wave 0 10 k ticks and wave 12 20 k).  Priority by age, youngest highest, only REVERSES the order (wave 12
+    // 9.7 k, wave 0 19.6 k; 1.70 vs 1.73 ms per launch): the four tiles of SIMD 0 cost 20 k ticks of that SIMD's issue whoever goes first - the passes are
+    // issue-bound, and the thirteenth tile (a fourth wave on one SIMD, three on the others) is what sets the pass length.
+    switch (wid >> 2) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     int it = blockIdx.x, par = 0;
     bf16x8 qf[KS], of[KS], af[KS];       // this wave's rows of Q, dO and of the forward's output O (for D = rowsum(dO o O)), prefetched one item ahead
     float lse_v = 0.f;                   // lse of query wid * 16 + i16
