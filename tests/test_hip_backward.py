@@ -97,6 +97,18 @@ def test_attention_backward(ops, B, S, H, dh):
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
 
 
+def test_training_blocks_choose_the_persistent_attention_backward_where_it_applies(ops):
+    """The training path keeps the forward's row statistics exactly for the shapes pv_attention_bwd_lse_bf16 serves (ViT at 224 / 16: S = 197, dh 48 / 64);
+    RankViT's shorter stages and other head widths keep the two-pass kernel."""
+    from peekvit_amd import train_engine
+    assert train_engine._ATTN_BWD == "lse"
+    for S, dh, want in ((197, 64, True), (197, 48, True), (193, 64, True), (208, 64, True), (99, 64, False), (50, 64, False), (209, 64, False), (197, 32, False), (192, 64, False)):
+        lse = train_engine._attn_lse(2, S, 3, dh, torch.device("cuda"))
+        assert (lse is not None) == want == ops.attention_bwd_lse_ok(S, dh), (S, dh)
+        if want:
+            assert lse.shape == (2, 3, S) and lse.dtype == torch.float32
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("B,S,H,dh", [(2, 197, 12, 64), (70, 197, 12, 64), (1, 193, 1, 64), (5, 208, 3, 64), (40, 197, 8, 48), (3, 200, 2, 48)])
 def test_attention_backward_from_the_forward_statistics(ops, B, S, H, dh, mode):
