@@ -304,7 +304,7 @@ int pv_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, uint16_t* d
  *                               recomputed row maximum / sum / sum(P o dP); K | V of the next item land while pass 2 of this one runs, every operand is fetched
  *                               once.  dbias_partial as above, in closed form where there is one: the key third is identically 0 (softmax is invariant under a
  *                               shift of all keys; autograd returns rounding noise there), the value third is the per-image column sums of dout (rows of this
- *                               head), the query third the column sums of the stored dQ.  dh in {48, 64}, 113 <= S <= 208; PV_ERR_UNSUPPORTED otherwise. */
+ *                               head), the query third the column sums of the stored dQ.  dh in {48, 64}, 129 <= S <= 208; PV_ERR_UNSUPPORTED otherwise. */
 int pv_attention_lse_bf16(const uint16_t* qkv, uint16_t* out, float* lse, int64_t B, int64_t S, int64_t H, int64_t dh, uint32_t* range_flag,
                           void* stream);
 int pv_attention_bwd_lse_bf16(const uint16_t* qkv, const uint16_t* dout, const uint16_t* out, const float* lse, uint16_t* dqkv,

@@ -2028,9 +2028,9 @@ static int pv_launch_attn_bwd5(const uint16_t* qkv, const uint16_t* dout, const 
 template <int DH>
 static int pv_dispatch_attn_bwd5(const uint16_t* qkv, const uint16_t* dout, const uint16_t* att, const float* lse, uint16_t* dqkv, float* dbp, int64_t B, int S,
                                  int H, float qscale, hipStream_t s) {
-    switch ((S + 15) / 16) {             // sequences of 113 .. 208 tokens: one tile per wave, at least three waves for the side work
+    switch ((S + 15) / 16) {             // sequences of 129 .. 208 tokens: one tile per wave, at least three waves for the side work
 #define PV_ATTN_CASE(N) case N: return pv_launch_attn_bwd5<DH, N>(qkv, dout, att, lse, dqkv, dbp, B, S, H, qscale, s);
-        PV_ATTN_CASE(13)
+        PV_ATTN_CASE(9) PV_ATTN_CASE(10) PV_ATTN_CASE(11) PV_ATTN_CASE(12) PV_ATTN_CASE(13)
 #undef PV_ATTN_CASE
         default: return PV_ERR_UNSUPPORTED;
     }
@@ -2043,7 +2043,7 @@ extern "C" int pv_attention_bwd_lse_bf16(const uint16_t* qkv, const uint16_t* do
         return PV_ERR_INVALID_ARG;
     if (B * H > 0x7fffffff) return PV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    switch (dh) {          // 113 <= S <= 208 at dh = 48 / 64; other shapes: pv_attention_bwd_bf16
+    switch (dh) {          // 129 <= S <= 208 at dh = 48 / 64; other shapes: pv_attention_bwd_bf16
         case 48: return pv_dispatch_attn_bwd5<48>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
         case 64: return pv_dispatch_attn_bwd5<64>(qkv, dout, out, lse, dqkv, dbias_partial, B, (int)S, (int)H, qscale, s);
         default: return PV_ERR_UNSUPPORTED;

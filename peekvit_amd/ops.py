@@ -307,8 +307,14 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, dh: 
 
 
 def attention_bwd_lse_ok(S: int, dh: int) -> bool:
-    """Shapes the persistent backward (pv_attention_bwd_lse_bf16) serves: 13 query tiles of 16, dh = 48 / 64."""
-    return dh in (48, 64) and 193 <= S <= 208
+    """Shapes for which the training path takes the persistent backward (pv_attention_bwd_lse_bf16): where it serves (attention_bwd_lse_supported) AND is the
+    faster kernel - 10 .. 13 query tiles (S = 197: 1.70 vs 1.97 ms, 177: 1.48 vs 1.64, 158: 1.25 vs 1.32; at 9 tiles, S = 129, the two are equal)."""
+    return attention_bwd_lse_supported(S, dh) and S >= 145
+
+
+def attention_bwd_lse_supported(S: int, dh: int) -> bool:
+    """Shapes pv_attention_bwd_lse_bf16 accepts: 9 .. 13 query tiles of 16 (one wave each, at least three waves left for the side work), dh = 48 / 64."""
+    return dh in (48, 64) and 129 <= S <= 208
 
 
 def attention_rows(q: torch.Tensor, kv: torch.Tensor, out: torch.Tensor, B: int, S: int, nq: int, H: int, dh: int):
