@@ -97,6 +97,30 @@ def test_attention_backward(ops, B, S, H, dh):
         assert err < 1e-2, (name, err)          # bf16 rounding of P / dS operands and of the stored gradient
 
 
+@pytest.mark.parametrize("B,H", [(257, 1), (86, 3), (1, 1)])
+def test_persistent_attention_backward_without_bias_sums_and_with_uneven_item_counts(ops, B, H):
+    """dbias_partial = None (frozen in-projection bias: the reference's finetuning) skips the side work; 257 / 258 items on 256 CUs give one or two workgroups
+    a second item and the others none; the gradients are bit-identical to the run that also forms the bias sums, launch after launch."""
+    from peekvit_amd import engine, _lib
+    S, dh = 197, 64
+    D = H * dh
+    with engine.precision("f16"):
+        dt = _lib.operand_dtype()
+        qkv = _bf(B, S, 3 * D, seed=B).to(dt)
+        dout = _bf(B, S, D, seed=B + 1, scale=0.1).to(dt)
+        att = torch.empty(B, S, D, dtype=dt, device="cuda")
+        lse = torch.empty(B, H, S, device="cuda")
+        ops.attention(qkv, att, B, S, H, dh, lse=lse)
+        ref = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=dt)
+        dbp = torch.full((B, 3 * D), float("nan"), device="cuda")
+        ops.attention_bwd_lse(qkv, dout, att, lse, ref, B, S, H, dh, dh ** -0.5, dbias_partial=dbp)
+        assert torch.isfinite(ref.float()).all() and torch.isfinite(dbp).all()
+        for _ in range(3):
+            got = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=dt)
+            ops.attention_bwd_lse(qkv, dout, att, lse, got, B, S, H, dh, dh ** -0.5)
+            assert torch.equal(got, ref)
+
+
 def test_training_blocks_choose_the_persistent_attention_backward_where_it_applies(ops):
     """The training path keeps the forward's row statistics exactly for the shapes pv_attention_bwd_lse_bf16 serves (145 <= S <= 208 at dh 48 / 64: ViT at 224 / 16, RankViT's
     first stage at budgets >= 0.74); shorter stages and other head widths keep the two-pass kernel."""
