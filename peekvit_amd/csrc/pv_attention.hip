@@ -1578,9 +1578,6 @@ __global__ __launch_bounds__(1024) void pv_attn_bwd5_kernel(const uint16_t* __re
             }
         }
     };
-    auto frag = [&](const char* X, int tile, int ks) __attribute__((always_inline)) {
-        return *reinterpret_cast<const bf16x8*>(X + foff[ks] + tile * TB);
-    };
     // transposed reads as inline asm: hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of every ds_read_tr BUILTIN while an LDS-DMA is in flight (it
     // cannot see that the image being filled is not the one being read) - which would park pass 1 until Q | dO have landed.  trN reads NDT fragments of one
     // tile (tr2N: of two consecutive tiles, joined for the K = 32 MFMA); the s_waitcnt that follows names them as operands, so every consumer depends on it.
