@@ -201,6 +201,9 @@ def extra_config(kind, dev, steps, warmup):
         def step():
             model(x)
     f0 = engine.fallback_count
+    rep0 = getattr(engine, "rank_repaired_images", 0)
+    sc0 = dict(engine.selfcheck_totals)           # (before the oracle check below: the first forward of a key is where its first probe runs)
+    engine.selfcheck_totals["worst_rel_l2"] = 0.0
     if hostile:
         import warnings
         warnings.simplefilter("ignore", RuntimeWarning)
@@ -218,21 +221,24 @@ def extra_config(kind, dev, steps, warmup):
     else:
         err = oracle_error(model, cfg, dev, 16 if rank else 64, train, rank)        # before the optimizer moves the weights
     engine.selfcheck_last = None
+    from peekvit_amd import telemetry
+    sampler = telemetry.sampler(dev.index or 0)
     with (torch.enable_grad() if train else torch.no_grad()):
         for _ in range(warmup):
             step()
         import gc
         gc.collect()                  # (see the headline's warm-up)
-        # forward entries: the median of three back-to-back timed segments of `steps` steps each (a 5 ms step on a shared host: one 25 ms hiccup inside a
-        # single segment of 50 steps read as -10 % in one of this round's runs); the training step (0.23 s each) keeps its single segment
+        # the median of three back-to-back timed segments of `steps` steps each (a 5 ms step on a shared host: one 25 ms hiccup inside a single segment
+        # of 50 steps read as -10 % in one of round 4's runs; round 6: the training step too - its single segment of ten 0.23 s steps was the review's item 7)
         segs = []
-        for _seg in range(1 if train else 3):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize(dev)
-            segs.append(time.perf_counter() - t0)
+        with sampler.window() as pw:
+            for _seg in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize(dev)
+                segs.append(time.perf_counter() - t0)
         dt = sorted(segs)[len(segs) // 2]
         with ops.KernelTimer() as kt:
             step()
@@ -249,7 +255,9 @@ def extra_config(kind, dev, steps, warmup):
            "model_mfma_roofline_frac": round(value * flops_exec / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
            ("train_forward_logits_rel_l2_vs_oracle" if train else "logits_rel_l2_vs_oracle"): err,
            "logits_sample_images": 16 if rank else 64,
-           "top_kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:4]}}
+           "top_kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:4]},
+           # package power / shader clock over the three timed segments (read-only sysfs sampling on a host thread, peekvit_amd/telemetry.py)
+           "power": pw.result()}
     if hostile:
         out.pop("logits_rel_l2_vs_oracle"); out.pop("logits_sample_images")
         out["guard"] = {"whole_forward_fallbacks": engine.fallback_count - f0, "sticky_split_operand_mode": bool(engine.guard_state(model).unsafe),
@@ -266,8 +274,14 @@ def extra_config(kind, dev, steps, warmup):
     if not train and not hostile and engine.selfcheck_last is not None:
         sc = engine.selfcheck_last
         out["self_check"] = {"fp16_vs_bf16x3_logits_rel_l2": float(f"{sc[0]:.3e}"), "images_compared": sc[1] - sc[2], "limit": engine.SELFCHECK_LIMIT}
+        tot = engine.selfcheck_totals
+        out["self_check"]["all_probes_of_this_entry"] = {"probes": tot["probes"] - sc0["probes"], "images": tot["images"] - sc0["images"],
+                                                         "worst_fp16_vs_bf16x3_logits_rel_l2": float(f"{tot['worst_rel_l2']:.3e}")}
         if rank:
-            out["self_check"]["rank_tie_flips"] = {"images": sc[2], "of": sc[1], "note": "probe images in which a ranked layer kept a different token SET than the "
+            # CUMULATIVE over every probe of this entry (oracle check, warm-up, timed segments) - round 5 reported the last probe only
+            out["self_check"]["rank_tie_flips"] = {"images": tot["tie_flips"] - sc0["tie_flips"], "of": tot["images"] - sc0["images"], "last_probe": {"images": sc[2], "of": sc[1]},
+                                                   "repaired_images": getattr(engine, "rank_repaired_images", 0) - rep0,
+                                                   "note": "probe images in which a ranked layer kept a different token SET than the "
                                                    "split-operand arithmetic did (a near-tie at the keep boundary resolved by 16-bit noise in the norms): their logits move "
                                                    "by percents and they are excluded from the comparison above; PEEKVIT_AMD_RANK_STRICT=1 sends the model to bf16x3 instead"}
     if train:
@@ -526,11 +540,14 @@ def main():
         import gc
         gc.collect()
         # (1) the contract's timed region: exactly K steps between barrier + synchronize, nothing else on the stream
+        from peekvit_amd import telemetry
+        sampler = telemetry.sampler(local)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(x)
-        barrier()
+        with sampler.window() as pw_headline:
+            for _ in range(args.steps):
+                out = model(x)
+            barrier()
         elapsed = time.perf_counter() - t0
         # (2) the same K steps again with two HIP events around EVERY launch (on the launch stream) for the per-kernel
         # roofline numbers; the ~200 extra stream commands per step cost ~3 %, which is why (1) is timed without them
@@ -651,6 +668,14 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        # the operating point the timed region ran at (round 6, review item 3): mean package power and shader clock over exactly the K timed steps of rank 0,
+        # the board's power cap, and the empirical (dependency-free instruction mix at this bytes/FLOP) roofline of the GEMM family next to the nominal one
+        pw = pw_headline.result()
+        line["power_w"], line["sclk_mhz"] = pw.get("power_w"), pw.get("sclk_mhz")
+        line["power"] = dict(pw, cap_w=sampler.cap_w(), source="sysfs hwmon power1_average / freq1_input of this GPU, ~50 Hz host thread (peekvit_amd/telemetry.py)")
+        emp = (roof.get("family") or roof).get("empirical")
+        if emp:
+            line["empirical_roofline"] = emp
         if args.train and world == 1 and not args.no_cpu_baseline and args.rank_budget is None:
             # the forward of the TRAINING arithmetic (fp16 operands + loss scale since round 5) against the fp32 oracle, next to `dtype`
             line["train_forward_logits_rel_l2_vs_oracle"] = train_fwd_err

@@ -210,12 +210,31 @@ class OverlappedGradReducer:
                 b["flat"].div_(world)
         self.skip_step = False
         if self.model is not None:
+            # The verdict exchange is UNCONDITIONAL (round 6): round 5 issued it only while this rank's operand was fp16 or its own step had been
+            # skipped - both rank-local.  An fp16 FORWARD overflow depends on the rank's data shard and makes only that rank's operand sticky bf16: from
+            # the next step on that rank left the collective out while the others still called it (gloo: blocked for ever; RCCL: the 1-element
+            # all-reduce paired with the other rank's next bucket).  Three words, MAX: [0] this rank's backward overflowed / its forward raised the
+            # overflow bit, [1] this rank's model has gone to bf16 operands for good (-> every rank does, together), [2] a non-finite value in the
+            # REDUCED buckets (whatever produced it: the optimizer must not consume it - the step pre-hook cannot drop gradients that alias the buckets).
             from . import train_engine
-            if train_engine.pass_operand(self.model) == "f16" or train_engine.last_step_skipped(self.model):
-                dev = self._buckets[0]["flat"].device if self._buckets else torch.device("cpu")
-                word = torch.tensor([1.0 if train_engine.last_step_skipped(self.model) else 0.0], device="cpu" if td.get_backend() == "gloo" else dev)
-                td.all_reduce(word, op=td.ReduceOp.MAX)
-                self.skip_step = bool(word.item() > 0.0)
+            st = train_engine.train_state(self.model)
+            skipped = train_engine.last_step_skipped(self.model)
+            dev = self._buckets[0]["flat"].device if self._buckets else torch.device("cpu")
+            on_host = td.get_backend() == "gloo"
+            if self._buckets:
+                with torch.no_grad():
+                    bad = (~torch.isfinite(torch.stack(torch._foreach_norm([b["flat"] for b in self._buckets])).sum())).float().reshape(1)
+            else:
+                bad = torch.zeros(1)
+            word = torch.cat([torch.tensor([1.0 if skipped else 0.0, 1.0 if st.operand == "bf16" else 0.0]), bad.cpu()]) if on_host else \
+                torch.cat([torch.tensor([1.0 if skipped else 0.0, 1.0 if st.operand == "bf16" else 0.0], device=dev), bad.to(dev)])
+            td.all_reduce(word, op=td.ReduceOp.MAX)
+            w = word.tolist()
+            self.skip_step = bool(w[0] > 0.0 or w[2] > 0.0)
+            if w[1] > 0.0 and st.operand != "bf16":
+                st.operand = "bf16"                    # another rank's forward overflowed fp16: all ranks train on bf16 operands from here on
+            if w[2] > 0.0 and not w[0] > 0.0:
+                train_engine.book_external_skip(self.model)
         n_buckets, self._work, self.buckets_launched = len(self._work), [], 0
         for b in self._buckets:
             b["pending"], b["launched"] = len(b["params"]), False

@@ -122,7 +122,7 @@ class RankVisionTransformer(_ViTBase):
             with engine.on_device(x):
                 return train_engine.model_forward_train(self, x, train_body)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            body = lambda xs: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
+            body = lambda xs: engine.pool_and_head(self, engine.call_module(self.encoder, engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
             # what a ranked layer decided for every image: its kept SET (sorted indices); mode auto's self-check compares arithmetic only where
             # these agree with the split-operand run (engine.RANK_STRICT)
             ranked = [blk for blk in self.encoder.layers if getattr(blk, "current_budget", 1) != 1 and hasattr(blk, "sort_and_drop")]

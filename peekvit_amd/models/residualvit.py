@@ -359,8 +359,8 @@ class ResidualVisionTransformer(_ViTBase):
                 cached = getattr(self, "_pv_budget", None)      # set_budget's value as a host float: no device read (a sync; illegal under graph capture)
                 budget = cached[1] if cached is not None and cached[0] is self.current_budget else float(self.current_budget)
                 btok = self.learnable_budget_token_1.detach().view(-1)
-            body = lambda xs: engine.pool_and_head(self, self.encoder(engine.embed_tokens(self, xs, btok, budget), _pos_added=True,
-                                                                      _rows=self.num_class_tokens))
+            body = lambda xs: engine.pool_and_head(self, engine.call_module(self.encoder, engine.embed_tokens(self, xs, btok, budget), _pos_added=True,
+                                                                            _rows=self.num_class_tokens))
             return engine.run_guarded(self, x, lambda: body(x), probe=body, probe_key=budget)
         if (self.training and train_engine.train_eligible(x, self, max(self.dropout, self.attention_dropout))
                 and train_engine.supported(self.hidden_dim, self.num_heads, self.seq_length + (1 if self.add_budget_token else 0))):

@@ -216,5 +216,5 @@ class VisionTransformer(_ViTBase):
 
     def _hip_forward(self, x: torch.Tensor):
         tokens = engine.embed_tokens(self, x)                      # im2col + GEMM (+bias +pos), cls rows
-        tokens = self.encoder(tokens, _pos_added=True, _rows=self.num_class_tokens)      # blocks dispatch themselves
+        tokens = engine.call_module(self.encoder, tokens, _pos_added=True, _rows=self.num_class_tokens)      # blocks dispatch themselves
         return engine.pool_and_head(self, tokens)                  # LN on CLS rows, sum, fp32 head

@@ -62,6 +62,10 @@ from .engine import _f32, bf16_weight, pver, workspace
 # PEEKVIT_AMD_TRAIN_OPERAND: "" (default) = fp16 in precision mode "auto", bf16 in mode "bf16"; "bf16" / "f16" force one
 _TRAIN_OPERAND = os.environ.get("PEEKVIT_AMD_TRAIN_OPERAND", "")
 SCALE_TARGET = float(os.environ.get("PEEKVIT_AMD_TRAIN_SCALE_TARGET", "128"))    # L * max|entering gradient|
+# An overflow divides the target by 4; round 5 never raised it again, so a few transient spikes left L 64x lower for the rest of a run - the smallest
+# per-tensor gradient maxima then sit in fp16's flush-to-zero range: silent precision loss instead of a skip.  Like GradScaler's
+# growth_interval: after this many CONSECUTIVE clean steps the target doubles, up to SCALE_TARGET.
+SCALE_GROWTH_INTERVAL = int(os.environ.get("PEEKVIT_AMD_TRAIN_SCALE_GROWTH_INTERVAL", "200"))
 _tls = threading.local()
 debug_amax = None            # a list: BlockFn.backward appends the maxima of its 16-bit gradients (diagnostics only)
 steps_skipped = 0            # training steps skipped because an fp16 gradient overflowed (tests / bench read it)
@@ -70,7 +74,7 @@ forward_fallbacks = 0        # models sent to bf16-operand training because thei
 
 class TrainState:
     """What the training path has learnt about one model (plain attribute `_pv_train`)."""
-    __slots__ = ("operand", "target", "amax", "scale", "steps", "skipped", "last_skipped", "on_skip", "warned", "pending")
+    __slots__ = ("operand", "target", "amax", "scale", "steps", "skipped", "last_skipped", "on_skip", "warned", "pending", "clean")
 
     def __init__(self):
         self.operand = None            # None: decided per pass from the precision mode; "bf16": sticky (an fp16 forward overflowed / weights do not fit)
@@ -78,6 +82,7 @@ class TrainState:
         self.amax = None               # max |gradient entering the chain| of the last finished pass (host float)
         self.scale = 1.0               # L of the last pass
         self.steps, self.skipped, self.last_skipped = 0, 0, False
+        self.clean = 0                 # consecutive clean steps since the target was last lowered (the target grows back after SCALE_GROWTH_INTERVAL of them)
         self.on_skip = None            # callable(model) -> None replacing the default "every .grad = None" (dist.OverlappedGradReducer)
         self.warned = False
         self.pending = None            # the last backward pass whose verdict has not been read on the host yet
@@ -118,6 +123,8 @@ class TrainPass:
         self.fwd_flag = None
         self.amax = None
         self.found, self.host, self.event, self.applied, self.skipped = None, None, None, True, False
+        self.stepped = set()           # ids of the model's parameters an optimizer has already stepped (or skipped) under this pass's verdict
+        self._pids = None
 
     # -- backward side ---------------------------------------------------------------------------------------------------------
     def begin_backward(self, grad: torch.Tensor, primary: bool) -> float:
@@ -170,6 +177,8 @@ class TrainPass:
             st.pending.resolve()
         st.pending = self
         self.applied = False
+        # (a pass some optimizer has already consumed is over once the model's NEXT backward ends: parameters no optimizer owns never complete it)
+        _pending_passes[:] = [tp for tp in _pending_passes if not (tp.state is st and tp.stepped)]
         _pending_passes.append(self)
         while len(_pending_passes) > 16:           # (backward passes that no optimizer step ever consumes - gradients taken for their own sake - must not pile up)
             old = _pending_passes.pop(0)
@@ -195,9 +204,14 @@ class TrainPass:
             st.last_skipped = False
             if amax > 0.0 and math.isfinite(amax):
                 st.amax = amax
+            if st.target < SCALE_TARGET and SCALE_GROWTH_INTERVAL > 0:
+                st.clean += 1
+                if st.clean >= SCALE_GROWTH_INTERVAL:
+                    st.target, st.clean = min(st.target * 2.0, SCALE_TARGET), 0
             return False
         st.skipped += 1
         st.last_skipped = True
+        st.clean = 0
         steps_skipped += 1
         if fwd_over:
             st.operand = "bf16"
@@ -212,6 +226,11 @@ class TrainPass:
                 warnings.warn(f"peekvit_amd: an fp16 gradient overflowed at loss scale {self.L:g}; this step's gradients were dropped (the optimizer "
                               "step is skipped) and the scale target was lowered", RuntimeWarning, stacklevel=2)
         return True
+
+    def param_ids(self):
+        if self._pids is None:
+            self._pids = frozenset(id(p) for p in self.model.parameters() if p.requires_grad)
+        return self._pids
 
     def drop_gradients(self):
         """The skip, host form: every .grad = None (torch optimizers and clip_grad_norm_ pass over such parameters), or the owner's own way
@@ -233,20 +252,37 @@ class TrainPass:
 _pending_passes: list = []
 
 
+def book_external_skip(model: nn.Module):
+    """A step of `model` is being skipped for a reason its own backward pass did not see (non-finite values in all-reduced gradients)."""
+    global steps_skipped
+    st = train_state(model)
+    st.skipped += 1
+    st.last_skipped = True
+    st.clean = 0
+    steps_skipped += 1
+
+
 def _optimizer_pre_hook(opt, args, kwargs):
     if not _pending_passes:
         return None
     mine = {id(p) for g in opt.param_groups for p in g["params"]}
-    todo = [tp for tp in _pending_passes if not tp.applied and any(id(p) in mine for p in tp.model.parameters())]
+    # Round 6 (ADVICE r5): a pass stays pending until EVERY parameter of its model has been stepped under its verdict (or the model's next backward
+    # ends).  Round 5 let the first optimizer that shared a parameter with the model consume the pass: a second optimizer over the model's other
+    # parameters (backbone / head, gates split off) then found nothing pending and stepped on the overflowed gradients.
+    todo = [tp for tp in _pending_passes if (tp.param_ids() & mine) - tp.stepped]
     if not todo:
         return None
     for tp in todo:
-        _pending_passes.remove(tp)
+        tp.stepped |= tp.param_ids() & mine
+        if tp.stepped >= tp.param_ids():
+            _pending_passes.remove(tp)
     # The verdict of a pass covers ITS backward.  Whoever sums gradients across ranks afterwards (torch's DistributedDataParallel, a hand-written
     # all-reduce) hands a rank whose own verdict says "clean" the inf / NaN of a rank that overflowed: the gradients this step is about to consume
     # are therefore checked as well (one multi-tensor norm over them - the pass clip_grad_norm_ makes too), on the device for fused optimizers.
     grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None and p.grad.is_cuda]
-    if getattr(opt, "_step_supports_amp_scaling", False) and all(tp.state.on_skip is None for tp in todo):
+    if getattr(opt, "_step_supports_amp_scaling", False):
+        # fused optimizer: the device-side verdict travels as `found_inf` - also when the gradients alias an OverlappedGradReducer's buckets
+        # (round 5 sent that case to the host form below, whose "every .grad = None" the reducer turns into a no-op: the step then ran)
         found = todo[0].found if len(todo) == 1 else torch.stack([tp.found for tp in todo]).amax(0)
         if grads:
             with torch.no_grad():
@@ -261,19 +297,24 @@ def _optimizer_pre_hook(opt, args, kwargs):
     skipped = False
     for tp in todo:
         if tp.resolve():
-            tp.drop_gradients()
             skipped = True
+            if tp.state.on_skip is not None and not tp.applied:
+                raise RuntimeError("peekvit_amd: this training step overflowed fp16 and must be skipped, but its gradients alias an OverlappedGradReducer's "
+                                   "buckets and cannot be dropped for a non-fused optimizer: call optimizer.step() only `if not reducer.skip_step` "
+                                   "(or use a fused torch optimizer, which receives the verdict as found_inf)")
+            tp.applied = False
+            tp.drop_gradients()
         tp.applied = True
     if not skipped and grads:
         with torch.no_grad():
             if not bool(torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum())):       # (non-finite gradients from somewhere else: see above)
-                global steps_skipped
+                if any(tp.state.on_skip is not None for tp in todo):
+                    raise RuntimeError("peekvit_amd: non-finite gradients in an OverlappedGradReducer's buckets at optimizer.step(): check "
+                                       "`reducer.skip_step` after finish() (it covers the reduced buckets) or use a fused torch optimizer")
                 for tp in todo:
-                    tp.state.skipped += 1
-                    tp.state.last_skipped = True
+                    book_external_skip(tp.model)
                     tp.applied = False
                     tp.drop_gradients()
-                steps_skipped += 1
     return None
 
 

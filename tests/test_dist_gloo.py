@@ -94,10 +94,32 @@ def _worker(rank, world, port, out_dir):
     red2.finish()
     skip_one = red2.skip_step
     train_engine.train_state(model).last_skipped = False
+    # round 6: the verdict exchange must not depend on rank-local state.  Rank 1's fp16 forward "overflowed": its operand goes to
+    # bf16 for good - round 5 then left the collective out on that rank only and the other one blocked in it.  Now every rank takes part in every
+    # finish(), and the sticky bf16 verdict reaches all of them together.
+    st = train_engine.train_state(model)
+    if rank == 1:
+        st.operand = "bf16"
+    red2.zero_grad()
+    (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    red2.finish()                                                      # (a hang here is the bug)
+    operand_after = st.operand
+    skip_diverged = red2.skip_step
+    # ... and a non-finite value in the REDUCED buckets (from whatever source) is a skip on every rank
+    red2.zero_grad()
+    (torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum") / x.shape[0]).backward()
+    if rank == 0:
+        with torch.no_grad():
+            red2._buckets[0]["flat"][0] = float("inf")
+    skipped0 = st.skipped
+    red2.finish()
+    skip_nonfinite, booked = red2.skip_step, st.skipped - skipped0
+    st.operand, st.last_skipped = None, False
     red2.remove()
     if rank == 0:
         np.savez(os.path.join(out_dir, "r0.npz"), logits=logits.numpy(), nb=nb, nb2=nb2, early=launched_during_backward, same=same, accum=accum, raised=raised,
                  nb_uniform=nb_uniform, n_buckets=len(reducer._buckets), skip_clean=skip_clean, skip_one=skip_one,
+                 operand_after=operand_after, skip_diverged=skip_diverged, skip_nonfinite=skip_nonfinite, booked=booked,
                  **{"g_" + n: g.numpy() for n, g in reduced.items()})
     td.barrier()
     td.destroy_process_group()
@@ -125,5 +147,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert bool(got["accum"]) and bool(got["raised"])                     # no_sync() accumulation; a second backward outside it is refused
     assert int(got["nb_uniform"]) == int(got["n_buckets"])                # every bucket leaves on every rank
     assert not bool(got["skip_clean"]) and bool(got["skip_one"])          # rank 0 learns that rank 1 dropped its step
+    # round 6: ranks whose operands diverged still meet in finish(); the sticky bf16 verdict of rank 1 reaches rank 0; a non-finite reduced bucket skips
+    assert str(got["operand_after"]) == "bf16" and not bool(got["skip_diverged"])
+    assert bool(got["skip_nonfinite"]) and int(got["booked"]) == 1
     for n, p in model.named_parameters():
         assert np.allclose(got["g_" + n], p.grad.numpy(), rtol=1e-4, atol=1e-6), n

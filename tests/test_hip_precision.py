@@ -559,12 +559,19 @@ def test_contract_self_check_of_mode_auto(monkeypatch):
     monkeypatch.setattr(engine, "SELFCHECK_IMAGES", 8)
     monkeypatch.setattr(engine, "SELFCHECK_LIMIT", 9e-4)
     engine.reset_guard(m)
-    seen = []
+    seen, seen_enc, seen_global = [], [], []
+    import torch.nn.modules.module as _tm
     h = m.encoder.layers[1].register_forward_hook(lambda mod, i, o: seen.append(o.shape[0]))
+    he = m.encoder.register_forward_hook(lambda mod, i, o: seen_enc.append(o.shape[0]))
+    hg = _tm.register_module_forward_hook(lambda mod, i, o: seen_global.append(o.shape[0]) if mod is m.encoder.layers[0] else None)
+    hooks_before = (m.encoder.layers[1]._forward_hooks, m.encoder._forward_hooks, _tm._global_forward_hooks)
     with torch.no_grad():
         f = m(x)
-    assert seen == [12] and engine.selfcheck_count == c0 + 4 and torch.equal(f, a)
-    assert len(m.encoder.layers[1]._forward_hooks) == 1       # (the hook is back in place)
+    assert seen == [12] and seen_enc == [12] and seen_global == [12] and engine.selfcheck_count == c0 + 4 and torch.equal(f, a)
+    # round 6: the probe never touches a hook dictionary - the very same objects, still holding the hooks, all along
+    assert all(x_ is y_ for x_, y_ in zip(hooks_before, (m.encoder.layers[1]._forward_hooks, m.encoder._forward_hooks, _tm._global_forward_hooks)))
+    assert len(m.encoder.layers[1]._forward_hooks) == 1
+    he.remove(); hg.remove()
     with torch.no_grad():
         m(x)
     h.remove()
