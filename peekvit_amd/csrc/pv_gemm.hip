@@ -175,6 +175,7 @@ struct GemmDev {
     float qscale;
     int tiles_m, tiles_n;
     int fr_full, fr_half;      // full-row kernel, split remainder: fr_full 128-row tiles (a multiple of 8) + fr_half 64-row tiles; 0, 0 = tiles_m plain tiles
+    int fr_big;                // ... or (round 6) fr_full 128-row tiles + fr_big 160-row tiles over the rows behind them
     int gm;                    // M-blocks per tile-order group (256^2 kernel): inside a group n is the SLOW index
     int gc;                    // column tiles per raster chunk (256^2 kernel): the tile list is chunk-major, so an XCD keeps the
                                // same gc weight tiles while it streams the activation row panels of its share of the rows
@@ -1709,22 +1710,22 @@ __device__ __forceinline__ void pv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 // exactly the pieces issued AFTER the ones phase j+1 (or phase 0 of the next K-tile) reads.  v[mode][j]: mode 0 steady state, 1 K-tile
 // nk-2, 2 K-tile nk-1 (its last phase waits for nothing).
 struct PvFrCounts { int pro; int v[3][4]; };
-constexpr PvFrCounts pv_fr_counts(int NPH, int PW) {
+constexpr PvFrCounts pv_fr_counts(int NPH, int PW, int AP = 2) {      // AP: A pieces per wave and K-tile (2; 3 for the 160-row tile)
     constexpr int NK = 8;                                // long enough for a steady state between prologue and tail
     int kind[512] = {}, tile[512] = {};                  // kind 0 = A, 1 + g = W group g
     int n = 0;
     auto issue = [&](int k, int t, int cnt) { for (int i = 0; i < cnt; ++i) { kind[n] = k; tile[n] = t; ++n; } };
     auto younger = [&](int k, int t) { int last = -1; for (int i = 0; i < n; ++i) if (kind[i] == k && tile[i] == t) last = i; return n - 1 - last; };
     PvFrCounts c = {};
-    issue(0, 0, 2);
+    issue(0, 0, AP);
     for (int g = 0; g < NPH; ++g) issue(1 + g, 0, PW);
-    issue(0, 1, 2);
+    issue(0, 1, AP);
     for (int g = 0; g < NPH - 1; ++g) issue(1 + g, 1, PW);
     c.pro = younger(1, 0);                               // A(0) is older than W group 0 of K-tile 0
     for (int s = 0; s < NK; ++s)
         for (int j = 0; j < NPH; ++j) {
             if (j == 0) { if (s + 1 < NK) issue(NPH, s + 1, PW); }
-            else if (s + 2 < NK) { if (j == 1) { issue(0, s + 2, 2); issue(1, s + 2, PW); } else issue(j, s + 2, PW); }
+            else if (s + 2 < NK) { if (j == 1) { issue(0, s + 2, AP); issue(1, s + 2, PW); } else issue(j, s + 2, PW); }
             int w = 0;
             if (j < NPH - 1) w = younger(2 + j, s);
             else if (s + 1 < NK) w = younger(1, s + 1);
@@ -1734,36 +1735,27 @@ constexpr PvFrCounts pv_fr_counts(int NPH, int PW) {
     return c;
 }
 
-template <int NT, int DPH = 0>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave; DPH = phases per K-tile of the deep-pipelined K loop (round 4), 0 = the plain loop
-__global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
+// Round 6: the body is a device function of MT = row tiles (16 rows) per wave group, so that one launch can mix 128-row tiles (MT = 4) with a LAST ROUND
+// of 160-row tiles (MT = 5, deep-pipelined loop at N <= 384 only).  788 tiles of 128 rows on 256 CUs are 3.08 rounds; round 3's split remainder ran
+// the 0.08 as a fourth round of 64-row tiles whose K loop is as long as a full tile's (the loop is paced by its staging, not by its MFMAs): 21 % of fc2's
+// time on 16 % of the CUs.  Two rounds of 128-row tiles + one round of 221 tiles of 160 rows cover the same rows in 3.25 tile times: 5 + 5 row tiles on the two
+// waves of a SIMD = 1.25 x the MFMAs per K-tile, the same W staging, 24 instead of 16 KiB of A (waves 4-7 repeat their first piece into a spare
+// slot so that every wave issues the same number of pieces: the counted waits stay one table), three epilogue passes (64 + 64 + 32 rows), one batch
+// of residual rows in registers instead of two (120 accumulator registers).  Per row the arithmetic is unchanged: bit-identical.
+template <int NT, int DPH, int MT>      // N = 64 * NT, NT in {4, 6, 8}: n-tiles (16 columns) per wave; DPH = phases per K-tile of the deep-pipelined K loop (round 4), 0 = the plain loop
+__device__ __forceinline__ void pv_fullrow_body(const GemmDev& p, char* const smem, const int m0, const bool half) {
     constexpr bool DP = DPH > 0;
-    constexpr int N = 64 * NT, BM = 128, BK = 64;
-    constexpr int A_BYTES = BM * BK * 2;                  // 16 KiB
+    static_assert(MT == 4 || (MT == 5 && DP && NT <= 6), "160-row tiles: deep-pipelined loop, N <= 384");
+    constexpr int N = 64 * NT, BM = 32 * MT, BK = 64;
+    constexpr int AP = (BM + 63) / 64;                    // A pieces (8 rows x 128 B) per wave and K-tile
+    constexpr int A_BYTES = AP * 64 * BK * 2;             // 16 KiB (24 KiB: 160 rows + 32 spare)
     constexpr int BUF = A_BYTES + N * BK * 2;             // one K-tile buffer
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    // Split remainder (round 3): 788 tiles of 128 rows on 256 CUs are 3.08 rounds - a quarter of the last one idle in every XCD.  With
-    // fr_full > 0 the launch is whole rounds of 128-row tiles plus ONE round of 64-row tiles over the remaining rows; every XCD (workgroup id
-    // & 7) takes an equal share of both lists, full tiles first.  A 64-row tile is this same code with wave group 1 (rows 64 - 127) idle:
-    // no A staging and no MFMAs for it, one epilogue pass - per row the arithmetic is unchanged.
-    int m0_;
-    bool half = false;
-    if (p.fr_full > 0) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, fper = p.fr_full >> 3, q = p.fr_half >> 3, r = p.fr_half & 7;
-        if (j < fper) m0_ = (x * fper + j) * BM;
-        else {
-            const int hj = j - fper;
-            if (hj >= q + (x < r ? 1 : 0)) return;          // (whole workgroup: before any barrier)
-            m0_ = p.fr_full * BM + ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + hj) * 64;
-            half = true;
-        }
-    } else m0_ = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
-    const int m0 = m0_;
 #ifdef PV_STAMPS
     const size_t pv_stamp_slot = (size_t)blockIdx.x;
-    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 5] = rt_; p.dbg[pv_stamp_slot * 16 + 7] = (unsigned long long)(half ? 1 : 0); }
+    if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 5] = rt_; p.dbg[pv_stamp_slot * 16 + 7] = (unsigned long long)(half ? 1 : MT == 5 ? 2 : 0); }
 #endif
     PV_STAMP(0);
     const bool skip_mm = half && wm == 1;              // (wave-uniform)
@@ -1775,7 +1767,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     // and no register load sits in the queue for the compiler to drain with vmcnt(0).
     constexpr bool BIAS_LDS = DP && NT <= 6;
     constexpr int BIAS_OFF = 2 * BUF;
-    f32x4 acc[NT][4];   // [nt][mt]: out[row wm*64 + mt*16 + i16][col wn*16*NT + nt*16 + 4g + 0..3]
+    f32x4 acc[NT][MT];  // [nt][mt]: out[row wm*16*MT + mt*16 + i16][col wn*16*NT + nt*16 + 4g + 0..3]
     if constexpr (BIAS_LDS) {
         if (p.bias && wid < NT)                                // (wave-uniform) 64 floats per wave
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + wid * 64 + lane),
@@ -1786,12 +1778,12 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 16 * NT + nt * 16 + 4 * g);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b4;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -1803,11 +1795,12 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     // waits leave the loads in flight), batch 1 at the start of the epilogue, pass 1's batches as pass 0 consumes the registers.
     constexpr int KC = NT;
     const int q4 = lane >> 4, l16 = lane & 15;
-    constexpr int RB = NT <= 6 ? 2 : 1;                    // batches of residual rows in registers (N = 512: 128 accumulator registers leave room for one)
+    constexpr int RB = (NT <= 6) ? 2 : 1;                  // batches of residual rows in registers (N = 512: 128 accumulator registers leave room for one; the 160-row tile at N = 384 fits two with no register to spare)
+    constexpr int NPASS = (BM + 63) / 64;                  // epilogue passes of 64 rows (a wave owns 8: two batches of four); the 160-row tile: 64 + 64 + 32 (4 rows: one batch)
     f32x4 rr[RB][KC];
     float sc[RB], lsc[RB];
     auto res_load = [&](int ps, int b) __attribute__((always_inline)) {
-        const int m = m0 + ps * 64 + wid * 8 + 4 * b + q4, mr = m < p.M ? m : p.M - 1;
+        const int m = m0 + ps * 64 + ((MT == 5 && ps == 2) ? wid * 4 + q4 : wid * 8 + 4 * b + q4), mr = m < p.M ? m : p.M - 1;
         sc[b % RB] = p.row_scale ? p.row_scale[mr] : 1.0f;        // (workgroup-uniform branches)
         lsc[b % RB] = p.ln_row_scale ? p.ln_row_scale[mr] : 1.0f;
         const float* src = p.res + (int64_t)mr * p.ldr + l16 * 4;
@@ -1838,15 +1831,17 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     constexpr int NP = DP ? DPH : 1;                     // phases per K-tile
     constexpr int NTP = NT / NP;                         // column tiles (16 columns) of a wave per phase = pieces per wave and W group
     static_assert(NT % NP == 0 && NTP >= 2 && NTP <= 4, "phases of 2 - 4 column tiles");
-    constexpr PvFrCounts CNT = pv_fr_counts(NP, NTP);
+    constexpr PvFrCounts CNT = pv_fr_counts(NP, NTP, AP);
     const int srow8 = lane >> 3;
     const int schunk = (lane & 7) ^ (srow8 & 7);
-    const char* ga[2];
+    const char* ga[AP];
     const char* gw[NTP];
     int lw_off[NTP];                                     // (wave-uniform) LDS byte offset of the wave's W piece i of group 0 inside a buffer
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int ra = m0 + j * 64 + wid * 8 + srow8; ra = ra < p.M ? ra : p.M - 1;
+    for (int j = 0; j < AP; ++j) {
+        // (160-row tile: piece 2 of waves 4 - 7 would be rows 160 - 191: they fetch their piece 0 again - an L1 / L2 hit - into that spare LDS slot)
+        const int jr = (j * 64 + wid * 8 < BM) ? j : 0;
+        int ra = m0 + jr * 64 + wid * 8 + srow8; ra = ra < p.M ? ra : p.M - 1;
         ga[j] = reinterpret_cast<const char*>(p.A + (int64_t)ra * p.lda + schunk * 8);
     }
     // W group j = the 16 NTP weight rows each of the four column groups reads in phase j (rows wn * 16 NT + 16 NTP j + ..): 8 NTP pieces of 8 rows,
@@ -1860,7 +1855,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     const int64_t wg_stride = 32 * NTP * p.ldw;         // bytes between W groups (16 NTP rows)
     auto stage_a = [&](int buf, int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) pv_glds16(ga[j] + kt * (BK * 2), smem + buf * BUF + j * 8192 + wid * 1024);
+        for (int j = 0; j < AP; ++j) pv_glds16(ga[j] + kt * (BK * 2), smem + buf * BUF + j * 8192 + wid * 1024);
     };
     auto stage_w = [&](int buf, int grp, int kt) {
 #pragma unroll
@@ -1875,12 +1870,12 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            a_rd[b][ks] = (lds_cc*)smem + b * BUF + (wm * 64 + i16) * 128 + (fx0 ^ (ks << 6));
+            a_rd[b][ks] = (lds_cc*)smem + b * BUF + (wm * 16 * MT + i16) * 128 + (fx0 ^ (ks << 6));
             w_rd[b][ks] = (lds_cc*)smem + b * BUF + A_BYTES + (wn * 16 * NT + i16) * 128 + (fx0 ^ (ks << 6));
             asm volatile("" : "+v"(a_rd[b][ks]));
             asm volatile("" : "+v"(w_rd[b][ks]));
         }
-    bf16x8 xf[4][2], wf[NTP][2];
+    bf16x8 xf[MT][2], wf[NTP][2];
 
     const int nk = p.K / BK;
     // prologue, in the steady-state issue order: all of K-tile 0, then K-tile 1 but its last W group (phase 0 of K-tile 0 issues that)
@@ -1899,7 +1894,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) b4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) char*)smem + BIAS_OFF + (wn * 16 * NT + nt * 16 + 4 * g) * 4);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b4;
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b4;
         }
     }
     PV_STAMP(1);
@@ -1910,7 +1905,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
         constexpr int B = decltype(buf_c)::value, MODE = decltype(mode_c)::value, j = decltype(j_c)::value;
         if constexpr (j == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     xf[mt][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a_rd[B][ks] + mt * 2048);
@@ -1938,7 +1933,7 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 #pragma unroll
             for (int t_ = 0; t_ < NTP; ++t_)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[NTP * j + t_][mt] = PV_MFMA_16x16x32(wf[t_][ks], xf[mt][ks], acc[NTP * j + t_][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[NTP * j + t_][mt] = PV_MFMA_16x16x32(wf[t_][ks], xf[mt][ks], acc[NTP * j + t_][mt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -2032,22 +2027,22 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
     if constexpr (!RES_AHEAD) res_load(0, 0);
     if constexpr (RB == 2) res_load(0, 1);
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int ps = 0; ps < NPASS; ++ps) {
         if (ps == 1 && half) break;                        // (workgroup-uniform) a 64-row tile has no second pass
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // K loop (ps = 0) / the previous pass's image reads (ps = 1) are done
 #ifdef PV_STAMPS
         if (ps == 0) PV_STAMP(8);
 #endif
-        if (wm == ps) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int row = mt * 16 + i16;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int gmt = wm * MT + mt;                                   // (wave-uniform) row tile of the workgroup's tile: pass gmt / 4, image rows (gmt % 4) * 16 ..
+            if ((gmt >> 2) != ps) continue;
+            const int row = (gmt & 3) * 16 + i16;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int c = wn * 4 * NT + nt * 4 + g;                 // 16-byte chunk of the row
-                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = wn * 4 * NT + nt * 4 + g;                     // 16-byte chunk of the row
+                *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + row * (N * 4) + ((c ^ (i16 & 7)) << 4)) = acc[nt][mt];
             }
         }
         if (ps == 0 && p.ln_out && tid < N) {              // (the region is beyond every row of the image)
@@ -2061,7 +2056,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
 #endif
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int row = wid * 8 + 4 * b + q4, m = m0 + ps * 64 + row;
+            const bool short_pass = MT == 5 && ps == 2;                     // (compile-time after unrolling) the 32-row pass: one batch of four rows per wave
+            if (short_pass && b == 1) break;
+            const int row = short_pass ? wid * 4 + q4 : wid * 8 + 4 * b + q4, m = m0 + ps * 64 + row;
             float4 v[KC];
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
@@ -2076,9 +2073,9 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
             // the next rows into the registers just consumed (workgroup-uniform branches): two batches in flight -> the same batch of pass 1,
             // one -> the next batch
             __builtin_amdgcn_sched_barrier(0);
-            if (RB == 2) { if (ps == 0 && !half) res_load(1, b); }
-            else if (b == 0) res_load(ps, 1);
-            else if (ps == 0 && !half) res_load(1, 0);
+            if (RB == 2) { if (ps + 1 < NPASS && !half && !(MT == 5 && ps == 1 && b == 1)) res_load(ps + 1, b); }      // (the 160-row tile's third pass has one batch)
+            else if (b == 0 && !short_pass) res_load(ps, 1);
+            else if (ps + 1 < NPASS && !half) res_load(ps + 1, 0);
             if (m < p.M) {
                 float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + l16 * 4;
 #pragma unroll
@@ -2104,11 +2101,48 @@ __global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
             if (ps == 0 && b == 0) PV_STAMP(12);
 #endif
         }
-        PV_STAMP(3 + ps);
+        PV_STAMP(ps < 2 ? 3 + ps : 13);
     }
 #ifdef PV_STAMPS
     if (threadIdx.x == 0 && p.dbg) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); p.dbg[pv_stamp_slot * 16 + 6] = rt_; }
 #endif
+}
+
+template <int NT, int DPH = 0>
+__global__ __launch_bounds__(512) void pv_gemm_fullrow_kernel(const GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128;
+    // Split remainder (round 3): 788 tiles of 128 rows on 256 CUs are 3.08 rounds - a quarter of the last one idle in every XCD.  With
+    // fr_full > 0 the launch is whole rounds of 128-row tiles plus ONE round of 64-row tiles over the remaining rows; every XCD (workgroup id
+    // & 7) takes an equal share of both lists, full tiles first.  A 64-row tile is this same code with wave group 1 (rows 64 - 127) idle:
+    // no A staging and no MFMAs for it, one epilogue pass - per row the arithmetic is unchanged.
+    // Round 6: fr_big > 0 - fr_big tiles of 160 rows FIRST in the grid (the longest tiles start first), over the rows behind the fr_full (a multiple
+    // of 8, possibly 0) 128-row tiles; again every XCD takes an equal share of both lists.
+    int m0_;
+    bool half = false, big = false;
+    if (p.fr_big > 0) {
+        const int nb8 = (p.fr_big + 7) >> 3;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if (j < nb8) {
+            const int q = p.fr_big >> 3, r = p.fr_big & 7;
+            if (j >= q + (x < r ? 1 : 0)) return;           // (whole workgroup: before any barrier)
+            m0_ = p.fr_full * BM + ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j) * 160;
+            big = true;
+        } else m0_ = (x * (p.fr_full >> 3) + (j - nb8)) * BM;
+    } else if (p.fr_full > 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, fper = p.fr_full >> 3, q = p.fr_half >> 3, r = p.fr_half & 7;
+        if (j < fper) m0_ = (x * fper + j) * BM;
+        else {
+            const int hj = j - fper;
+            if (hj >= q + (x < r ? 1 : 0)) return;          // (whole workgroup: before any barrier)
+            m0_ = p.fr_full * BM + ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + hj) * 64;
+            half = true;
+        }
+    } else m0_ = pv_xcd_remap(blockIdx.x, p.tiles_m) * BM;
+    if constexpr (DPH > 0 && NT <= 6) {
+        if (big) { pv_fullrow_body<NT, DPH, 5>(p, smem, m0_, false); return; }      // (workgroup-uniform)
+    }
+    pv_fullrow_body<NT, DPH, 4>(p, smem, m0_, half);
 }
 
 static int g_pv_frdp = -1;         // -1: PV_FULLROW_DP / default; 0 / 1: A/B override (scripts/fullrow_ab4.py)
@@ -2119,8 +2153,8 @@ static int pv_fullrow_dp_mode() {           // 0: plain K loop, otherwise the de
 }
 static int g_pv_frsplit = -1;
 extern "C" void pv_debug_set_fullrow_split(int on) { g_pv_frsplit = on; }
-static int pv_fullrow_split_mode() {       // 0: plain 128-row tiles, 1: split remainder (round 3)
-    static const int env = [] { const char* e = getenv("PV_FULLROW_SPLIT"); return e ? atoi(e) : 1; }();
+static int pv_fullrow_split_mode() {       // 0: plain 128-row tiles, 1: split remainder (round 3), 2: a last round of 160-row tiles where it applies, else as 1 (round 6)
+    static const int env = [] { const char* e = getenv("PV_FULLROW_SPLIT"); return e ? atoi(e) : 2; }();
     return g_pv_frsplit >= 0 ? g_pv_frsplit : env;
 }
 static bool pv_fullrow_split_enabled() { return pv_fullrow_split_mode() != 0; }
@@ -2129,17 +2163,34 @@ template <int NT>
 static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
     constexpr int lds = 2 * (128 * 64 * 2 + 64 * NT * 64 * 2);
+    constexpr int lds_big = 2 * (192 * 64 * 2 + 64 * NT * 64 * 2) + 256 * NT;      // 160-row tiles (24 KiB of A per K-tile buffer) + the bias
     if (attr_set.first_use()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NT <= 6 ? lds + 256 * NT : lds);      // (+ the bias)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_gemm_fullrow_kernel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NT <= 6 ? lds_big : lds);      // (+ the bias)
     }
     // split remainder: whole rounds of 128-row tiles, then the rest as ONE round of 64-row tiles - when there is more than one round and the
     // remainder fits half a round (otherwise plain 128-row tiles; PV_FULLROW_SPLIT=0 / pv_debug_set_fullrow_split(0): A/B)
     GemmDev q = p;
-    q.fr_full = 0; q.fr_half = 0;
+    q.fr_full = 0; q.fr_half = 0; q.fr_big = 0;
     unsigned grid = (unsigned)p.tiles_m;
     const int cus = pv_cu_count() & ~7;
-    if (pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
+    const bool dp = p.K % 128 == 0 && pv_fullrow_dp_mode() != 0;
+    // round 6: the remainder of the last whole round is small (<= 32 rows per CU): take one round of 128-row tiles back and cover its rows and
+    // the remainder with ONE round of 160-row tiles: 3.08 rounds of work in 2 + 1.25 tile times instead of 3 + ~0.85
+    if (pv_fullrow_split_mode() == 2 && NT <= 6 && dp && cus >= 8 && p.tiles_m > cus) {
+        const int rounds = p.tiles_m / cus;
+        const int64_t rem = p.M - (int64_t)rounds * cus * 128;
+        if (rem > 0 && rem <= (int64_t)cus * 32) {
+            q.fr_full = (rounds - 1) * cus;
+            q.fr_big = (int)((p.M - (int64_t)q.fr_full * 128 + 159) / 160);
+            grid = 8u * (unsigned)((q.fr_big + 7) / 8) + (unsigned)q.fr_full;
+        }
+    }
+    if (pv_fullrow_split_mode() == 3 && NT <= 6 && dp && cus >= 8 && p.tiles_m > cus) {      // experiment: 160-row tiles only
+        q.fr_full = 0; q.fr_big = (int)((p.M + 159) / 160);
+        grid = 8u * (unsigned)((q.fr_big + 7) / 8);
+    }
+    if (q.fr_big == 0 && pv_fullrow_split_enabled() && cus >= 8 && p.tiles_m > cus) {
         const int full = p.tiles_m / cus * cus;
         const int64_t rem = p.M - (int64_t)full * 128;
         if (rem > 0 && rem <= (int64_t)cus * 64) {
@@ -2149,7 +2200,7 @@ static int pv_launch_gemm_fullrow(const GemmDev& p, hipStream_t stream) {
     }
     // the deep-pipelined loop (K-tiles in pairs) with TWO phases of 8 NT MFMAs per K-tile: phases of 16 MFMAs (NT / 2 of them, the first form of
     // round 4) cost a barrier pair more per K-tile at N = 384 / 512 and measured 0.4 % behind in the model (scripts/vit_small_inproc_ab.py)
-    if (p.K % 128 == 0 && pv_fullrow_dp_mode() != 0) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, 2>), dim3(grid), dim3(512), NT <= 6 ? lds + 256 * NT : lds, stream, q);
+    if (dp) PV_LAUNCH((pv_gemm_fullrow_kernel<NT, 2>), dim3(grid), dim3(512), q.fr_big > 0 ? lds_big : NT <= 6 ? lds + 256 * NT : lds, stream, q);
     else PV_LAUNCH((pv_gemm_fullrow_kernel<NT, 0>), dim3(grid), dim3(512), lds, stream, q);
     return pv_check_launch();
 }

@@ -33,12 +33,12 @@ for name, N, K in [("out", 384, 384), ("fc2", 384, 1536)]:
         torch.cuda.synchronize()
         d = dbg.view(nblk, 16).cpu()
         used = d[:, 0] != 0
-        for kind in (0, 1):
+        for kind in (0, 1, 2):
             sel = used & (d[:, 7] == kind)
             if sel.sum() == 0: continue
             x = d[sel].double()
             seg = lambda i, j: (x[:, j] - x[:, i]).median().item()
-            last = 4 if kind == 0 else 3
+            last = {0: 4, 1: 3, 2: 13}[kind]
             clk = ((x[:, last] - x[:, 0]) / ((x[:, 6] - x[:, 5]) * 10e-9)).median().item() / 1e9
-            print(f"{name} K={K} dp={dp} {'half' if kind else 'full'} tiles {int(sel.sum())}: prologue {seg(0,1):.0f}  kloop {seg(1,2):.0f} ({seg(1,2) / (K // 64):.0f}/ktile)  "
-                  f"pass0 {seg(2,3):.0f} [K-loop end -> barrier {seg(2,8):.0f} | image + barrier {seg(8,10):.0f} | batch 0: image rows + residual -> fp32 stores {seg(10,11):.0f} | LayerNorm + 16-bit stores {seg(11,12):.0f} | batch 1 {seg(12,3):.0f}]  pass1 {seg(3,4) if kind == 0 else 0:.0f}  total {seg(0,last):.0f} ticks  clock {clk:.2f} GHz", flush=True)
+            print(f"{name} K={K} dp={dp} {('full', 'half', 'big (160 rows)')[kind]} tiles {int(sel.sum())}: prologue {seg(0,1):.0f}  kloop {seg(1,2):.0f} ({seg(1,2) / (K // 64):.0f}/ktile)  "
+                  f"pass0 {seg(2,3):.0f} [K-loop end -> barrier {seg(2,8):.0f} | image + barrier {seg(8,10):.0f} | batch 0: image rows + residual -> fp32 stores {seg(10,11):.0f} | LayerNorm + 16-bit stores {seg(11,12):.0f} | batch 1 {seg(12,3):.0f}]  pass1 {seg(3,4) if kind != 1 else 0:.0f}  pass2 {seg(4,13) if kind == 2 else 0:.0f}  total {seg(0,last):.0f} ticks  clock {clk:.2f} GHz", flush=True)

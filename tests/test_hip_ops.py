@@ -225,7 +225,12 @@ def test_gemm_kernels_agree_bitwise(ops):
                                    # round 4, the deep-pipelined K loop of the full-row kernel (K % 128 == 0; K = 64 and 192 keep the plain loop): 2, 3, 5, 8 and
                                    # 16 K-tile pairs at every width, 64-row tail tiles, fewer rows than one tile
                                    (5000, 384, 640), (777, 256, 1024), (4097, 512, 256), (130, 384, 2048), (63, 256, 256), (3 * 128 + 1, 384, 192),
-                                   (256 * 128 + 64 * 40 + 3, 384, 768)])
+                                   (256 * 128 + 64 * 40 + 3, 384, 768),
+                                   # round 6, a LAST ROUND of 160-row tiles (N <= 384, deep-pipelined loop, remainder of the last whole round <= 32 rows per CU):
+                                   # vit_small's own shapes at batch 512 (two rounds of 128-row tiles + 221 tiles of 160 rows), one round of 160-row tiles only,
+                                   # N = 256, the remainder at the rule's boundary and one row beyond it (-> 64-row tiles), a ragged last 160-row tile
+                                   (512 * 197, 384, 384), (512 * 197, 384, 1536), (256 * 128 + 8000, 256, 256), (256 * 128 + 8192, 384, 128),
+                                   (256 * 128 + 8193, 384, 128), (2 * 256 * 128 + 161, 256, 768)])
 def test_gemm_fused_layernorm_bit_identical_to_separate_kernels(ops, M, N, K):
     """GEMM with fused LayerNorm (full-row tile for N = 256 / 384 / 512, row-block kernel otherwise) == plain GEMM followed by
     pv_layernorm_bf16, bit for bit (with and without row scale); N = 384 ... also cover the full-row kernel WITHOUT LayerNorm against the
