@@ -22,12 +22,13 @@ class GraphedForward:
     "auto": the capture is the fp16-operand forward incl. the zeroing of the range flag; every replay reads the flag and a
     forward that tripped it is repeated eagerly (engine.run_guarded: folding off or the bf16x3 mode, whichever the flag asks for)."""
 
-    def __init__(self, model: torch.nn.Module, example: torch.Tensor, warmup: int = 2):
+    def __init__(self, model: torch.nn.Module, example: torch.Tensor, warmup: int = 2, capture_error_mode: str = "global"):
         assert example.is_cuda and not model.training, "GraphedForward needs an eval-mode model and a GPU tensor"
         self.model = model
         self.static_in = example.clone()
         self._ws = engine._Workspace()
         self._flag = engine.range_flag_for(example.device)
+        self._error_mode = capture_error_mode          # "thread_local" for engine-initiated captures (peekvit_amd.autograph): other threads keep launching
         self._capture(warmup)
 
     def _capture(self, warmup: int):
@@ -46,7 +47,7 @@ class GraphedForward:
             # has already sent this model to the fallback mode (parameter bounds, or three trips in a row during warm-up): that capture
             # neither zeroes nor writes the word, so the replayer must not read it (a stale bit would send every replay to eager)
             # (or the warm-up forwards' self-check measured this model / budget / batch size outside the contract on fp16 operands)
-            with torch.cuda.graph(self.graph, stream=side):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=self._error_mode):
                 self.static_out = self.model(self.static_in)
             self._guarded = engine._mode() == "auto" and engine.last_forward_guarded()
             gs = engine.guard_state(self.model)

@@ -15,20 +15,24 @@ g = torch.Generator(device=dev).manual_seed(0)
 SL = 16          # stamp slots per workgroup
 SHAPES = {"vit_b_16": [("qkv", 2304, 768, 0, False), ("qkv_fold", 2304, 768, 0, True), ("out", 768, 768, 2, False), ("fc1", 3072, 768, 1, False),
                        ("fc1_fold", 3072, 768, 1, True), ("fc2", 768, 3072, 2, False)],
-          "vit_small": [("qkv", 1152, 384, 0, False), ("fc1", 1536, 384, 1, False)]}      # (M=100864; its residual GEMMs run the full-row kernel)
+          "vit_small": [("qkv", 1152, 384, 0, False), ("fc1", 1536, 384, 1, False)],
+          # the training step's two byte-heaviest GEMMs: fc1 forward with the pair epilogue (gelu | pre-activation planes), fc2's data gradient with gelu' (round 6)
+          "train": [("fc1_gelu_fwd", 3072, 768, 1, False), ("fc1_pair", 3072, 768, 6, False), ("dgelu", 3072, 768, 7, False), ("dgrad_plain", 3072, 768, 0, False)]}      # (M=100864; its residual GEMMs run the full-row kernel)
 for name, N, K, epi, fold in SHAPES[os.environ.get("MODEL", "vit_b_16")]:
     a = torch.randn(M, K, generator=g, device=dev).to(torch.float16)
     w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.float16)
     bias = torch.randn(N, generator=g, device=dev)
     stat = torch.stack([torch.randn(M, generator=g, device=dev) * 0.05, 1.0 + 0.1 * torch.rand(M, generator=g, device=dev)], 1).contiguous()
     c1 = w.float().sum(1).contiguous()
-    out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.float16, device=dev)
-    res = torch.randn(M, N, generator=g, device=dev) if epi == 2 else None
+    out = torch.empty((M, 2 * N if epi == 6 else N), dtype=torch.float32 if epi == 2 else torch.float16, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev) if epi == 2 else torch.randn(M, N, generator=g, device=dev).to(torch.float16) if epi == 7 else None
+    if epi == 7:
+        bias = None
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
     dbg = torch.zeros(nblk * SL, dtype=torch.int64, device=dev)
     lib.pv_debug_set_stamp_buffer(dbg.data_ptr())
-    args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr(), out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
-                    row_scale=0, pos=0, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, rows_per_img_in=0, rows_per_img_out=0, row_off=0,
+    args = GemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=bias.data_ptr() if bias is not None else 0, out=out.data_ptr(), res=res.data_ptr() if res is not None else 0,
+                    row_scale=0, pos=0, M=M, N=N, K=K, lda=K, ldw=K, ldo=out.shape[1], ldr=N, rows_per_img_in=0, rows_per_img_out=0, row_off=0,
                     qcols=0, qscale=1.0, epilogue=epi)
     if fold:
         args.bias, args.fold_stat, args.fold_c1, args.fold_c2 = 0, stat.data_ptr(), c1.data_ptr(), bias.data_ptr()

@@ -181,6 +181,48 @@ def test_attention_backward_from_the_forward_statistics(ops, B, S, H, dh, mode):
         assert float(dqkv[..., D:2 * D].double().sum(1).abs().max()) < 3e-3 * float(dqkv[..., D:2 * D].double().abs().sum(1).max())
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("dh", [48, 64])
+@pytest.mark.parametrize("tiles", [9, 10, 11, 12, 13])
+def test_persistent_attention_backward_every_instantiation(ops, tiles, dh, mode):
+    """Round 6 (review item 7): every LDS read of pv_attn_bwd5_kernel's two passes is inline asm behind hand-counted waits, which the static ISA audit
+    checks for today's compiler output only.  This is the FUNCTIONAL check on the GPU over every instantiation the dispatcher can select - 9 ... 13 tiles
+    (a ragged and an exactly full last tile each) x head width 48 / 64 x both operand types x with / without the bias sums - against fp32 autograd,
+    with more items than CUs so that a workgroup walks several (the hand-over between items is where a short wait would show)."""
+    from peekvit_amd import engine, _lib
+    H = 3
+    qscale = dh ** -0.5
+    D = H * dh
+    for S, B in ((16 * tiles - 3, 100), (16 * tiles, 2)):              # 300 items on 256 CUs; 6 items
+        if not ops.attention_bwd_lse_ok(S, dh):
+            assert S < 145 or S > 208                                    # (outside the entry's range: 9 tiles = 129 ... 144 rows go to the two-pass kernel)
+            if not ops.attention_bwd_lse_supported(S, dh):
+                continue
+        with engine.precision(mode):
+            dt = _lib.operand_dtype()
+            qkv = _bf(B, S, 3 * D, seed=S + dh).float()
+            qkv[..., :D] *= qscale
+            qkv = qkv.to(dt)
+            dout = _bf(B, S, D, seed=S + dh + 1, scale=0.1).to(dt)
+            att = torch.empty(B, S, D, dtype=dt, device="cuda")
+            lse = torch.empty(B, H, S, device="cuda")
+            ops.attention(qkv, att, B, S, H, dh, lse=lse)
+            got = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=dt)
+            dbp = torch.full((B, 3 * D), float("nan"), device="cuda")
+            ops.attention_bwd_lse(qkv, dout, att, lse, got, B, S, H, dh, qscale, dbias_partial=dbp)
+            nob = torch.full((B, S, 3 * D), float("nan"), device="cuda", dtype=dt)
+            ops.attention_bwd_lse(qkv, dout, att, lse, nob, B, S, H, dh, qscale)
+            assert torch.isfinite(got.float()).all() and torch.isfinite(dbp).all() and torch.equal(got, nob)
+            n_ref = min(B, 4)                                            # (fp64 autograd on the first and the last images: the items of a workgroup's first and later trips)
+            for sl in (slice(0, n_ref), slice(B - n_ref, B)):
+                ref = _attn_ref(qkv[sl], dout[sl], n_ref, S, H, dh, qscale)
+                for i, name in enumerate("qkv"):
+                    err = rel_l2(got[sl][..., i * D:(i + 1) * D].float(), ref[..., i * D:(i + 1) * D])
+                    assert err < (1e-2 if mode == "bf16" else 1.5e-3), (S, name, err)
+            assert rel_l2(dbp[:, :D], got[..., :D].double().sum(1)) < 2e-6 and float(dbp[:, D:2 * D].abs().max()) == 0.0
+            assert rel_l2(dbp[:, 2 * D:], dout.double().sum(1)) < 2e-6
+
+
 @pytest.mark.parametrize("B,S,H,dh", [(3, 197, 12, 64), (2, 26, 12, 64), (2, 1, 2, 64), (2, 5, 2, 32), (2, 401, 8, 32), (3, 99, 8, 48), (1, 50, 3, 96),
                                       (2, 130, 2, 128)])
 def test_attention_rows_backward(ops, B, S, H, dh):

@@ -563,19 +563,32 @@ def test_contract_self_check_of_mode_auto(monkeypatch):
     import torch.nn.modules.module as _tm
     h = m.encoder.layers[1].register_forward_hook(lambda mod, i, o: seen.append(o.shape[0]))
     he = m.encoder.register_forward_hook(lambda mod, i, o: seen_enc.append(o.shape[0]))
-    hg = _tm.register_module_forward_hook(lambda mod, i, o: seen_global.append(o.shape[0]) if mod is m.encoder.layers[0] else None)
     hooks_before = (m.encoder.layers[1]._forward_hooks, m.encoder._forward_hooks, _tm._global_forward_hooks)
     with torch.no_grad():
         f = m(x)
-    assert seen == [12] and seen_enc == [12] and seen_global == [12] and engine.selfcheck_count == c0 + 4 and torch.equal(f, a)
+    assert seen == [12] and seen_enc == [12] and engine.selfcheck_count == c0 + 4 and torch.equal(f, a)
     # round 6: the probe never touches a hook dictionary - the very same objects, still holding the hooks, all along
     assert all(x_ is y_ for x_, y_ in zip(hooks_before, (m.encoder.layers[1]._forward_hooks, m.encoder._forward_hooks, _tm._global_forward_hooks)))
     assert len(m.encoder.layers[1]._forward_hooks) == 1
+    # ... a process-wide hook as well (it watches the LAST block too, which then computes every row instead of the class rows: same logits within rounding)
+    hg = _tm.register_module_forward_hook(lambda mod, i, o: seen_global.append(o.shape[0]) if mod is m.encoder.layers[0] else None)
+    engine.reset_guard(m)
+    gdict = _tm._global_forward_hooks
+    with torch.no_grad():
+        f2 = m(x)
+    assert seen_global == [12] and seen == [12, 12] and engine.selfcheck_count == c0 + 5 and _tm._global_forward_hooks is gdict and len(gdict) == 1
+    assert rel_l2(f2, a) < 5e-4
     he.remove(); hg.remove()
+    seen.clear()
+    engine.reset_guard(m)
     with torch.no_grad():
         m(x)
+    seen.clear()
+    with torch.no_grad():
+        m(x)
+        m(x)
     h.remove()
-    assert seen == [12, 12] and engine.selfcheck_count == c0 + 4          # the verdict is kept
+    assert seen == [12, 12] and engine.selfcheck_count == c0 + 6          # the verdict is kept
     # periodic re-probe (round 5): every SELFCHECK_EVERY-th guarded forward of a key measures again - an "ok" from the first batch says little
     # about batch 500 - and a later batch that measures outside the limit sends the key to the split-operand arithmetic
     monkeypatch.setattr(engine, "SELFCHECK_EVERY", 3)
@@ -618,3 +631,60 @@ def test_deferred_flag_read_repeats_only_the_batch_that_tripped():
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert torch.isfinite(got[2]).all()
+
+
+def test_mode_auto_replays_a_hipgraph_for_launch_bound_forwards_by_itself(monkeypatch):
+    """Round 6 (review item 8): a launch-bound model forward (vit_tiny at batch 32: ~100 launches of microseconds) is captured by the engine after a few
+    clean eager forwards of the key and replayed from then on - bit-identical logits in fresh tensors - and the graph is dropped the moment what it was
+    captured under changes: a parameter edited in place, a module hook, a guard trip, the knob that switches it off."""
+    from peekvit_amd import autograph, engine
+    cfg, m = _model("vit", "vit_tiny")
+    x = torch.from_numpy(synth.synth_images(32, cfg["image_size"], seed=11)).to(DEV)
+    assert autograph.launch_bound(m, 32)
+    c0, r0 = autograph.captures, autograph.replays
+    with torch.no_grad():
+        outs = [m(x) for _ in range(1 + autograph.WARM + 4)]           # the key's first forward carries the self-check probe; WARM clean forwards; then replays
+    assert autograph.captures == c0 + 1 and autograph.replays == r0 + 4
+    assert all(torch.equal(o, outs[0]) for o in outs) and len({o.data_ptr() for o in outs}) == len(outs)      # same bits, never the same tensor
+    # another input of the key: the replay computes THAT input
+    x2 = torch.from_numpy(synth.synth_images(32, cfg["image_size"], seed=12)).to(DEV)
+    with torch.no_grad():
+        got = m(x2)
+        monkeypatch.setattr(autograph, "ENABLED", False)
+        want = m(x2)
+        monkeypatch.setattr(autograph, "ENABLED", True)
+    assert torch.equal(got, want) and not torch.equal(got, outs[0]) and autograph.replays == r0 + 5
+    # a parameter edited in place (its version counter moves): the graph is dropped, the forward follows the new weights
+    with torch.no_grad():
+        m.head.weight.mul_(2.0)
+        d0 = autograph.drops
+        got = m(x2)
+        assert autograph.drops == d0 + 1 and not torch.equal(got, want)
+        monkeypatch.setattr(autograph, "ENABLED", False)
+        assert torch.equal(got, m(x2))
+        monkeypatch.setattr(autograph, "ENABLED", True)
+        for _ in range(autograph.WARM + 1):
+            m(x2)
+        assert autograph.captures == c0 + 2                                # warm again, captured again
+        # somebody watches the forward: replays stop, the hook sees every forward
+        seen = []
+        h = m.encoder.layers[0].register_forward_hook(lambda mod, i, o: seen.append(1))
+        r1 = autograph.replays
+        m(x2); m(x2)
+        h.remove()
+        assert len(seen) == 2 and autograph.replays == r1
+        # a batch that overflows fp16 inside the replay: answered by the eager path's fallback, as without a graph
+        for _ in range(autograph.WARM + 1):
+            m(x2)
+        r2, f0 = autograph.replays, engine.fallback_count
+        m(x2)
+        assert autograph.replays == r2 + 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            big = m(x2 * 3.0e4)
+            assert engine.fallback_count == f0 + 1
+            with engine.precision("bf16x3"):
+                assert torch.equal(big, m(x2 * 3.0e4))
+    # not launch-bound: never captured
+    cfg_b, mb = _model("vit", "vit_b_16")
+    assert not autograph.launch_bound(mb, 64)
