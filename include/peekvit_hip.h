@@ -98,8 +98,9 @@ int pv_layernorm_bf16(const float* x, int64_t ldx, const float* gamma, const flo
 #define PV_EPI_BIAS_F32 4             /* out f32 = (acc + bias[n]) * (n < qcols ? qscale : 1)           [in-proj, fp32 q|k|v]  */
 #define PV_EPI_BIAS_GELU_SPLIT_BF16 5 /* out bf16 [M, 3N] = [hi | lo | hi] of gelu_erf(acc + bias[n]), ldo >= 3N [MLP fc1]    */
 /* training path (ABI v4): */
-#define PV_EPI_BIAS_GELU_PAIR_BF16  6   /* out bf16 [M, 2N] (ldo >= 2N): cols [0,N) = gelu(acc+bias), cols [N,2N) = acc+bias (saved for backward) */
-#define PV_EPI_GELU_GRAD_BF16       7   /* out bf16 = (acc+bias) * gelu'(pre[m][n]), pre = bf16 matrix passed in `res` (row stride ldr elements) */
+#define PV_EPI_BIAS_GELU_PAIR_BF16  6   /* out bf16 [M, 2N] (ldo >= 2N): cols [0,N) = gelu(acc+bias), cols [N,2N) = gelu'(acc+bias) (saved for backward; ABI v10 -
+                                           * v4-v9 saved acc+bias itself and PV_EPI_GELU_GRAD_BF16 evaluated gelu' from it) */
+#define PV_EPI_GELU_GRAD_BF16       7   /* out bf16 = (acc+bias) * d[m][n], d = the saved gelu' plane of PV_EPI_BIAS_GELU_PAIR_BF16: a 16-bit matrix passed in `res` (row stride ldr elements) */
 
 typedef struct pv_gemm_args {
     /* ABI v7: sizeof(pv_gemm_args) as the CALLER's binding knows it - the first field, so that it can be read whatever the caller's

@@ -92,7 +92,7 @@ SIGNATURES = {
     "pv_residual_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lock = threading.Lock()
 _libs: dict = {}
 

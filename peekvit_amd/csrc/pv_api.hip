@@ -1,7 +1,7 @@
 // ABI identification and error strings of libpeekvit_hip.so.
 #include "pv_common.h"
 
-extern "C" int pv_version(void) { return 9; }
+extern "C" int pv_version(void) { return 10; }
 extern "C" uint64_t pv_gemm_args_size(void) { return (uint64_t)sizeof(pv_gemm_args); }
 extern "C" const char* pv_arch(void) { return "gfx950"; }
 extern "C" int pv_operand_type(void) { return PV_OPERAND_CODE; }      // 0 = bf16 operands, 1 = fp16 operands (libpeekvit_hip_f16.so)

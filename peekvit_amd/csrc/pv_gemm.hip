@@ -150,15 +150,30 @@ __device__ __forceinline__ void pv_gelu_lut2(float& x0, float& x1, const __attri
     x0 = pv_gelu_poly(x0, c0); x1 = pv_gelu_poly(x1, c1);
 }
 
-// gelu'(x) = Phi(x) + x * phi(x) from its own table on the same grid (pv_gelu_grad_tab): the same 7 VALU + one gather
-template <typename TabPtr>
-__device__ __forceinline__ float pv_gelu_grad_lut(float x, TabPtr tab) {
-    float t = fmaf(x, 256.0f, 2048.0f);
-    t = __builtin_amdgcn_fmed3f(t, 0.0f, 4095.9998f);
-    const int i = (int)t;
-    const float fr = t - (float)i;
-    const pv_f32x2_t e = tab[i];
-    return fmaf(fr, e[1], e[0]);
+// gelu'(x) for the training pair epilogue (round 6): the DERIVATIVE OF THE INTERVAL'S CUBIC, c1 + x (2 c2 + 3 c3 x), from the very table entry the
+// forward GELU gathers - no second table, no second gather.  Against fp64 gelu'(x) = Phi(x) + x phi(x): |error| <= 1.0e-4 (the derivative of a fit is
+// one order less accurate than the fit: 8e-7), relative L2 1.2e-5 - a quarter of the rounding of the 16-bit plane it is stored in.  Rounds 1-5 saved the
+// pre-activation instead and evaluated gelu' in the DATA-GRADIENT GEMM's epilogue from a 4096-entry linear table: 23.4 k ticks per 256^2 tile against
+// 6.4 k for a plain 16-bit epilogue (profiles/r06_gemm_stamps_train.txt: ~45 vector instructions and four gathers per row of eight rows of four
+// passes); a conflict-free cubic table there measured 26.2 k.  Now that epilogue multiplies by the saved derivative.
+// Scalar arithmetic (the 128^2 kernel evaluates it under in-flight register loads; every kernel rounds an element identically).
+__device__ __forceinline__ float pv_gelu_dpoly(float x, const f32x4 c) {        // c = {c0, c2, c1, c3}
+    const float t = pv_fma_s(pv_mul_s(c[3], 3.0f), x, pv_add_s(c[1], c[1]));      // (3 c3, not 3 x: the outermost entries have c3 = 0, and 0 * (3 x) would be NaN once 3 x overflows)
+    return pv_fma_s(x, t, c[2]);
+}
+__device__ __forceinline__ void pv_gelu_dlut2(float& x0, float& x1, const f32x4* tab) {          // table in global memory, two values in place
+    uint32_t b0, b1;
+    pv_gelu_bits2(x0, x1, b0, b1);
+    const f32x4 c0 = tab[(b0 - 0x4B400000u) * PV_GELU_CUB_REP], c1 = tab[(b1 - 0x4B400000u) * PV_GELU_CUB_REP];
+    x0 = pv_gelu_dpoly(x0, c0); x1 = pv_gelu_dpoly(x1, c1);
+}
+__device__ __forceinline__ void pv_gelu_dlut2(float& x0, float& x1, const __attribute__((address_space(3))) f32x4* tab) {   // table in LDS
+    uint32_t b0, b1;
+    pv_gelu_bits2(x0, x1, b0, b1);
+    const uint32_t base = (uint32_t)(uintptr_t)tab - 0x40000000u;
+    const f32x4 c0 = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)((b0 << 8) + base);
+    const f32x4 c1 = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)((b1 << 8) + base);
+    x0 = pv_gelu_dpoly(x0, c0); x1 = pv_gelu_dpoly(x1, c1);
 }
 
 struct GemmDev {
@@ -296,15 +311,13 @@ __device__ __forceinline__ void pv_epilogue_store(const GemmDev& p, int m, int n
     } else if (EPI == PV_EPI_BIAS_GELU_PAIR_BF16) {
         const f32x4* tab = reinterpret_cast<const f32x4*>(pv_gelu_cub) + (threadIdx.x & 15);
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
-        float y0 = v0, y1 = v1, y2 = v2, y3 = v3;
+        float y0 = v0, y1 = v1, y2 = v2, y3 = v3, d0 = v0, d1 = v1, d2 = v2, d3 = v3;
         pv_gelu_lut2(y0, y1, tab); pv_gelu_lut2(y2, y3, tab);
-        *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2(y0, y1), pv_pack_bf16x2(y2, y3)};
-        *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(v0, v1), pv_pack_bf16x2(v2, v3)};
+        pv_gelu_dlut2(d0, d1, tab); pv_gelu_dlut2(d2, d3, tab);
+        *reinterpret_cast<u32x2*>(o) = (u32x2){pv_pack_bf16x2_tracked(y0, y1, vmax), pv_pack_bf16x2_tracked(y2, y3, vmax)};
+        *reinterpret_cast<u32x2*>(o + p.N) = (u32x2){pv_pack_bf16x2(d0, d1), pv_pack_bf16x2(d2, d3)};
     } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
-        const pv_f32x2_t* tab = reinterpret_cast<const pv_f32x2_t*>(pv_gelu_grad_tab);
-        const float x0 = r[0], x1 = r[1], x2 = r[2], x3 = r[3];
-        u32x2 o = {pv_pack_bf16x2(v0 * pv_gelu_grad_lut(x0, tab), v1 * pv_gelu_grad_lut(x1, tab)),
-                   pv_pack_bf16x2(v2 * pv_gelu_grad_lut(x2, tab), v3 * pv_gelu_grad_lut(x3, tab))};
+        u32x2 o = {pv_pack_bf16x2(pv_mul_s(v0, r[0]), pv_mul_s(v1, r[1])), pv_pack_bf16x2(pv_mul_s(v2, r[2]), pv_mul_s(v3, r[3]))};      // r = the saved gelu'(pre)
         *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = o;
     } else {   // PV_EPI_BIAS_POS_F32
         const int img = m / p.rpi, pi = m - img * p.rpi;
@@ -679,16 +692,16 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
     }
     if (own_tile0) { stage_a(0, 0, 0); stage_a(0, 1, 0); stage_b(0, 0, 0); stage_b(0, 1, 0); }
     stage_a(1, 0, 1); stage_a(1, 1, 1);
-    constexpr bool HAS_TAB = EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16;
-    constexpr int NTAB = HAS_TAB ? (EPI == PV_EPI_GELU_GRAD_BF16 ? 4 : 2) : 0;
+    constexpr bool HAS_TAB = EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+    constexpr int NTAB = HAS_TAB ? 2 : 0;
     if (HAS_TAB && own_tile0) {
-        // GELU table (16 KiB replicated cubic; 32 KiB linear table for gelu') into the LDS above the staging buffers.  Issued AFTER the
+        // GELU table (16 KiB replicated cubic) into the LDS above the staging buffers.  Issued AFTER the
         // first K tiles (round 3; round 2 issued it first, so the K loop could not start before the table had landed: fc1's prologue took
         // 4.0 k cycles against QKV's 2.4 k): the wait below leaves it in flight, and the first counted wait of the K loop - which leaves
         // only the 4 youngest operations, all issued later - covers it long before the epilogue reads it.
 #pragma unroll
         for (int i = 0; i < NTAB; ++i)
-            pv_glds16(reinterpret_cast<const char*>(EPI == PV_EPI_GELU_GRAD_BF16 ? pv_gelu_grad_tab : pv_gelu_cub) + (i * 512 + tid) * 16,
+            pv_glds16(reinterpret_cast<const char*>(pv_gelu_cub) + (i * 512 + tid) * 16,
                       smem + G2_LDS + (i * 512 + wid * 64) * 16);
     }
     // LayerNorm folding (consumer): the tile's row statistics [256][2] and column constants c1[256], c2[256] (4 KiB) behind the table,
@@ -779,9 +792,11 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         float vmax = 0.f;          // operand-range guard (fp16 build): largest magnitude this lane packs
         const bool fold = p.fold_stat != nullptr;
         constexpr int FOLD_BASE = G2_LDS + (EPI != PV_EPI_BIAS_BF16 ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0);
-        // PAIR (training forward of fc1): TWO output planes from the same accumulators - 32 virtual units: units 0-15 pack the raw
-        // pre-activation (plane 1 of the [M, 2N] output, saved for backward), units 16-31 its GELU (plane 0); the image regions are reused
-        // four passes later, three barriers after they were read back
+        // PAIR (training forward of fc1): TWO output planes from the same accumulators - 32 virtual units, PLANE-MINOR (round 6): virtual unit vn is
+        // accumulator unit n = vn >> 1, plane vn & 1 - plane 0 its GELU, plane 1 gelu'(pre-activation) = the derivative of the SAME gathered cubic (saved
+        // for backward; rounds 1-5 packed the raw pre-activation in units 0-15 and the GELU in units 16-31).  One set of gathers per accumulator unit
+        // serves both planes (issued two virtual units ahead).  A pass (4 virtual units) is now ONE 16-row tile of both wave groups x both planes:
+        // 64 image row slots = plane * 32 + wave group * 16 + row; waves 0-3 read back and store plane 0, waves 4-7 plane 1; 8 passes.
         constexpr bool PAIR2 = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
         constexpr int NU = PAIR2 ? 32 : 16;
         if (fold) {
@@ -811,7 +826,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         PV_STAMP(8);
         const uint32_t tabc = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16) - 0x40000000u;
         const bool ocol_ok = n0 + (lane & 31) * 8 < p.N;
-        const int rb_row0 = (wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5);      // + 32 q + 2 j: the rows this wave stores in pass q
+        // + 32 q + 2 j: the rows this wave stores in pass q (PAIR: + 16 q + 2 j, wave group (wid >> 1) & 1, rows (wid & 1) * 8 .. of the pass's 16-row tile)
+        const int rb_row0 = (EPI == PV_EPI_BIAS_GELU_PAIR_BF16 ? ((wid >> 1) & 1) * 128 + (wid & 1) * 8 : (wid >> 2) * 128 + (wid & 3) * 8) + (lane >> 5);
         // The image of a pass: 64 rows x 512 B = 32 KiB, local row lr = (wave group) * 32 + (tile row % 32); two such regions alternate
         // (pass q -> region q & 1) inside K-tile buffer 1 ONLY: buffer 0 stays free, so the prefetching launch can stage the next
         // tile's first K-tile into it while this epilogue runs.  Region q & 1 is rewritten in pass q + 2, after barrier q + 1 - by
@@ -827,16 +843,20 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         f32x4 cf[2][8];            // gathered table entries of two units in flight (GELU units only)
         u32x4 rb[4];               // rows read back from the image, waiting for their store slot
         // virtual unit vn: accumulator unit n = vn & 15 (16-row tile mt = n >> 1, column half u = n & 1), plane vn >> 4
-        auto unit_x = [&](int vn, int e) -> float { return acc[2 * (vn & 1) + (e >> 2)][(vn & 15) >> 1][e & 3]; };
-        auto is_gelu = [&](int vn) -> bool { return EPI == PV_EPI_BIAS_GELU_BF16 || (PAIR2 && vn >= 16); };
+        auto acc_unit = [&](int vn) -> int { return PAIR2 ? vn >> 1 : vn; };                           // accumulator unit: 16-row tile mt = n >> 1, column half u = n & 1
+        auto cf_slot = [&](int vn) -> int { return acc_unit(vn) & 1; };
+        auto unit_x = [&](int vn, int e) -> float { const int n = acc_unit(vn); return acc[2 * (n & 1) + (e >> 2)][n >> 1][e & 3]; };
+        auto is_gelu = [&](int vn) -> bool { return EPI == PV_EPI_BIAS_GELU_BF16 || PAIR2; };         // units that evaluate a table entry per value
+        auto gathers = [&](int vn) -> bool { return EPI == PV_EPI_BIAS_GELU_BF16 || (PAIR2 && (vn & 1) == 0); };      // ... and ISSUE its gathers (PAIR: once per accumulator unit)
+        auto is_deriv = [&](int vn) -> bool { return PAIR2 && (vn & 1) == 1; };
         auto issue = [&](int vn) __attribute__((always_inline)) {
-            if (is_gelu(vn)) {
+            if (gathers(vn)) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     uint32_t b0, b1;
                     pv_gelu_bits2(unit_x(vn, e), unit_x(vn, e + 1), b0, b1);
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[vn & 1][e]) : "v"((b0 << 8) + tabc));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[vn & 1][e + 1]) : "v"((b1 << 8) + tabc));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[cf_slot(vn)][e]) : "v"((b0 << 8) + tabc));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cf[cf_slot(vn)][e + 1]) : "v"((b1 << 8) + tabc));
                 }
             }
         };
@@ -845,8 +865,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // statement, so no consumer can be scheduled above it.  with_rb: the read-back registers are threaded through as well (first
         // unit after a read-back).
         auto wait_unit = [&](int vn, bool next_in_flight, bool with_rb) __attribute__((always_inline)) {
-            if (is_gelu(vn)) {
-                f32x4(&c)[8] = cf[vn & 1];
+            if (gathers(vn)) {
+                f32x4(&c)[8] = cf[cf_slot(vn)];
                 if (next_in_flight && with_rb)
                     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                                  "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
@@ -863,23 +883,36 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             }
         };
         auto finish = [&](int vn) __attribute__((always_inline)) {
-            const int n = vn & 15, mt = n >> 1, u = n & 1;
+            const int n = acc_unit(vn), mt = n >> 1, u = n & 1;
             float y[8];
             if (is_gelu(vn)) {
                 // pv_gelu_poly for the 8 values in lock step (step by step ACROSS the values): no instruction depends on its predecessor,
                 // so the wave issues back to back (value by value, hipcc padded every dependent pair of asm steps with an s_nop)
                 float x[8];
+                if (is_deriv(vn)) {
+                    // pv_gelu_dpoly in lock step: c1 + x (2 c2 + 3 c3 x) from the entry {c0, c2, c1, c3}
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { x[e] = unit_x(vn, e); y[e] = pv_mul_s(cf[cf_slot(vn)][e][3], 3.0f); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = pv_add_s(cf[cf_slot(vn)][e][1], cf[cf_slot(vn)][e][1]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = pv_fma_s(y[e], x[e], t[e]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = pv_fma_s(x[e], t[e], cf[cf_slot(vn)][e][2]);
+                } else {
                 pv_f32x2_t r[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     x[e] = unit_x(vn, e);
-                    const f32x4 c = cf[vn & 1][e];
+                    const f32x4 c = cf[cf_slot(vn)][e];
                     r[e] = __builtin_elementwise_fma((pv_f32x2_t){c[2], c[3]}, (pv_f32x2_t){x[e], x[e]}, (pv_f32x2_t){c[0], c[1]});
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = pv_mul_s(x[e], r[e][1]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = pv_fma_s(x[e], y[e], r[e][0]);
+                }
             } else {
                 // the lane's 8 consecutive columns start at en0 + 32u: q-scaling is uniform per such chunk (qcols % 8 == 0)
                 const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
@@ -888,8 +921,10 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             }
             const u32x4 pk = {pv_pack_bf16x2_tracked(y[0], y[1], vmax), pv_pack_bf16x2_tracked(y[2], y[3], vmax),
                               pv_pack_bf16x2_tracked(y[4], y[5], vmax), pv_pack_bf16x2_tracked(y[6], y[7], vmax)};
-            const int lrow = wr * 32 + (mt & 1) * 16 + i16, c = wc * 8 + u * 4 + g;
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(img + ((mt >> 1) & 1) * 32768 + lrow * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
+            // image slot of the row: pass = 4 virtual units -> region (pass & 1); rows of the pass: two 16-row tiles of both wave groups (PAIR: one tile x both planes)
+            const int lrow = PAIR2 ? (vn & 1) * 32 + wr * 16 + i16 : wr * 32 + (mt & 1) * 16 + i16, c = wc * 8 + u * 4 + g;
+            const int region = PAIR2 ? mt & 1 : (mt >> 1) & 1;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(img + region * 32768 + lrow * 512 + ((c ^ (i16 & 7)) << 4)) = pk;
         };
         // Output addresses (round 4).  The stores of this epilogue leave in a fixed order (pass by pass, four 2-row stores per wave and pass), so
         // ONE running per-lane pointer walks them: first row of the wave + (lane >> 5) rows + (lane & 31) 16-byte chunks, advanced after every
@@ -900,21 +935,22 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // (a workgroup-uniform 64-bit base in scalar registers + ONE 32-bit running byte offset per lane: the tile spans < 4 MiB)
         const uint32_t row_bytes = (uint32_t)p.ldo * 2u;
         char* const obase = reinterpret_cast<char*>(p.out) + ((int64_t)m0 * p.ldo + n0) * 2;
-        uint32_t ooff = (uint32_t)((wid >> 2) * 128 + (wid & 3) * 8 + (lane >> 5)) * row_bytes + (uint32_t)(lane & 31) * 16u
-                        + (PAIR2 ? (uint32_t)p.N * 2u : 0u);                               // (the pair's raw plane goes first)
+        uint32_t ooff = (uint32_t)rb_row0 * row_bytes + (uint32_t)(lane & 31) * 16u
+                        + ((PAIR2 && wid >= 4) ? (uint32_t)p.N * 2u : 0u);                 // (the pair: waves 4-7 store the derivative plane, N columns to the right)
         {
-            auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // virtual pass vq: image region vq & 3, plane vq >> 2
-                if (FULL || (m0 + rb_row0 + 32 * (vq & 3) + 2 * j < p.M && ocol_ok)) PV_STORE16(reinterpret_cast<u32x4*>(obase + ooff), rb[j]);
-                // to the next store in program order: (vq, j + 1), else (vq + 1, 0) - which for the pair's fifth pass is row 0 of the OTHER plane
+            auto store_row = [&](int vq, int j) __attribute__((always_inline)) {       // pass vq (PAIR: 16 tile rows per pass, otherwise 32)
+                if (FULL || (m0 + rb_row0 + (PAIR2 ? 16 : 32) * vq + 2 * j < p.M && ocol_ok)) PV_STORE16(reinterpret_cast<u32x4*>(obase + ooff), rb[j]);
+                // to the next store in program order: (vq, j + 1), else (vq + 1, 0)
                 if (j < 3) ooff += 2u * row_bytes;
-                else if (PAIR2 && vq == 3) ooff -= 102u * row_bytes + (uint32_t)p.N * 2u;
-                else ooff += 26u * row_bytes;
+                else ooff += (PAIR2 ? 10u : 26u) * row_bytes;
             };
             issue(0);
 #pragma unroll
             for (int vn = 0; vn < NU; ++vn) {
                 const int vq = vn >> 2;
-                if (vn + 1 < NU) issue(vn + 1);
+                // the next accumulator unit's gathers fly under this one's arithmetic (PAIR: under both planes of it)
+                if (PAIR2) { if ((vn & 1) == 0 && vn + 2 < NU) issue(vn + 2); }
+                else if (vn + 1 < NU) issue(vn + 1);
                 if (PFM == 2 && vn < 4 && pf_next) {
                     // the next tile's first K-tile, two pieces per unit of the first pass: the memory path is idle until the first store (unit 4),
                     // and a burst of all 64 KiB at the start of the epilogue held every wave at the ISSUE of its loads for ~1 k cycles (stamps)
@@ -922,7 +958,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     stage_next_piece(nm0, nn0, 2 * vn);
                     stage_next_piece(nm0, nn0, 2 * vn + 1);
                 }
-                wait_unit(vn, vn + 1 < NU && is_gelu(vn + 1), vq > 0 && (vn & 3) == 0);
+                wait_unit(vn, PAIR2 ? vn + 2 < NU : (vn + 1 < NU && gathers(vn + 1)), vq > 0 && (vn & 3) == 0);
                 finish(vn);
                 if (PFM == 1 && vn == 4 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 has landed (before any store)
                 if (vq > 0) store_row(vq - 1, vn & 3);                  // one 1-KiB store of the previous pass per unit
@@ -946,7 +982,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // bf16 image: 256 rows x 512 B, 16-B chunk c of row r stored at chunk c ^ (r & 7).  SPLIT (precision mode): the fp32
         // results stay in the accumulators; pass 0 stores their bf16 "hi" image to planes 0 and 2 of the [M, 3N] output, pass 1
         // the "lo" image (v - hi) to plane 1.
-        // PAIR (training forward): pass 0 stores bf16 of the raw pre-activation to plane 1 of the [M, 2N] output, pass 1 its GELU to plane 0.
+        // PAIR (training forward): pass 0 stores gelu'(pre-activation) to plane 1 of the [M, 2N] output, pass 1 its GELU to plane 0.
         constexpr bool SPLIT = EPI == PV_EPI_BIAS_GELU_SPLIT_BF16;
         constexpr bool PAIR = EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
         float vmax = 0.f;          // operand-range guard (fp16 build): largest magnitude this lane packs
@@ -1000,12 +1036,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     const float qs = (EPI == PV_EPI_BIAS_BF16 && en0 + u * 32 < p.qcols) ? p.qscale : 1.0f;
                     u32x4 pk;
                     if (PAIR) {
-                        if (pass == 1) {
+                        {
                             const __attribute__((address_space(3))) f32x4* tab = (const __attribute__((address_space(3))) f32x4*)(cimg + G2_LDS) + i16;
 #pragma unroll
                             for (int e = 0; e < 4; e += 2) {
                                 float t0 = lo[e], t1 = lo[e + 1], t2 = hi[e], t3 = hi[e + 1];
-                                pv_gelu_lut2(t0, t1, tab); pv_gelu_lut2(t2, t3, tab);
+                                if (pass == 1) { pv_gelu_lut2(t0, t1, tab); pv_gelu_lut2(t2, t3, tab); }
+                                else { pv_gelu_dlut2(t0, t1, tab); pv_gelu_dlut2(t2, t3, tab); }
                                 lo[e] = t0; lo[e + 1] = t1; hi[e] = t2; hi[e + 1] = t3;
                             }
                         }
@@ -1091,7 +1128,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 f32x4& r = rr[q & 1][j];
                 if (EPI == PV_EPI_BIAS_F32) {
                     r = (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved bf16 pre-activation row, 512 B per instruction
+                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved 16-bit gelu'(pre-activation) row, 512 B per instruction
                     const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + ncol);
                     r = (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]), pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
@@ -1144,9 +1181,7 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                     const float qs = ncol < p.qcols ? p.qscale : 1.0f;
                     o = (f32x4){v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs};
                 } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
-                    const __attribute__((address_space(3))) pv_f32x2_t* tab = (const __attribute__((address_space(3))) pv_f32x2_t*)(cimg + G2_LDS);
-                    o = (f32x4){v[0] * pv_gelu_grad_lut(r[0], tab), v[1] * pv_gelu_grad_lut(r[1], tab),
-                                v[2] * pv_gelu_grad_lut(r[2], tab), v[3] * pv_gelu_grad_lut(r[3], tab)};
+                    o = (f32x4){pv_mul_s(v[0], r[0]), pv_mul_s(v[1], r[1]), pv_mul_s(v[2], r[2]), pv_mul_s(v[3], r[3])};      // (scalar: the next rows are still returning)
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     const float tr = p.res_scaled ? sc : 1.0f;
                     o = (f32x4){fmaf(sc, v[0], tr * r[0]), fmaf(sc, v[1], tr * r[1]), fmaf(sc, v[2], tr * r[2]), fmaf(sc, v[3], tr * r[3])};
@@ -1637,11 +1672,10 @@ static int pv_cu_count() {              // per device (the current one = the str
 template <int EPI>
 static int pv_launch_gemm256(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;
-    constexpr int lds = G2_LDS + (EPI == PV_EPI_GELU_GRAD_BF16 ? PV_GELU_TAB_N * 8      // + 32 KiB gelu' table = all 160 KiB
-                                  : (EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)
+    constexpr int lds = G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16)
                                         ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0)                   // + 16 KiB replicated cubic GELU table
                         + ((EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) ? 4096 : 0);         // + 4 KiB folded-LayerNorm constants
-    // (persistent launch: + 1 KiB of bias values behind the table and the fold slot; the gelu' epilogue has neither bias nor room)
+    // (persistent launch: + 1 KiB of bias values behind the table and the fold slot; the gelu' epilogue has no bias)
     constexpr int lds_pf = EPI == PV_EPI_GELU_GRAD_BF16 ? lds
                          : G2_LDS + ((EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_SPLIT_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16) ? PV_GELU_CUB_N * PV_GELU_CUB_REP * 16 : 0) + 4096 + 1024;
     // the prefetching persistent launch: every epilogue but the one-pass forms (bf16x3's SPLIT; -DPV_EPI_PIPE=0 builds) keeps buffer 0 free

@@ -4,10 +4,10 @@ autograd Functions so that the reference's loop (train/train.py:112-121: `out = 
 
 Per encoder block (reference models/vit.py:45-55), R = B*S token rows:
   forward   h1 = LN1(x) | qkv = h1.Win^T+b (q pre-scaled) | att = attention(qkv) | x1 = x + att.Wo^T+b | h2 = LN2(x1)
-            [gl | pre] = fc1 epilogue pair: pre = h2.W1^T+b, gl = gelu(pre) | out = x1 + gl.W2^T+b
-                                                                         saved: x, h1, qkv, att, x1, h2, [gl | pre]
+            [gl | dgl] = fc1 epilogue pair: pre = h2.W1^T+b, gl = gelu(pre), dgl = gelu'(pre) | out = x1 + gl.W2^T+b
+                                                                         saved: x, h1, qkv, att, x1, h2, [gl | dgl]
   backward  d2 = bf16(dout)
-            dpre = (d2.W2)*gelu'(pre)  [one GEMM, PV_EPI_GELU_GRAD_BF16]      dW2 = d2^T.gl     db2 = colsum(d2)
+            dpre = (d2.W2)*dgl         [one GEMM, PV_EPI_GELU_GRAD_BF16]      dW2 = d2^T.gl     db2 = colsum(d2)
             dh2 = dpre.W1      dW1 = dpre^T.h2   db1 = colsum(dpre)
             dx1 = dout + LN2'(dh2)               (dgamma2, dbeta2)
             d1 = bf16(dx1)
@@ -601,7 +601,7 @@ class BlockFn(torch.autograd.Function):
         att = torch.empty((R, D), dtype=bf, device=dev)
         x1 = torch.empty((B, S, D), dtype=torch.float32, device=dev)
         h2 = torch.empty((R, D), dtype=bf, device=dev)
-        pair = torch.empty((R, 2 * Mh), dtype=bf, device=dev)           # [gelu(pre) | pre]: one fc1 epilogue writes both
+        pair = torch.empty((R, 2 * Mh), dtype=bf, device=dev)           # [gelu(pre) | gelu'(pre)]: one fc1 epilogue writes both (round 6: the derivative, not the pre-activation)
         gl, pre = pair[:, :Mh], pair[:, Mh:]
         out = torch.empty_like(x)
         qscale = float(dh) ** -0.5
@@ -649,7 +649,7 @@ class BlockFn(torch.autograd.Function):
             db2 = db2c if db2 is None else db2
         elif need["b2"] and db2 is None:
             db2 = ops.colsum(d2, torch.empty((D,), dtype=torch.float32, device=dev))
-        dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * gelu'(pre), fused in the epilogue
+        dpre = ws.get("bw_dgl", (R, Mh), bf, dev)                               # (d2 . W2) * the saved gelu'(pre), fused in the epilogue
         db1 = torch.empty((Mh,), dtype=torch.float32, device=dev) if need["b1"] else None
         ops.gemm(d2, bf16_weight_t(blk.mlp.fc2.weight), None, dpre, PV_EPI_GELU_GRAD_BF16, M=R, res=pre, tag="[dgrad]", colsum_out=db1)
         dw1 = _wgrad(dpre, h2, "fc1", bias_grad=False)[0] if need["w1"] else None
@@ -868,7 +868,7 @@ class RowsBlockFn(torch.autograd.Function):
     the reference's backward through them multiplies zeros.  All-token work left: LN1, the k|v two thirds of the in-projection and their
     backward; everything else runs on B rows.
       forward   h1 = LN1(x) | kv = h1.Wkv^T+b | q = h1[cls].Wq^T+b (scaled) | att = attention_rows(q, kv) | x1 = x[cls] + att.Wo^T+b
-                h2 = LN2(x1) | [gl | pre] = fc1 pair | out = x1 + gl.W2^T+b                  saved: x, h1, kv, q, att, x1, h2, [gl | pre]
+                h2 = LN2(x1) | [gl | dgl] = fc1 pair | out = x1 + gl.W2^T+b                  saved: x, h1, kv, q, att, x1, h2, [gl | dgl]
       backward  as BlockFn on B rows down to datt; (dq, dkv) = attention_rows'(q, kv, att, datt); dWin = [dq^T.h1[cls] ; dkv^T.h1];
                 dh1 = dkv.Wkv (+ dq.Wq on the class rows); dx = LN1'(dh1) (+ dx1 on the class rows)."""
 

@@ -20,10 +20,10 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pv_[a-z0-9_]+)\s*\(", header)) - {"pv_gemm_args"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                                   # dlopen + getattr of every symbol (no compute call)
-    assert lib.pv_version() == _lib.ABI_VERSION == 9 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
+    assert lib.pv_version() == _lib.ABI_VERSION == 10 and lib.pv_arch() == b"gfx950" and lib.pv_operand_type() == 0
     assert b"launch" in lib.pv_error_string(-3)
     lib16 = _lib.load("f16")                            # the fp16-operand build of the same sources exports the same ABI
-    assert lib16.pv_version() == 9 and lib16.pv_operand_type() == 1
+    assert lib16.pv_version() == 10 and lib16.pv_operand_type() == 1
 
 
 def _header_gemm_fields():
