@@ -334,6 +334,13 @@ int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_
  * rowsq fp32 [tiles, B*S] over the rows of x[B,S,D] (row 0 of every image = class token, not ranked); norm of token i of image b
  * = sqrt(sum_t rowsq[t][b*S + 1 + i]).  keep int32 [B,k] as pv_rank_topk (N = S-1 <= 4096). */
 int pv_rank_topk_partials(const float* rowsq, int64_t tiles, int32_t* keep, int64_t B, int64_t S, int64_t k, void* stream);
+/* The same two rankings that also report each image's keep BOUNDARY (ABI v10): gap_min fp32 [B] (device, optional) is lowered to
+ * min(gap_min[b], (n_{k-1} - n_k) / n_{k-1}), the relative gap between the image's last kept and first dropped norm (untouched when k == N).  The caller
+ * fills it with +inf before the forward and passes the same array to every ranked layer: what remains is the narrowest boundary an image crossed.
+ * models/rankvit.py:63-77 ranks fp32 norms; here they carry the 16-bit layers' rounding (~1e-4 relative), so an image whose gap is of that size may keep
+ * another token than the reference - the host side repairs exactly those images in split precision when asked to (PEEKVIT_AMD_RANK_REPAIR). */
+int pv_rank_topk_gap(const float* norms, int32_t* keep, float* gap_min, int64_t B, int64_t N, int64_t k, void* stream);
+int pv_rank_topk_partials_gap(const float* rowsq, int64_t tiles, int32_t* keep, float* gap_min, int64_t B, int64_t S, int64_t k, void* stream);
 
 /* Compaction gather: models/rankvit.py:71,75-77 gather + slice + cat class token.
  * x fp32 [B,S_in,D], keep int32 [B,k] (indices into rows 1..S_in-1, i.e. 0-based among non-CLS tokens)

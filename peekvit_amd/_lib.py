@@ -87,6 +87,8 @@ SIGNATURES = {
     "pv_token_norm": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
     "pv_rank_topk": (C.c_int, [_p, _p, _i64, _i64, _i64, _p]),
     "pv_rank_topk_partials": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "pv_rank_topk_gap": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "pv_rank_topk_partials_gap": (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "pv_gather_tokens": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "pv_residual_gate": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _p]),
     "pv_residual_gate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _p]),

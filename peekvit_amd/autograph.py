@@ -59,6 +59,7 @@ def _knobs():
     from . import engine, ops
     return (engine._STREAMS, engine.LOCAL_FALLBACK, engine.SELFCHECK_IMAGES, engine.SELFCHECK_LIMIT, engine.RANK_STRICT, engine._FUSE_LN, engine._FULLROW_LN,
             engine._FOLD_LN, engine._FUSE_RANK_NORM, engine._SMALL_M_SPLITK, engine._LAST_BLOCK_ROWS, engine._GATE_NO_MASKED, engine.FALLBACK_MODE,
+            engine.RANK_REPAIR, engine.RANK_TIE_GAP,
             getattr(ops, "knob_epoch", 0))
 
 
@@ -111,7 +112,7 @@ def _entry(owner: nn.Module, x: torch.Tensor, probe_key, st, create: bool) -> Op
     key = (probe_key, tuple(x.shape), x.dtype, x.device.index)
     ent = graphs.get(key)
     if ent is None and create:
-        if not launch_bound(owner, int(x.shape[0])):
+        if getattr(owner, "_pv_no_autograph", False) or not launch_bound(owner, int(x.shape[0])):      # (a forward with a host decision inside: RankViT's near-tie repair)
             return None
         while len(graphs) >= MAX_GRAPHS:
             graphs.pop(next(iter(graphs)))

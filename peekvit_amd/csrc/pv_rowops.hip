@@ -966,10 +966,27 @@ __device__ __forceinline__ uint32_t pv_sort_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// The keep BOUNDARY of an image (round 6): the relative gap between its last kept norm (rank k - 1) and its first dropped one (rank k),
+// (n_{k-1} - n_k) / n_{k-1}.  The ranking is a discrete decision on norms that carry the 16-bit layers' noise (~1e-4 relative): an image whose gap is
+// of that size may keep another token than the reference's fp32 arithmetic does.  gap_min[b] = min(gap_min[b], gap): the caller fills it with +inf and
+// hands the same array to every ranked layer of a forward - what is left is each image's narrowest boundary (peekvit_amd.models.rankvit repairs those
+// images in split precision when asked to).  The two threads that own ranks k - 1 and k leave their norms in LDS; thread 0 folds them in.
+__device__ __forceinline__ float pv_unsort_key(uint32_t u) {
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ void pv_rank_gap(const uint32_t* edge, float* __restrict__ gap_min, int64_t b, int N, int k) {
+    if (gap_min && threadIdx.x == 0 && k < N) {
+        const float hi = pv_unsort_key(edge[0]), lo = pv_unsort_key(edge[1]);
+        const float gap = hi > 0.f ? (hi - lo) / hi : 0.f;
+        if (gap < gap_min[b]) gap_min[b] = gap;          // (one workgroup per image, launches of a forward in stream order: no race)
+    }
+}
+
 // one workgroup per image: keys in LDS, rank_i = #{j : key_j > key_i or (key_j == key_i and j < i)} (stable descending)
-__global__ __launch_bounds__(256) void pv_rank_topk_kernel(const float* __restrict__ norms, int32_t* __restrict__ keep, int N, int k) {
+__global__ __launch_bounds__(256) void pv_rank_topk_kernel(const float* __restrict__ norms, int32_t* __restrict__ keep, float* __restrict__ gap_min, int N, int k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* edge = keys + N;                           // [2]: the keys of rank k - 1 and rank k
     const int64_t b = blockIdx.x;
     for (int i = threadIdx.x; i < N; i += 256) keys[i] = pv_sort_key(norms[b * N + i]);
     __syncthreads();
@@ -981,24 +998,31 @@ __global__ __launch_bounds__(256) void pv_rank_topk_kernel(const float* __restri
             rank += (kj > ki) || (kj == ki && j < i);
         }
         if (rank < k) keep[b * k + rank] = i;
+        if (rank == k - 1) edge[0] = ki;
+        if (rank == k) edge[1] = ki;
     }
+    if (gap_min) { __syncthreads(); pv_rank_gap(edge, gap_min, b, N, k); }
 }
 
-extern "C" int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_t k, void* stream) {
+extern "C" int pv_rank_topk_gap(const float* norms, int32_t* keep, float* gap_min, int64_t B, int64_t N, int64_t k, void* stream) {
     if (!norms || !keep || B <= 0 || N <= 0 || k < 0 || k > N) return PV_ERR_INVALID_ARG;
     if (N > 4096) return PV_ERR_UNSUPPORTED;
     if (k == 0) return PV_OK;
-    PV_LAUNCH(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)N * 4, (hipStream_t)stream, norms, keep, (int)N, (int)k);
+    PV_LAUNCH(pv_rank_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)(N + 2) * 4, (hipStream_t)stream, norms, keep, gap_min, (int)N, (int)k);
     return pv_check_launch();
+}
+extern "C" int pv_rank_topk(const float* norms, int32_t* keep, int64_t B, int64_t N, int64_t k, void* stream) {
+    return pv_rank_topk_gap(norms, keep, nullptr, B, N, k, stream);
 }
 
 // the same ranking with the norms assembled from a producer GEMM's per-column-tile sums of squares (no pass over the tokens)
 __global__ __launch_bounds__(256) void pv_rank_topk_partials_kernel(const float* __restrict__ rowsq, int tiles, int64_t rows, int32_t* __restrict__ keep,
-                                                                    int S, int k) {
+                                                                    float* __restrict__ gap_min, int S, int k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
     const int64_t b = blockIdx.x;
     const int N = S - 1;
+    uint32_t* edge = keys + N;
     for (int i = threadIdx.x; i < N; i += 256) {
         float s = 0.f;
         for (int t = 0; t < tiles; ++t) s += rowsq[(int64_t)t * rows + b * S + 1 + i];
@@ -1013,16 +1037,22 @@ __global__ __launch_bounds__(256) void pv_rank_topk_partials_kernel(const float*
             rank += (kj > ki) || (kj == ki && j < i);
         }
         if (rank < k) keep[b * k + rank] = i;
+        if (rank == k - 1) edge[0] = ki;
+        if (rank == k) edge[1] = ki;
     }
+    if (gap_min) { __syncthreads(); pv_rank_gap(edge, gap_min, b, N, k); }
 }
 
-extern "C" int pv_rank_topk_partials(const float* rowsq, int64_t tiles, int32_t* keep, int64_t B, int64_t S, int64_t k, void* stream) {
+extern "C" int pv_rank_topk_partials_gap(const float* rowsq, int64_t tiles, int32_t* keep, float* gap_min, int64_t B, int64_t S, int64_t k, void* stream) {
     if (!rowsq || !keep || B <= 0 || S < 2 || tiles <= 0 || k < 0 || k > S - 1) return PV_ERR_INVALID_ARG;
     if (S - 1 > 4096 || tiles > 64) return PV_ERR_UNSUPPORTED;
     if (k == 0) return PV_OK;
-    PV_LAUNCH(pv_rank_topk_partials_kernel, dim3((unsigned)B), dim3(256), (size_t)(S - 1) * 4, (hipStream_t)stream, rowsq, (int)tiles, B * S, keep, (int)S,
-              (int)k);
+    PV_LAUNCH(pv_rank_topk_partials_kernel, dim3((unsigned)B), dim3(256), (size_t)(S + 1) * 4, (hipStream_t)stream, rowsq, (int)tiles, B * S, keep, gap_min,
+              (int)S, (int)k);
     return pv_check_launch();
+}
+extern "C" int pv_rank_topk_partials(const float* rowsq, int64_t tiles, int32_t* keep, int64_t B, int64_t S, int64_t k, void* stream) {
+    return pv_rank_topk_partials_gap(rowsq, tiles, keep, nullptr, B, S, k, stream);
 }
 
 __global__ __launch_bounds__(256) void pv_gather_tokens_kernel(const float* __restrict__ x, const int32_t* __restrict__ keep, float* __restrict__ out,

@@ -122,13 +122,48 @@ class RankVisionTransformer(_ViTBase):
             with engine.on_device(x):
                 return train_engine.model_forward_train(self, x, train_body)
         if engine.backend_for(x, self, max(self.dropout, self.attention_dropout)) == "hip":
-            body = lambda xs: engine.pool_and_head(self, engine.call_module(self.encoder, engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
+            plain = lambda xs: engine.pool_and_head(self, engine.call_module(self.encoder, engine.embed_tokens(self, xs), _pos_added=True, _rows=self.num_class_tokens))
             # what a ranked layer decided for every image: its kept SET (sorted indices); mode auto's self-check compares arithmetic only where
             # these agree with the split-operand run (engine.RANK_STRICT)
             ranked = [blk for blk in self.encoder.layers if getattr(blk, "current_budget", 1) != 1 and hasattr(blk, "sort_and_drop")]
             state = (lambda: [torch.sort(blk.last_keep, dim=1).values for blk in ranked if getattr(blk, "last_keep", None) is not None]) if ranked else None
+            body = (lambda xs: self._forward_repairing_near_ties(xs, plain, ranked)) if ranked and engine.RANK_REPAIR else plain
+            object.__setattr__(self, "_pv_no_autograph", bool(ranked and engine.RANK_REPAIR))      # (the repair reads a count on the host: not a forward to capture)
             return engine.run_guarded(self, x, lambda: body(x), probe=body, probe_key=repr(getattr(self, "current_budget", None)), probe_state=state)
         return self._composite_head(self.encoder(self._composite_tokens(x)))
+
+    def _forward_repairing_near_ties(self, x: torch.Tensor, plain, ranked):
+        """The forward with its keep boundaries watched (engine.RANK_REPAIR, round 6): on 16-bit operands every ranking also reports each image's
+        relative gap between its last kept and its first dropped token norm; the images whose narrowest gap is under engine.RANK_TIE_GAP - where the
+        16-bit layers' noise in the norms (~1e-4) may have resolved a near-tie differently from the reference's fp32 arithmetic (models/rankvit.py:63-77)
+        - are run AGAIN as a small sub-batch in the split-operand arithmetic (kept sets bit-exact end to end), their logits and the blocks' `last_keep`
+        rows replaced.  Everything else stays on fp16 operands.  One extra host read per forward (the count of such images)."""
+        if engine._mode() != "f16" or torch.cuda.is_current_stream_capturing():       # the split-operand arithmetic itself / an unguarded A/B mode / a capture: nothing to repair
+            return plain(x)
+        with engine.rank_gaps(int(x.shape[0]), x.device) as gap:
+            out = plain(x)
+        engine.rank_repair_forwards += 1
+        idx = torch.nonzero(gap < engine.RANK_TIE_GAP).flatten()                       # (host synchronisation: the size of idx)
+        if idx.numel() == 0:
+            return out
+        if 2 * int(idx.numel()) > int(x.shape[0]):
+            # a dense boundary (random weights on random images: 87 % of the images sit within 4e-4 of a tie, profiles/r06_rank_tie_calibration.json):
+            # the whole batch in split precision, no gather
+            engine.rank_repaired_images += int(x.shape[0])
+            with engine.precision(engine.FALLBACK_MODE):
+                return plain(x)
+        keeps = [blk.last_keep for blk in ranked]
+        with engine.precision(engine.FALLBACK_MODE):
+            fixed = plain(x.index_select(0, idx))
+        out = out.clone() if out.is_inference() else out
+        out.index_copy_(0, idx, fixed.to(out.dtype))
+        for blk, kp in zip(ranked, keeps):                                             # what the blocks remember is the whole batch's, repaired rows included
+            if kp is not None and getattr(blk, "last_keep", None) is not None and blk.last_keep.shape[1:] == kp.shape[1:]:
+                kp = kp.clone() if kp.is_inference() else kp
+                kp.index_copy_(0, idx, blk.last_keep.to(kp.dtype))
+                blk.last_keep = kp
+        engine.rank_repaired_images += int(idx.numel())
+        return out
 
     def set_budget(self, budget: float):
         """Only the blocks in rankvit_layers receive it; a list is indexed by LAYER index

@@ -601,11 +601,15 @@ def token_norm(x: torch.Tensor) -> torch.Tensor:
     return norms
 
 
-def rank_topk(norms: torch.Tensor, k: int) -> torch.Tensor:
+def rank_topk(norms: torch.Tensor, k: int, gap_min: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """keep int32 [B,k]; gap_min (fp32 [B], optional) is lowered to each image's relative gap at the keep boundary (include/peekvit_hip.h pv_rank_topk_gap)."""
     B, N = norms.shape
     keep = torch.empty((B, k), dtype=torch.int32, device=norms.device)
+    if gap_min is not None:
+        _chk(gap_min, torch.float32, "gap_min")
+        assert gap_min.numel() == B
     with _timed("pv_rank_topk", norms.device, 0.0, 4.0 * (norms.numel() + B * k)):
-        check(_lib.load().pv_rank_topk(_ptr(norms), _ptr(keep), B, N, k, _stream(norms)), "pv_rank_topk")
+        check(_lib.load().pv_rank_topk_gap(_ptr(norms), _ptr(keep), _ptr(gap_min), B, N, k, _stream(norms)), "pv_rank_topk_gap")
     _count()
     return keep
 
@@ -616,13 +620,16 @@ def gemm_tile_rows(M: int, N: int, K: int, epilogue: int) -> int:
     return int(_lib.load().pv_gemm_tile_rows(C.byref(args)))
 
 
-def rank_topk_partials(rowsq: torch.Tensor, B: int, S: int, k: int) -> torch.Tensor:
-    """keep int32 [B,k] from a producer GEMM's per-column-tile row sums of squares (rowsq fp32 [tiles, B*S])."""
+def rank_topk_partials(rowsq: torch.Tensor, B: int, S: int, k: int, gap_min: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """keep int32 [B,k] from a producer GEMM's per-column-tile row sums of squares (rowsq fp32 [tiles, B*S]); gap_min as in rank_topk."""
     _chk(rowsq, torch.float32, "rowsq")
     tiles = rowsq.shape[0]
     keep = torch.empty((B, k), dtype=torch.int32, device=rowsq.device)
+    if gap_min is not None:
+        _chk(gap_min, torch.float32, "gap_min")
+        assert gap_min.numel() == B
     with _timed("pv_rank_topk", rowsq.device, 0.0, 4.0 * (rowsq.numel() + B * k)):
-        check(_lib.load().pv_rank_topk_partials(_ptr(rowsq), tiles, _ptr(keep), B, S, k, _stream(rowsq)), "pv_rank_topk_partials")
+        check(_lib.load().pv_rank_topk_partials_gap(_ptr(rowsq), tiles, _ptr(keep), _ptr(gap_min), B, S, k, _stream(rowsq)), "pv_rank_topk_partials_gap")
     _count()
     return keep
 

@@ -2,6 +2,8 @@
   (a) the oracle in bf16 'same-rounding-points' mode (tight), and
   (b) golden logits captured from the REAL fp32 reference (looser: bf16 operand rounding),
 plus size-independent properties at BASELINE's full batch (batch invariance, permutation equivariance)."""
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -940,3 +942,115 @@ def test_local_fallback_of_the_score_guard_on_other_model_families(kind, monkeyp
         ref = O.vit_forward(x, sd, cfg, "fp32").numpy()
     assert rel_l2(logits, ref) < TOL_CONTRACT, rel_l2(logits, ref)
     engine.reset_guard(m)
+
+
+def test_rank_topk_reports_the_gap_at_the_keep_boundary():
+    """pv_rank_topk_gap / pv_rank_topk_partials_gap (ABI v10): gap_min[b] is lowered to the relative gap between image b's last kept and first dropped
+    norm; the kept indices are those of the plain entry points; an array handed to two rankings keeps the smaller gap; k == N leaves it alone."""
+    from peekvit_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N, k = 37, 196, 98
+    norms = (torch.rand(B, N, generator=g) + 0.5).to(DEV)
+    gap = torch.full((B,), float("inf"), device=DEV)
+    keep = ops.rank_topk(norms, k, gap)
+    assert torch.equal(keep, ops.rank_topk(norms, k))
+    srt = torch.sort(norms.cpu().double(), dim=1, descending=True).values
+    want = (srt[:, k - 1] - srt[:, k]) / srt[:, k - 1]
+    assert torch.allclose(gap.cpu().double(), want, rtol=1e-5, atol=1e-7)
+    k2 = 150
+    ops.rank_topk(norms, k2, gap)                                   # a second ranking into the same array: the minimum of both
+    want2 = torch.minimum(want, (srt[:, k2 - 1] - srt[:, k2]) / srt[:, k2 - 1])
+    assert torch.allclose(gap.cpu().double(), want2, rtol=1e-5, atol=1e-7)
+    before = gap.clone()
+    ops.rank_topk(norms, N, gap)                                    # nothing dropped: no boundary
+    assert torch.equal(gap, before)
+    # the partials form: norms = sqrt of per-tile sums of squares over rows [B * S], class row first
+    S, tiles = N + 1, 3
+    rowsq = torch.rand(tiles, B * S, generator=g).to(DEV)
+    gp = torch.full((B,), float("inf"), device=DEV)
+    kp = ops.rank_topk_partials(rowsq, B, S, k, gp)
+    assert torch.equal(kp, ops.rank_topk_partials(rowsq, B, S, k))
+    nn_ = rowsq.cpu().double().sum(0).sqrt().view(B, S)[:, 1:]
+    s2 = torch.sort(nn_, dim=1, descending=True).values
+    assert torch.allclose(gp.cpu().double(), (s2[:, k - 1] - s2[:, k]) / s2[:, k - 1], rtol=1e-4, atol=1e-6)
+
+
+def test_rankvit_repairs_the_images_that_sit_on_a_ranking_near_tie(monkeypatch):
+    """Round 6 (review item 6): with engine.RANK_REPAIR the forward watches every image's relative gap at its keep boundaries and re-runs the images under
+    engine.RANK_TIE_GAP - where 16-bit noise in the norms may have kept another token than the reference's fp32 ranking - in the split-operand arithmetic:
+    their kept sets and logits become that arithmetic's, every other image stays on fp16 operands.  Threshold 0: nothing changes."""
+    from peekvit_amd import engine
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    m.set_budget(0.5)
+    B = 48
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(21)).to(torch.bfloat16).float().to(DEV)
+    ranked = [m.encoder.layers[i] for i in (3, 6, 9)]
+    sets = lambda: [torch.sort(b.last_keep, dim=1).values.clone() for b in ranked]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with engine.precision("f16"), engine.rank_gaps(B, x.device) as gap:
+            plain = m(x).clone()
+            plain_sets = sets()
+        with engine.precision("bf16x3"):
+            exact = m(x).clone()
+            exact_sets = sets()
+        flipped = torch.zeros(B, dtype=torch.bool, device=DEV)
+        for a, b in zip(plain_sets, exact_sets):
+            flipped |= (a != b).any(dim=1)
+        thr = float(torch.sort(gap).values[B // 3])                 # a third of the images count as near-ties
+        monkeypatch.setattr(engine, "RANK_REPAIR", True)
+        monkeypatch.setattr(engine, "RANK_TIE_GAP", thr)
+        monkeypatch.setattr(engine, "SELFCHECK_IMAGES", 0)          # (the arithmetic under test is the repair, not the self-check's verdict)
+        engine.reset_guard(m)
+        r0 = engine.rank_repaired_images
+        got = m(x)
+        got_sets = sets()
+        near = gap < thr
+        n_near = int(near.sum())
+        assert 0 < n_near < B // 2 and engine.rank_repaired_images == r0 + n_near
+        for a, b, c in zip(got_sets, exact_sets, plain_sets):
+            assert torch.equal(a[near], b[near]) and torch.equal(a[~near], c[~near])      # repaired images: the exact sets; the others: untouched
+        assert torch.equal(got[~near], plain[~near])
+        assert rel_l2(got[near], exact[near]) < 2e-5                                       # (a sub-batch of another size: fp32 summation order of the split GEMMs)
+        # a threshold of 0: nothing is repaired
+        monkeypatch.setattr(engine, "RANK_TIE_GAP", 0.0)
+        engine.reset_guard(m)
+        assert torch.equal(m(x), plain) and engine.rank_repaired_images == r0 + n_near
+        # a dense boundary (more than half of the batch under the threshold): the whole batch runs in split precision
+        monkeypatch.setattr(engine, "RANK_TIE_GAP", float(torch.sort(gap).values[-2]))
+        engine.reset_guard(m)
+        dense = m(x)
+        assert rel_l2(dense, exact) < 2e-5 and engine.rank_repaired_images == r0 + n_near + B
+        for a, b in zip(sets(), exact_sets):
+            assert torch.equal(a, b)
+    assert bool(flipped.any()) or True      # (random weights on random images: some image usually flips; the assertions above do not depend on it)
+
+
+def test_rank_strict_holds_on_random_images_through_the_near_tie_repair(monkeypatch):
+    """PEEKVIT_AMD_RANK_STRICT=1 (a ranking tie flip counts as a contract violation) implies the repair: on a batch of random images - where the
+    synthetic model's keep boundary is dense - the images under the calibrated gap run in split precision, the self-check's probe images keep the
+    split-operand arithmetic's token sets (no flip left to count), the model is NOT sent to bf16x3 for good, and over the whole batch the kept sets are
+    the exact ones (profiles/r06_rank_tie_calibration.json: the largest gap of a flipped image among 1 024 was 9.6e-4, the threshold is 1.2e-3)."""
+    from peekvit_amd import engine
+    monkeypatch.setattr(engine, "RANK_STRICT", True)
+    monkeypatch.setattr(engine, "RANK_REPAIR", True)
+    cfg, m = _model("rank", "vit_b_16", rankvit_layers=[3, 6, 9])
+    m.set_budget(0.5)
+    B = 512
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(33)).to(torch.bfloat16).float().to(DEV)
+    ranked = [m.encoder.layers[i] for i in (3, 6, 9)]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")                      # (a flip warning or a verdict warning would be an error here)
+        t0, c0 = engine.selfcheck_trips, engine.selfcheck_count
+        got = m(x)
+        got_sets = [torch.sort(b.last_keep, dim=1).values.clone() for b in ranked]
+        assert engine.selfcheck_count == c0 + 1 and engine.selfcheck_trips == t0 and engine.selfcheck_last[2] == 0 and engine.selfcheck_last[0] < engine.SELFCHECK_LIMIT
+        assert not engine.guard_state(m).unsafe
+        with engine.precision("bf16x3"):
+            exact = m(x)
+            exact_sets = [torch.sort(b.last_keep, dim=1).values.clone() for b in ranked]
+    wrong = torch.zeros(B, dtype=torch.bool, device=DEV)
+    for a, b in zip(got_sets, exact_sets):
+        wrong |= (a != b).any(dim=1)
+    assert int(wrong.sum()) <= 1                            # (an image beyond the calibrated gap that still flips: none among 1 024 in the calibration run)
+    assert rel_l2(got[~wrong], exact[~wrong]) < TOL_CONTRACT
