@@ -66,6 +66,14 @@ int pv_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 int pv_im2col_bf16(const float* x, uint16_t* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P,
                    uint32_t* range_flag, void* stream);
 
+/* models/vit.py:203-222 WITHOUT a materialised patch matrix (ABI v10): tokens[b, row_off + i, :] = patch_i(img[b]) . W^T + bias + pos[row_off + i, :] in one
+ * launch - a 128 x 128 tile GEMM whose activation operand is gathered from the image while it is staged.  img fp32 [B,C,R,R] (NCHW); W 16-bit [D, C*P*P] =
+ * conv_proj.weight in its own layout; pos fp32 [S, D]; tokens fp32 [B, S, D] (rows [row_off, row_off + (R/P)^2) of every image are written).  R % P == 0,
+ * P % 8 == 0, C*P*P % 64 == 0.  Bit-identical to pv_im2col_bf16 + pv_gemm_bf16(PV_EPI_BIAS_POS_F32); the faster form for D <= 512 (each 128-column tile
+ * gathers the pixels again).  range_flag as pv_im2col_bf16. */
+int pv_patch_embed_f32(const float* img, const uint16_t* W, const float* bias, const float* pos, float* tokens, int64_t B, int64_t C, int64_t R,
+                       int64_t P, int64_t D, int64_t S, int64_t row_off, uint32_t* range_flag, void* stream);
+
 /* The same patch gather straight from the DataLoader's RAW image: x uint8 [B,H,W,3] (NHWC); ToTensor + Normalize of
  *   data/imagenette.py:73 (x/255, then (x - mean[c]) / std[c], fp32, this op order) are applied per element, so `cols` is
  * bit-identical to pv_im2col_bf16 of the normalised fp32 NCHW tensor at a quarter of the input bytes.  P % 8 == 0. */

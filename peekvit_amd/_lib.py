@@ -49,6 +49,7 @@ SIGNATURES = {
     "pv_error_string": (C.c_char_p, [C.c_int]),
     "pv_cast_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "pv_im2col_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p]),
+    "pv_patch_embed_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p]),
     "pv_im2col_u8_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p]),
     "pv_split3_f32_bf16": (C.c_int, [_p, _p, _i64, _i64, C.c_int, _p]),
     "pv_im2col_split_bf16": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p]),

@@ -59,7 +59,7 @@ def _knobs():
     from . import engine, ops
     return (engine._STREAMS, engine.LOCAL_FALLBACK, engine.SELFCHECK_IMAGES, engine.SELFCHECK_LIMIT, engine.RANK_STRICT, engine._FUSE_LN, engine._FULLROW_LN,
             engine._FOLD_LN, engine._FUSE_RANK_NORM, engine._SMALL_M_SPLITK, engine._LAST_BLOCK_ROWS, engine._GATE_NO_MASKED, engine.FALLBACK_MODE,
-            engine.RANK_REPAIR, engine.RANK_TIE_GAP,
+            engine.RANK_REPAIR, engine.RANK_TIE_GAP, engine._FUSED_PATCH_EMBED,
             getattr(ops, "knob_epoch", 0))
 
 

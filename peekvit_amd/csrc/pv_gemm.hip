@@ -456,6 +456,165 @@ __global__ __launch_bounds__(256, 2) void pv_gemm128_kernel(const GemmDev p_in) 
     if (EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16) pv_range_commit(vmax, p.range_flag);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Patch embedding WITHOUT a materialised patch matrix (round 6; models/vit.py:203-222: conv_proj with kernel = stride = P, reshape, permute,
+// + positional embedding).  The 128 x 128 tile kernel above with its A operand gathered from the fp32 NCHW image on the fly: a thread's 16-byte
+// chunk of the LDS image (8 consecutive K values of one patch row) is 8 consecutive pixels of one image row - two 16-byte loads, converted and
+// written where the LDS-DMA would have put them, so the fragment reads and the MFMA order are the tile kernel's: bit-identical to
+// pv_im2col_bf16 + pv_gemm_bf16(PV_EPI_BIAS_POS_F32).  The pixels of K-tile kt + 1 fly under the MFMAs of K-tile kt.  What it saves is the
+// patch matrix's round trip (vit_small, batch 512: 154 MB written by pv_im2col and read back: 90 + 120 us of a 4.8 ms forward); a lane's eight
+// rows-of-patches are neighbours in the image (8 patches x 64 B of one image row per wave instruction).  For narrow models only: each of the N / 128
+// column tiles gathers the pixels again (from L2), and at D = 768 the 256^2 kernel on a materialised matrix is the faster form.
+// ------------------------------------------------------------------------------------------------
+struct PatchGeom { const float* img; int C, R, P, Wp, Np; };      // image fp32 [B, C, R, R]; Wp = R / P patches per row, Np = Wp * Wp per image
+
+__global__ __launch_bounds__(256, 2) void pv_patch_embed_kernel(const GemmDev p, const PatchGeom gm) {
+    constexpr int EPI = PV_EPI_BIAS_POS_F32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile = pv_xcd_remap(blockIdx.x, ntiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * G1_BM, n0 = tn * G1_BN;
+
+    const int srow = wid * 8 + (lane >> 3);                      // + 32 * i
+    const int schunk = (lane & 7) ^ ((lane >> 3) & 7);           // logical 16-B chunk (8 K values) this lane provides
+    const float* gpx[4];                                         // first pixel of the row's patch (channel 0, patch row 0)
+    const uint16_t* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = m0 + i * 32 + srow; ra = ra < p.M ? ra : p.M - 1;
+        const int b = ra / gm.Np, pi = ra - b * gm.Np, py = pi / gm.Wp, px = pi - py * gm.Wp;
+        gpx[i] = gm.img + ((int64_t)b * gm.C * gm.R + (int64_t)py * gm.P) * gm.R + px * gm.P;
+        int rw = n0 + i * 32 + srow; rw = rw < p.N ? rw : p.N - 1;
+        gw[i] = p.W + (int64_t)rw * p.ldw + schunk * 8;
+    }
+    float4 pxv[4][2];
+    auto fetch = [&](int kt) {                                   // the 8 pixels of this lane's chunk of K-tile kt, for its four rows
+        const int k0 = kt * G1_BK + schunk * 8, pp = gm.P * gm.P;
+        const int c = k0 / pp, rem = k0 - c * pp, ky = rem / gm.P, kx = rem - ky * gm.P;
+        const int64_t off = ((int64_t)c * gm.R + ky) * gm.R + kx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pxv[i][0] = *reinterpret_cast<const float4*>(gpx[i] + off);
+            pxv[i][1] = *reinterpret_cast<const float4*>(gpx[i] + off + 4);
+        }
+    };
+    float vmax = 0.f;                                            // operand-range guard of the packed pixels (fp16 build), as pv_im2col_bf16
+    auto put = [&](int buf) {
+        char* la = smem + buf * (2 * G1_TILE_BYTES) + wid * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = {pv_pack_bf16x2_tracked(pxv[i][0].x, pxv[i][0].y, vmax), pv_pack_bf16x2_tracked(pxv[i][0].z, pxv[i][0].w, vmax),
+                             pv_pack_bf16x2_tracked(pxv[i][1].x, pxv[i][1].y, vmax), pv_pack_bf16x2_tracked(pxv[i][1].z, pxv[i][1].w, vmax)};
+            *reinterpret_cast<u32x4*>(la + i * 4096) = v;
+        }
+    };
+    auto stage_w = [&](int buf, int kt) {
+        char* lw = smem + buf * (2 * G1_TILE_BYTES) + G1_TILE_BYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv_glds16(gw[i] + kt * G1_BK, lw + i * 4096);
+    };
+
+    const int frow = lane & 15;
+    const int fx0 = (((lane >> 4) ^ (lane & 7)) << 4);
+    const int a_off = (wm * 64 + frow) * 128;
+    const int w_off = (wn * 64 + frow) * 128;
+    const int en = n0 + wn * 64 + ((lane >> 4) << 2);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && en + i * 16 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + en + i * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = b4;
+    }
+
+    const int nk = p.K / G1_BK;
+    stage_w(0, 0);
+    fetch(0);
+    put(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) { stage_w(cur ^ 1, kt + 1); fetch(kt + 1); }
+        const char* la = smem + cur * (2 * G1_TILE_BYTES);
+        const char* lw = la + G1_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fx = fx0 ^ (ks << 6);
+            bf16x8 xf[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xf[t] = *reinterpret_cast<const bf16x8*>(la + a_off + t * 2048 + fx);
+                wf[t] = *reinterpret_cast<const bf16x8*>(lw + w_off + t * 2048 + fx);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = PV_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) put(cur ^ 1);                           // (buffer cur ^ 1 was last read before the previous barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int em = m0 + wm * 64 + (lane & 15);
+    float dummy = 0.f;
+    f32x4 rr[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) rr[mt][nt] = pv_epilogue_fetch<EPI>(p, em + mt * 16, en + nt * 16);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(rr[mt][nt]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (m0 + G1_BM <= p.M && n0 + G1_BN <= p.N) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, false>(p, em + mt * 16, en + nt * 16, acc[nt][mt], rr[mt][nt], 1.0f, dummy);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pv_epilogue_store<EPI, true>(p, em + mt * 16, en + nt * 16, acc[nt][mt], rr[mt][nt], 1.0f, dummy);
+    }
+    pv_range_commit(vmax, p.range_flag);
+}
+
+// models/vit.py:203-222 in one launch: tokens[b, row_off + i, :] = patch_i(img[b]) . W^T + bias + pos[row_off + i, :].  img fp32 [B, C, R, R] (NCHW,
+// 16-byte aligned, R % P == 0, P % 8 == 0, C P P % 64 == 0), W 16-bit [D, C P P] (the conv weight's own layout), tokens fp32 [B, S, D].
+extern "C" int pv_patch_embed_f32(const float* img, const uint16_t* W, const float* bias, const float* pos, float* tokens, int64_t B, int64_t C, int64_t R,
+                                  int64_t P, int64_t D, int64_t S, int64_t row_off, uint32_t* range_flag, void* stream) {
+    if (!img || !W || !pos || !tokens || B <= 0 || C <= 0 || R <= 0 || P <= 0 || D <= 0 || S <= 0 || row_off < 0) return PV_ERR_INVALID_ARG;
+    if (R % P || P % 8 || (C * P * P) % G1_BK || D % 4 || R % 4 || ((uintptr_t)img & 15) || ((uintptr_t)W & 15) || ((uintptr_t)tokens & 15) || ((uintptr_t)pos & 15) ||
+        (bias && ((uintptr_t)bias & 15)))
+        return PV_ERR_UNSUPPORTED;
+    const int64_t Wp = R / P, Np = Wp * Wp, M = B * Np;
+    if (row_off + Np > S || M > 0x7fffffff || B * S > 0x7fffffff) return PV_ERR_INVALID_ARG;
+    GemmDev p = {};
+    p.W = W; p.bias = bias; p.out = tokens; p.pos = pos;
+    p.M = (int)M; p.N = (int)D; p.K = (int)(C * P * P);
+    p.ldw = p.K; p.ldo = D;
+    p.rpi = (int)Np; p.rpo = (int)S; p.row_off = (int)row_off;
+    p.qscale = 1.0f;
+    p.tiles_m = (int)((M + G1_BM - 1) / G1_BM); p.tiles_n = (int)((D + G1_BN - 1) / G1_BN);
+    p.range_flag = range_flag;
+    const PatchGeom gm = {img, (int)C, (int)R, (int)P, (int)Wp, (int)Np};
+    static PvPerDevice attr_set;
+    const int lds = 2 * 2 * G1_TILE_BYTES;
+    if (attr_set.first_use()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_patch_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    PV_LAUNCH(pv_patch_embed_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, (hipStream_t)stream, p, gm);
+    return pv_check_launch();
+}
+
 template <int EPI>
 static int pv_launch_gemm128(const GemmDev& p, hipStream_t stream) {
     static PvPerDevice attr_set;

@@ -867,33 +867,52 @@ extern "C" int pv_cls_pool(const float* x, const float* gamma, const float* beta
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pv_head_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
                                                       float* __restrict__ out, int B, int D, int C) {
-    __shared__ float As[16][65];
-    __shared__ float Ws[16][65];
+    // Round 6: 32 x 64 tiles (rounds 1-5: 64 x 64 - 128 workgroups for 512 x 1000 logits, half of the CUs idle and the others bound by their fp32
+    // FMAs: 44 us at vit_small's batch), 32-column K steps with the NEXT step's rows already in registers while this one is multiplied.
+    // Same FMA order per logit (k ascending).
+    constexpr int BK = 32, TM = 32;
+    __shared__ float As[BK][TM + 1];
+    __shared__ float Ws[BK][65];
     const int t = threadIdx.x, tm = t >> 4, tn = t & 15;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4] = {};
-    const int lr = t >> 2, lk = (t & 3) << 2;   // loader: row lr (0..63), k offset lk (0,4,8,12)
-    for (int k0 = 0; k0 < D; k0 += 16) {
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
-        if (m0 + lr < B && k0 + lk < D) av = *reinterpret_cast<const float4*>(a + (int64_t)(m0 + lr) * D + k0 + lk);
-        if (n0 + lr < C && k0 + lk < D) wv = *reinterpret_cast<const float4*>(w + (int64_t)(n0 + lr) * D + k0 + lk);
-        As[lk + 0][lr] = av.x; As[lk + 1][lr] = av.y; As[lk + 2][lr] = av.z; As[lk + 3][lr] = av.w;
-        Ws[lk + 0][lr] = wv.x; Ws[lk + 1][lr] = wv.y; Ws[lk + 2][lr] = wv.z; Ws[lk + 3][lr] = wv.w;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
+    float acc[2][4] = {};
+    const int ar_ = t >> 3, ak = (t & 7) << 2;                  // A loader: row ar_ (0..31), k offset ak (0..28)
+    const int wr_ = t >> 2, wk = (t & 3) << 2;                  // W loader: row wr_ (0..63), k offsets wk and wk + 16
+    const bool a_ok = m0 + ar_ < B, w_ok = n0 + wr_ < C;
+    const float* ap = a + (int64_t)(a_ok ? m0 + ar_ : 0) * D + ak;
+    const float* wp = w + (int64_t)(w_ok ? n0 + wr_ : 0) * D + wk;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 av, wv[2];
+    auto fetch = [&](int k0) {
+        av = (a_ok && k0 + ak < D) ? *reinterpret_cast<const float4*>(ap + k0) : z4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wv[h] = (w_ok && k0 + wk + 16 * h < D) ? *reinterpret_cast<const float4*>(wp + k0 + 16 * h) : z4;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < D; k0 += BK) {
+        As[ak + 0][ar_] = av.x; As[ak + 1][ar_] = av.y; As[ak + 2][ar_] = av.z; As[ak + 3][ar_] = av.w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Ws[16 * h + wk + 0][wr_] = wv[h].x; Ws[16 * h + wk + 1][wr_] = wv[h].y; Ws[16 * h + wk + 2][wr_] = wv[h].z; Ws[16 * h + wk + 3][wr_] = wv[h].w;
+        }
         __syncthreads();
+        if (k0 + BK < D) fetch(k0 + BK);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float ar[4], wr[4];
+        for (int k = 0; k < BK; ++k) {
+            float ar[2], wr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ar[i] = As[k][tm + 16 * i]; wr[i] = Ws[k][tn + 16 * i]; }
+            for (int i = 0; i < 2; ++i) ar[i] = As[k][tm + 16 * i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) wr[j] = Ws[k][tn + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ar[i], wr[j], acc[i][j]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         int m = m0 + tm + 16 * i;
         if (m >= B) continue;
 #pragma unroll
@@ -928,7 +947,7 @@ extern "C" int pv_head_f32(const float* pooled, const float* w, const float* b, 
         PV_LAUNCH(pv_head_small_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(64), 0, (hipStream_t)stream, pooled, w, b, logits, (int)B, (int)D, (int)C);
         return pv_check_launch();
     }
-    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((B + 63) / 64));
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((B + 31) / 32));
     PV_LAUNCH(pv_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, pooled, w, b, logits, (int)B, (int)D, (int)C);
     return pv_check_launch();
 }

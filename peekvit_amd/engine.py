@@ -1302,6 +1302,9 @@ def _run_layers(mods, x: torch.Tensor, last_rows: int, hybrid) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # patch embedding + special tokens + positional embedding (reference models/vit.py:203-236, :92)
 # ------------------------------------------------------------------------------------------------
+_FUSED_PATCH_EMBED = os.environ.get("PEEKVIT_AMD_FUSED_PATCH_EMBED", "1") != "0"
+
+
 def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[torch.Tensor] = None,
                  budget: float = 0.0) -> torch.Tensor:
     """img fp32 [B,3,R,R] -> tokens fp32 [B,S_total,D] = [cls | registers | patches] + pos_embedding
@@ -1327,6 +1330,16 @@ def embed_tokens(model: nn.Module, img: torch.Tensor, budget_token: Optional[tor
         img = ((img.permute(0, 3, 1, 2).float().div(255.0) - mt) / st).contiguous()
         u8 = False
     x3 = _mode() == "bf16x3" and not u8
+    if _FUSED_PATCH_EMBED and not u8 and not x3 and D <= 512 and K % 64 == 0 and P % 8 == 0 and Hh == Ww and Hh % 4 == 0:
+        # round 6: narrow models gather the patches inside the GEMM's operand staging (pv_patch_embed_f32: bit-identical, no patch matrix)
+        tokens = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        pos = _f32(model.encoder.pos_embedding).view(-1, D)
+        ops.patch_embed(img, bf16_weight(model.conv_proj.weight).view(D, K), _f32(model.conv_proj.bias), pos, tokens, P, n_special)
+        special = _f32(model.class_tokens).view(-1, D)
+        if model.num_registers > 0:
+            special = torch.cat([special, _f32(model.register_tokens).view(-1, D)], dim=0)
+        ops.token_prologue(tokens, special, pos, _f32(budget_token), budget, n_special)
+        return tokens
     cols = workspace.get("cols", (B * Np, 3 * K if x3 else K), _lib.operand_dtype(), dev)
     if x3:
         ops.im2col_split(img, P, cols)

@@ -178,6 +178,22 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+def patch_embed(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], pos: torch.Tensor, tokens: torch.Tensor, patch: int, row_off: int) -> torch.Tensor:
+    """tokens[b, row_off + i, :] = patch_i(x[b]) . w^T + bias + pos[row_off + i, :] in ONE launch (pv_patch_embed_f32: no materialised patch matrix).
+    x fp32 [B,C,R,R]; w 16-bit [D, C*P*P]; pos fp32 [>= row_off + Np, D]; tokens fp32 [B, S, D]."""
+    _chk(x, torch.float32, "x"); _chk(w, _lib.operand_dtype(), "w"); _chk(pos, torch.float32, "pos"); _chk(tokens, torch.float32, "tokens")
+    B, Cc, H, W = x.shape
+    _, S, D = tokens.shape
+    if H != W or w.shape != (D, Cc * patch * patch) or pos.shape[1] != D or pos.shape[0] < row_off + (H // patch) ** 2:      # (ResidualViT's budget-token row has no positional row)
+        raise _lib.PeekvitHipError(f"patch_embed: shapes x {tuple(x.shape)}, w {tuple(w.shape)}, pos {tuple(pos.shape)}, tokens {tuple(tokens.shape)}")
+    M = B * (H // patch) ** 2
+    with _timed("pv_gemm_bf16", x.device, 2.0 * M * D * w.shape[1], 4.0 * x.numel() + 2.0 * w.numel() + 4.0 * M * D, member=(D, w.shape[1], _lib.PV_EPI_BIAS_POS_F32)):
+        check(_lib.load().pv_patch_embed_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(pos), _ptr(tokens), B, Cc, H, patch, D, S, row_off, _flag(x.device), _stream(x)),
+              "pv_patch_embed_f32")
+    _count()
+    return tokens
+
+
 def im2col(x: torch.Tensor, patch: int, out: torch.Tensor) -> torch.Tensor:
     _chk(x, torch.float32, "x")
     B, Cc, H, W = x.shape

@@ -581,3 +581,30 @@ def test_attention_row_maximum_is_taken_from_finished_scores(B, S, H, dh, operan
             _lib.set_operand(old)
         assert torch.isfinite(out.float()).all(), (amp, int((~torch.isfinite(out.float())).any(1).sum()))
         assert rel_l2(out, ref) < (2e-3 if operand == "f16" else 1.2e-2), (amp, rel_l2(out, ref))
+
+
+@pytest.mark.parametrize("B,R,P,D,S,row_off", [(3, 224, 16, 384, 197, 1), (5, 160, 8, 256, 401, 1), (2, 224, 16, 512, 200, 4), (9, 64, 16, 128, 17, 1), (1, 32, 8, 64, 17, 1)])
+def test_patch_embed_without_a_patch_matrix_is_bit_identical_to_im2col_plus_gemm(ops, B, R, P, D, S, row_off):
+    """pv_patch_embed_f32 (round 6): the patch embedding with the patches gathered inside the GEMM's operand staging - same bits as pv_im2col_bf16 followed
+    by pv_gemm_bf16(PV_EPI_BIAS_POS_F32), rows outside [row_off, row_off + Np) of every image untouched; ragged row and column tiles; P = 8 and 16."""
+    from peekvit_amd import _lib
+    from peekvit_amd._lib import PV_EPI_BIAS_POS_F32
+    Np, K = (R // P) ** 2, 3 * P * P
+    assert row_off + Np <= S
+    x = T(f"pe_x{B}{R}", (B, 3, R, R), bf16=False).to(DEV)
+    w = bf(T(f"pe_w{D}{K}", (D, K), "uniform", 1.0 / math.sqrt(K)))
+    bias, pos = T(f"pe_b{D}", (D,), "uniform", 0.1, bf16=False).to(DEV), T(f"pe_p{S}{D}", (S, D), "uniform", 0.02, bf16=False).to(DEV)
+    cols = torch.empty((B * Np, K), dtype=_lib.operand_dtype(), device=DEV)
+    ops.im2col(x, P, cols)
+    want = torch.full((B, S, D), 7.0, device=DEV)
+    ops.gemm(cols, w, bias, want.view(B * S, D), PV_EPI_BIAS_POS_F32, M=B * Np, pos=pos, rows_per_img_in=Np, rows_per_img_out=S, row_off=row_off)
+    got = torch.full((B, S, D), 7.0, device=DEV)
+    ops.patch_embed(x, w, bias, pos, got, P, row_off)
+    assert torch.equal(got, want)
+    ref = (torch.nn.functional.unfold(x.to(w.dtype).float(), P, stride=P).transpose(1, 2) @ w.float().t() + bias + pos[row_off:row_off + Np])
+    assert rel_l2(got[:, row_off:row_off + Np], ref) < 2e-5
+    # without a bias
+    got2, want2 = torch.zeros((B, S, D), device=DEV), torch.zeros((B, S, D), device=DEV)
+    ops.gemm(cols, w, None, want2.view(B * S, D), PV_EPI_BIAS_POS_F32, M=B * Np, pos=pos, rows_per_img_in=Np, rows_per_img_out=S, row_off=row_off)
+    ops.patch_embed(x, w, None, pos, got2, P, row_off)
+    assert torch.equal(got2, want2)
