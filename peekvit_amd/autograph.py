@@ -86,7 +86,7 @@ def _signature(owner: nn.Module, ent: _Entry, st) -> tuple:
     from . import engine
     layers = getattr(getattr(owner, "encoder", None), "layers", ())
     return (_structure_epoch, engine._opt_generation, tuple(map(id, layers)), sum(p._version for p in ent.params), _knobs(),
-            st.unsafe, st.no_fold, st.hybrid, owner.training)
+            st.unsafe, st.no_fold, st.hybrid, st.mlp_hybrid, owner.training)
 
 
 def _hooked(ent: _Entry) -> bool:
@@ -137,7 +137,7 @@ def try_replay(owner: nn.Module, x: torch.Tensor, probe_key, st) -> Optional[tor
     if engine.SELFCHECK_EVERY > 0:
         # the periodic self-check lives in the eager path and counts EVERY guarded forward of the key, replayed or not: a replay advances the same
         # counter, and the forward on which the probe is due is left to the eager path (which counts it and probes)
-        vkey = (probe_key, int(x.shape[0]), st.no_fold, x.dtype, tuple(x.shape[1:]), st.hybrid)
+        vkey = (probe_key, int(x.shape[0]), st.no_fold, x.dtype, tuple(x.shape[1:]), st.hybrid, st.mlp_hybrid)
         n = st.calls.get(vkey, 0) + 1
         if n >= engine.SELFCHECK_EVERY:
             return None

@@ -182,7 +182,7 @@ class GuardState:
              fp16's subnormal range), or the data-dependent guard tripped on three forwards in a row: go straight to the fallback mode
     no_fold  a row mean large against its spread was seen: LayerNorm folding stays off for this module (fp16 operands otherwise)
     gen      the optimizer-step generation the verdicts were made for; an optimizer step or load_state_dict() resets them"""
-    __slots__ = ("unsafe", "no_fold", "trips", "gen", "verdicts", "hybrid", "calls", "graphs")
+    __slots__ = ("unsafe", "no_fold", "trips", "gen", "verdicts", "hybrid", "calls", "graphs", "mlp_hybrid")
 
     def __init__(self):
         self.unsafe, self.no_fold, self.trips, self.gen = False, False, 0, _opt_generation
@@ -190,6 +190,7 @@ class GuardState:
         self.hybrid = frozenset()   # encoder layers whose attention half runs in split precision (their scores left PV_SCORE_LIMIT)
         self.calls = {}             # verdict key -> guarded forwards since the last self-check probe (periodic re-probe)
         self.graphs = {}            # launch-bound keys -> captured hipGraph (peekvit_amd.autograph, round 6); dies with this state
+        self.mlp_hybrid = False     # the MLP half of every layer runs in split precision (round 6: the self-check's first escalation step)
 
 
 def guard_state(owner: nn.Module) -> GuardState:
@@ -226,6 +227,10 @@ _FLAG_SCORE = 4
 # numbered layer, still sends the forward to FALLBACK_MODE.  PEEKVIT_AMD_LOCAL_FALLBACK=0 restores the round-4 behaviour.
 LOCAL_FALLBACK = os.environ.get("PEEKVIT_AMD_LOCAL_FALLBACK", "1") != "0"
 hybrid_fallback_count = 0   # forwards repeated with more hybrid layers (still fp16 operands everywhere else)
+# ... and of the contract self-check (round 6): a key that measures outside the limit first gets the MLP half of every layer in split precision and is
+# measured again; only if that is not enough does it go to FALLBACK_MODE.  PEEKVIT_AMD_MLP_FALLBACK=0 restores the one-step escalation of round 5.
+MLP_FALLBACK = os.environ.get("PEEKVIT_AMD_MLP_FALLBACK", "1") != "0"
+mlp_fallback_count = 0      # models whose MLP halves were sent to split precision by the self-check
 
 
 # The contract SELF-CHECK of mode "auto" (round 4).  The flag-word guards catch what is known to break fp16 operands (overflow, folded rows
@@ -406,6 +411,11 @@ def _local_fallback(st: GuardState, words, bits: int, launched_hybrid) -> bool:
     return True
 
 
+def layer_mlp_is_hybrid() -> bool:
+    """Does the calling thread's forward run the MLP half of its encoder layers in split precision (the self-check's first escalation step)?"""
+    return getattr(_region, "layer", None) is not None and getattr(_region, "mlp_hybrid", False)
+
+
 def layer_is_hybrid() -> bool:
     """Is the encoder layer the calling thread is in (engine.run_layers) one whose attention half runs in split precision?"""
     i = getattr(_region, "layer", None)
@@ -423,7 +433,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
     `probe(x_part) -> logits` (model-level forwards only) enables the contract self-check described above SELFCHECK_IMAGES;
     `probe_key` = whatever else selects the arithmetic (the budget setting); `probe_state()` = per-image integer tensors of the discrete decisions
     the last forward took (RankViT: the kept sets), see RANK_STRICT above."""
-    global fallback_count, fold_fallback_count, selfcheck_count, selfcheck_trips, selfcheck_last
+    global fallback_count, fold_fallback_count, selfcheck_count, selfcheck_trips, selfcheck_last, mlp_fallback_count
     with on_device(x):
         if _mode() != "auto" or getattr(_region, "active", False):
             return fn()
@@ -436,7 +446,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                 ref = None
                 for attempt in range(5):
                     # the self-check verdict is per (what selects the arithmetic, batch size, input type and image shape, folding, hybrid layers)
-                    vkey = (probe_key, int(x.shape[0]), st.no_fold, x.dtype, tuple(x.shape[1:]), st.hybrid)
+                    vkey = (probe_key, int(x.shape[0]), st.no_fold, x.dtype, tuple(x.shape[1:]), st.hybrid, st.mlp_hybrid)
                     verdict = st.verdicts.get(vkey) if probe is not None else "ok"
                     if verdict == "x3":
                         break
@@ -465,6 +475,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                     ops.set_range_flag(flag)
                     _region.no_fold = st.no_fold
                     _region.hybrid = st.hybrid
+                    _region.mlp_hybrid = st.mlp_hybrid
                     launched_hybrid, launched_no_fold = st.hybrid, st.no_fold
                     out = None
                     try:
@@ -478,6 +489,7 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                         ops.set_range_flag(None)
                         _region.no_fold = False
                         _region.hybrid = frozenset()
+                        _region.mlp_hybrid = False
                     if out is None:
                         break
                     _region.last = "guarded"
@@ -537,6 +549,19 @@ def run_guarded(owner: nn.Module, x: torch.Tensor, fn, probe=None, probe_key=Non
                             if len(st.verdicts) >= 64:
                                 st.verdicts.clear()
                                 st.calls.clear()
+                            if not err <= SELFCHECK_LIMIT and LOCAL_FALLBACK and MLP_FALLBACK and not st.mlp_hybrid and attempt < 3:
+                                # Escalation in two steps (round 6): before the whole forward goes to the split-operand arithmetic, the MLP HALF of every
+                                # layer does - LayerNorm 2 as [hi|lo|hi] planes, fc1 and fc2 as three bf16 products each with the GELU output split
+                                # (the kernels of mode bf16x3); the in-projection, the attention core and the out-projection stay on fp16 operands (the
+                                # attention half of the layers the score guard named is split already).  The MLP is 2/3 of a layer's operand roundings
+                                # and FLOPs; what it leaves in 16 bits measures 3 - 5e-4 on the models that fail the first check.  Measured again at once,
+                                # against the reference logits already in hand.
+                                st.mlp_hybrid = True
+                                mlp_fallback_count += 1
+                                _warn_once(f"mlp:{id(owner)}:{probe_key}", f"peekvit_amd: fp16 operands measure {err:.2e} against the {FALLBACK_MODE} arithmetic on the first "
+                                           f"{probed} images (limit {SELFCHECK_LIMIT:g}): the MLP half of every layer runs in split precision from now on, and the forward is measured again")
+                                ref = (ref, ref_state) if flips == 0 else None
+                                continue
                             if not err <= SELFCHECK_LIMIT:
                                 st.verdicts[vkey] = "x3"
                                 selfcheck_trips += 1
@@ -1006,6 +1031,24 @@ def _attention_half_split(blk: nn.Module, x: torch.Tensor, att: torch.Tensor, B:
     ops.attention_split(qkv32, att, B, S, H, dh)
 
 
+def _mlp_half_split(blk: nn.Module, x1: torch.Tensor, out: torch.Tensor, R: int, eps: float, row_scale: Optional[torch.Tensor]):
+    """[LayerNorm 2 -> fc1 -> GELU -> fc2 -> + residual] of one block in SPLIT precision (round 6, the self-check's first escalation step): LN2(x1) as
+    [hi|lo|hi] bf16 planes, fc1 as three bf16 products whose epilogue splits gelu(.) the same way, fc2 as three products onto the fp32 residual x1 -
+    the second half of _block_forward_x3, on the bf16 library whatever the calling thread's operand type is (models/blocks.py:74-84 is exact on any
+    weights; this is 6e-6 from it).  x1 fp32 [R, D] in, `out` fp32 [R, D] written."""
+    D, M = x1.shape[-1], blk.mlp.fc1.out_features
+    dev = x1.device
+    old = _lib.set_operand("bf16")
+    try:
+        h3 = workspace.get("h3", (R, 3 * D), torch.bfloat16, dev)
+        g3 = workspace.get("g3", (R, 3 * M), torch.bfloat16, dev)
+        ops.layernorm_split(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h3, row_scale)
+        ops.gemm(h3, bf16x3_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g3, PV_EPI_BIAS_GELU_SPLIT_BF16, M=R)
+        ops.gemm(g3, bf16x3_weight(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias), out.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x1.view(R, D))
+    finally:
+        _lib.set_operand(old)
+
+
 def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Optional[torch.Tensor] = None,
                   next_ln: Optional[nn.LayerNorm] = None, next_ranks: bool = False, h1: Optional[torch.Tensor] = None,
                   res_scaled: bool = False) -> torch.Tensor:
@@ -1068,8 +1111,12 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
             ops.attention(qkv, att, B, S, H, dh)
         x16 = workspace.get("fold_x16", (R, D), _lib.operand_dtype(), dev)
         part = workspace.get("fold_part", (nt, R, 2), torch.float32, dev)
+        mlp_hyb = layer_mlp_is_hybrid()
         ops.gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), PV_EPI_BIAS_RES_F32, M=R, res=x.view(R, D),
-                 x16_out=x16, rowstat_out=part)
+                 x16_out=None if mlp_hyb else x16, rowstat_out=None if mlp_hyb else part)
+        if mlp_hyb:
+            _mlp_half_split(blk, x1, out, R, eps, None)          # (no hand-off: the next layer normalises its own input)
+            return out
         wg, c1, c2 = _fold_weights(blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.ln_2)
         stat = ops.rowstat_finalize(part, D, blk.ln_2.eps, workspace.get("fold_stat", (R, 2), torch.float32, dev))
         ops.gemm(x16, wg, None, g, PV_EPI_BIAS_GELU_BF16, M=R, fold=(stat, c1, c2))
@@ -1100,7 +1147,10 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
         ops.gemm(h, bf16_weight(mha.in_proj_weight), _f32(mha.in_proj_bias), qkv, PV_EPI_BIAS_BF16, M=R,
                  qcols=D, qscale=float(dh) ** -0.5)
         ops.attention(qkv, att, B, S, H, dh)
-    fuse2 = _ln_fusable(D, D)
+    mlp_hyb = layer_mlp_is_hybrid()
+    if mlp_hyb and res_scaled:
+        raise PeekvitHipError("block_forward(res_scaled=True) cannot run a layer whose MLP half is in split precision: pass the masked tokens")
+    fuse2 = _ln_fusable(D, D) and not mlp_hyb
     if res_scaled and (h1 is None or row_scale is None or fuse2):
         raise PeekvitHipError("block_forward(res_scaled=True) needs row_scale, the caller's h1 and the tile GEMM (no full-row LayerNorm fusion)")
     if fuse2 or row_scale is not None:
@@ -1111,6 +1161,9 @@ def block_forward(blk: nn.Module, x: torch.Tensor, eps: float, row_scale: Option
     else:
         ln2_done = _residual_gemm(att, bf16_weight(mha.out_proj.weight), _f32(mha.out_proj.bias), x1.view(R, D), x.view(R, D), R,
                                   ln=(_f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2))
+    if mlp_hyb:
+        _mlp_half_split(blk, x1, out, R, eps, row_scale)
+        return out
     if not ln2_done:
         ops.layernorm_bf16(x1, _f32(blk.ln_2.weight), _f32(blk.ln_2.bias), eps, h2, row_scale)
     _act_gemm(h2, bf16_weight(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias), g, R, gelu=True)
@@ -1147,7 +1200,7 @@ def rows_only_ok(blk: nn.Module) -> bool:
     """May the LAST block of a model forward compute only the rows its consumer reads (block_forward_rows)?  Not in mode "bf16x3", and not
     when someone observes the block's output (or its gradient) through a module hook (they would see [B,nq,D] instead of [B,S,D])."""
     import torch.nn.modules.module as _m
-    if not _LAST_BLOCK_ROWS or _mode() == "bf16x3" or layer_is_hybrid():       # (a hybrid layer runs all rows: block_forward has the split attention half)
+    if not _LAST_BLOCK_ROWS or _mode() == "bf16x3" or layer_is_hybrid() or layer_mlp_is_hybrid():       # (a hybrid layer runs all rows: block_forward has the split halves)
         return False
     own = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
     glob = ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks")

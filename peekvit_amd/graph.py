@@ -51,7 +51,7 @@ class GraphedForward:
                 self.static_out = self.model(self.static_in)
             self._guarded = engine._mode() == "auto" and engine.last_forward_guarded()
             gs = engine.guard_state(self.model)
-            self._captured_state = (gs.unsafe, gs.no_fold, gs.hybrid)
+            self._captured_state = (gs.unsafe, gs.no_fold, gs.hybrid, gs.mlp_hybrid)
         torch.cuda.current_stream().wait_stream(side)
 
     def refresh(self):
@@ -65,7 +65,7 @@ class GraphedForward:
         if self._guarded and int(self._flag.max().item()) != 0:      # a guard tripped inside the replay: this batch again, eagerly, in a mode that keeps the contract
             out = self.model(self.static_in).clone()
             gs = engine.guard_state(self.model)
-            if (gs.unsafe, gs.no_fold, gs.hybrid) != self._captured_state:
+            if (gs.unsafe, gs.no_fold, gs.hybrid, gs.mlp_hybrid) != self._captured_state:
                 # the eager repeat changed what mode "auto" does for this model from now on (folding off, hybrid layers, or the split-operand mode for good):
                 # capture THAT forward, or every later call would replay the graph that trips and then run eagerly again (round 3 ADVICE)
                 self._capture(1)

@@ -166,7 +166,7 @@ class ResidualViTBlock(ResidualModule):
             h1 = engine.workspace.get("h", (x.shape[0] * x.shape[1], x.shape[2]), engine._lib.operand_dtype(), x.device)
         # with h1 from the gate and a tile GEMM for out-proj the masked tokens themselves are never needed: the out-proj epilogue computes
         # row_scale * (x + branch) from the unmasked rows (pv_gemm_args.res_scaled)
-        no_masked = h1 is not None and engine._GATE_NO_MASKED and not engine._ln_fusable(x.shape[2], x.shape[2])
+        no_masked = h1 is not None and engine._GATE_NO_MASKED and not engine._ln_fusable(x.shape[2], x.shape[2]) and not engine.layer_mlp_is_hybrid()      # (a split MLP half reads the masked tokens' x1)
         masked = None if no_masked else torch.empty_like(x)
         f32 = engine._f32
         self.mask, row_scale = ops.residual_gate(x, masked, f32(gate.weight), f32(gate.bias), f32(bgate.weight), f32(bgate.bias),

@@ -240,14 +240,15 @@ def test_residualvit_parity(golden, tag, name, gb):
         # mode "auto" measures every new (parameters, budget, batch size) against its split-operand arithmetic on the first forward
         # (engine.run_guarded, "contract self-check"); a trip means THIS forward already came from the bf16x3 mode
         tripped = engine.selfcheck_trips > t0
+        mlp_split = engine.guard_state(m).mlp_hybrid          # (round 6: the self-check's first escalation step - the MLP halves in split precision, still no whole-forward fallback)
         assert engine.fallback_count - f0 == (1 if tripped else 0)
         masks = torch.stack([blk.mask.cpu() for blk in m.encoder.layers]).numpy()
         assert masks.shape[1] == x.shape[0]                                       # the probe's slice never overwrites what the blocks remember
         thr = torch.stack([blk.residual_gate.threshold.cpu() for blk in m.encoder.layers])      # left behind like ResidualGate.forward does (utils.py:131)
         assert thr.shape == (cfg["num_layers"], x.shape[0], 1, 1) and bool(((thr > 0) & (thr < 1)).all())
         tr = {}
-        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "fp32" if tripped else _op(), trace=tr).numpy()
-        assert rel_l2(logits, same) < (1e-4 if tripped else TOL_SAME)
+        same = O.residualvit_forward(x, sd, dict(cfg, **extra), b, "fp32" if (tripped or mlp_split) else _op(), trace=tr).numpy()
+        assert rel_l2(logits, same) < (1e-4 if tripped else 9e-4 if mlp_split else TOL_SAME)
         assert np.abs(masks - torch.stack(tr["masks"]).numpy()).max() < 5e-3
         if "thresholds" in tr:
             assert np.abs(thr.view(cfg["num_layers"], -1).numpy() - torch.stack(tr["thresholds"]).view(cfg["num_layers"], -1).numpy()).max() < 5e-3
@@ -260,7 +261,8 @@ def test_residualvit_parity(golden, tag, name, gb):
             # masks are 0.05 .. 0.44, nowhere near the gate threshold).  The self-check sees exactly that and answers from bf16x3.
             assert rel_l2(logits, g[f"{tag}_b{b}_logits"]) < TOL_CONTRACT
             if (tag, b) == ("vit_micro", 0.2):
-                assert tripped and rel_l2(logits, g[f"{tag}_b{b}_logits"]) < 1e-4
+                # round 6: the self-check's FIRST step (MLP halves in split precision) brings the toy inside the limit - no whole-forward fallback any more
+                assert (mlp_split and not tripped and rel_l2(logits, g[f"{tag}_b{b}_logits"]) < 9e-4) or (tripped and rel_l2(logits, g[f"{tag}_b{b}_logits"]) < 1e-4)
         with torch.no_grad():                                                    # the verdict is kept: no second probe, same arithmetic again
             c0 = engine.selfcheck_count
             again = m(x.to(DEV)).cpu().numpy()

@@ -523,6 +523,7 @@ def test_contract_self_check_of_mode_auto(monkeypatch):
     bf16x3 - measured, not inferred from a flag bit.  Mechanics: one probe per key; a verdict "x3" makes that key's forwards bitwise the
     bf16x3 mode's and counts as a fallback; what the blocks remember (masks) stays the whole batch's; IMAGES = 0 switches it off."""
     from peekvit_amd import engine
+    monkeypatch.setattr(engine, "MLP_FALLBACK", False)          # (the one-step mechanics; the two-step escalation of round 6 has its own test below)
     cfg, m = _model("vit", "vit_tiny")
     x = torch.from_numpy(synth.synth_images(12, cfg["image_size"], seed=3)).to(DEV)
     c0, t0, f0 = engine.selfcheck_count, engine.selfcheck_trips, engine.fallback_count
@@ -688,3 +689,42 @@ def test_mode_auto_replays_a_hipgraph_for_launch_bound_forwards_by_itself(monkey
     # not launch-bound: never captured
     cfg_b, mb = _model("vit", "vit_b_16")
     assert not autograph.launch_bound(mb, 64)
+
+
+def test_self_check_escalates_in_two_steps_mlp_half_first(monkeypatch):
+    """Round 6 (review item 4): a key that measures outside the self-check's limit first gets the MLP half of every layer in split precision
+    (LayerNorm 2 as [hi|lo|hi] planes, fc1 / GELU / fc2 as three bf16 products each) and is measured AGAIN against the reference logits already in hand;
+    only if that is not enough does the whole forward go to bf16x3.  vit_tiny on uniform-noise images measures 1.05e-3 on fp16 operands (round 4):
+    with the MLP halves split it is inside the limit, no whole-forward fallback, and the result is closer to bf16x3 than the fp16 one."""
+    from peekvit_amd import engine
+    cfg, m = _model("vit", "vit_tiny")
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(16, 3, cfg["image_size"], cfg["image_size"], generator=g) * 2 - 1).to(DEV)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with engine.precision("bf16x3"):
+            exact = m(x).clone()
+        with engine.precision("f16"):
+            raw = m(x).clone()
+        # (1) a limit between what the MLP-hybrid forward measures and what plain fp16 does: one escalation step, no whole-forward fallback
+        e_raw = rel_l2(raw, exact)
+        monkeypatch.setattr(engine, "SELFCHECK_LIMIT", 0.75 * e_raw)
+        engine.reset_guard(m)
+        f0, t0, k0 = engine.fallback_count, engine.selfcheck_trips, engine.mlp_fallback_count
+        got = m(x)
+        st = engine.guard_state(m)
+        e_got = rel_l2(got, exact)
+        print("fp16", e_raw, "MLP halves split", e_got)
+        assert st.mlp_hybrid and engine.mlp_fallback_count == k0 + 1 and engine.fallback_count == f0 and engine.selfcheck_trips == t0
+        assert e_got < 0.75 * e_raw and not torch.equal(got, exact)
+        again = m(x)
+        assert torch.equal(again, got) and engine.mlp_fallback_count == k0 + 1              # the module remembers; no second probe for the key
+        # (2) an impossible limit: both steps, then the split-operand arithmetic
+        monkeypatch.setattr(engine, "SELFCHECK_LIMIT", 1e-7)
+        engine.reset_guard(m)
+        got2 = m(x)
+        assert torch.equal(got2, exact) and engine.fallback_count == f0 + 1 and engine.selfcheck_trips == t0 + 1 and engine.mlp_fallback_count == k0 + 2
+        # (3) switched off: straight to bf16x3, as in round 5
+        monkeypatch.setattr(engine, "MLP_FALLBACK", False)
+        engine.reset_guard(m)
+        assert torch.equal(m(x), exact) and engine.mlp_fallback_count == k0 + 2 and not engine.guard_state(m).mlp_hybrid
