@@ -458,282 +458,8 @@ static int pv_launch_attn_stream(const uint16_t* qkv, uint16_t* out, int64_t B, 
     return pv_check_launch();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Persistent forward (round 6, the structure of pv_attn_bwd5_kernel): ONE workgroup of 16 waves per CU walks over its (image, head) items; wave w owns
-// query tile w (S = 177 .. 224: 12 - 14 tiles, one each); the K | V images of item j + 1 land by LDS-DMA in a second pair of buffers while item j is
-// computed, its Q rows in registers - every load has a whole item's arithmetic to arrive under, where pv_attn_kernel's three workgroups per CU each idle
-// while their own 53 KiB land (0.548 ms per layer at ViT-B/16 against 0.36 - 0.43 with the operands in L2).  One barrier per item.
-// The arithmetic per row is pv_attn_kernel's, in its order: bit-identical outputs (tests/test_hip_ops.py).
-// What hipcc cannot see is done by hand, as in the persistent backward: every LDS read is inline asm behind a counted s_waitcnt lgkmcnt that names the
-// registers (hipcc puts s_waitcnt vmcnt(0) in front of any LDS read it can see while an LDS-DMA is in flight: it cannot tell the image being filled from the one
-// being read), fragment reads run one tile ahead of their MFMAs, and everything that depends on the lane alone is recomputed per item (left invariant it is
-// hoisted, spilled and reloaded under the DMA).
-// ------------------------------------------------------------------------------------------------
-static int pv_attn_cu_count();
-static int g_pv_attn_persist = -1;        // -1: PV_ATTN_PERSIST / default; 0 / 1: A/B override (scripts/attn_persist_ab.py)
-extern "C" void pv_debug_set_attn_persist(int on) { g_pv_attn_persist = on; }
-static bool pv_attn_persist_enabled() {
-    static const int env = [] { const char* e = getenv("PV_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
-    return (g_pv_attn_persist >= 0 ? g_pv_attn_persist : env) != 0;
-}
-
-template <int DH, int NKT, bool LSE>
-__global__ __launch_bounds__(1024) void pv_attn_p_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, uint32_t* flag, int B,
-                                                         float* __restrict__ lse, int n_items) {
-    constexpr int NW = 16, NT = NW * 64;
-    constexpr int DHP = (DH + 31) / 32 * 32, CPR = DHP / 8, TB = 16 * DHP * 2;
-    constexpr int SP = NKT * 16, IMG = SP * DHP * 2, NDT = DH / 16, KS = DHP / 32, NKT32 = NKT / 2;
-    constexpr int NCH = SP * CPR, NIT = (NCH + NT - 1) / NT;
-    static_assert(CPR == 8 && NKT <= NW, "row images of 128 bytes (dh = 48 / 64), one query tile per wave");
-    extern __shared__ __attribute__((aligned(16))) char smem[];        // [2 buffers][K image | V image]
-    typedef __attribute__((address_space(3))) char lds_c;
-    const int tid = threadIdx.x;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = H * DH;
-    const int64_t ld = 3 * (int64_t)D;
-    const bool tile_wave = wid < ((S + 15) >> 4);
-    int lane, g, i16, foff[KS], toff[NDT];
-    unsigned off3[NIT];
-    auto relane = [&]() __attribute__((always_inline)) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        lane = t & 63;
-        g = lane >> 4;
-        i16 = lane & 15;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) foff[ks] = pv_swz<CPR>(i16, ks * 4 + g);
-        const int tq_ = i16 >> 2, tp_ = i16 & 3;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) toff[dt] = pv_swz<CPR>(4 * g + tq_, dt * 2 + (tp_ >> 1)) + ((tp_ & 1) << 3);
-        const int lsw = (t & 7) ^ ((t >> 3) & 7);
-        const int c_lane = lsw * 8 >= DH ? 0 : lsw;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            int row = i * (NT / CPR) + (t >> 3);
-            row = row < S ? row : S - 1;
-            off3[i] = (unsigned)(row * 3 * D + c_lane * 8) * 2u;
-        }
-    };
-    auto stage = [&](char* kd, const uint16_t* qb) __attribute__((always_inline)) {          // K | V of the (image, head) at qb into the buffer pair at kd
-#pragma unroll
-        for (int kv = 0; kv < 2; ++kv) {
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                if (NCH % NT == 0 || i * NT + wid * 64 < NCH) {
-                    const char* src = reinterpret_cast<const char*>(qb + (kv + 1) * D) + off3[i];
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(kd + kv * IMG + (size_t)(i * NT + wid * 64) * 16), 16, 0, 0);
-                }
-            }
-        }
-    };
-    auto qrows = [&](const uint16_t* qb, bf16x8 (&f)[KS]) __attribute__((always_inline)) {   // this wave's Q^T fragments (B operand): lane (g, i16) holds Q[16 wid + i16][32 ks + 8 g ..]
-        int r = wid * 16 + i16;
-        r = r < S ? r : S - 1;
-        const unsigned o = (unsigned)(r * 3 * D + 8 * g) * 2u;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ks * 32 + 8 * g < DH) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(qb) + o + ks * 64);
-            f[ks] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    relane();
-    int it = blockIdx.x, par = 0;
-    bf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
-    char* const touch = smem + 4 * IMG + wid * 256;          // 4 bytes per lane: where the "touch" loads of the next item's Q rows land (never read)
-    {
-        int b, h;
-        pv_bh_map(it, B, H, b, h);
-        const uint16_t* qb = qkv + (int64_t)b * S * ld + h * DH;
-        stage(smem, qb);
-        if (tile_wave) qrows(qb, qf);
-    }
-    for (;;) {
-        relane();
-        int b, h;
-        pv_bh_map(it, B, H, b, h);
-        // ---- K | V of this item (every wave's pieces) and this wave's Q rows have landed ----
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- the NEXT item's K | V into the other buffer pair (last read during the previous item: every wave is past the barrier), its Q rows into registers ----
-        const int nit = it + (int)gridDim.x;
-        if (nit < n_items) {
-            int bn, hn;
-            pv_bh_map(nit, B, H, bn, hn);
-            const uint16_t* qbn = qkv + (int64_t)bn * S * ld + hn * DH;
-            stage(smem + (par ^ 1) * 2 * IMG, qbn);
-            // ... and its Q rows as far as the L2 (a 4-byte LDS-DMA per row into a scratch slot: a register load issued here would be copied - and so
-            // waited for - before the arithmetic below; the fragments themselves are loaded when this item's tile is done, from the L2)
-            if (tile_wave && g == 0) {
-                int r = wid * 16 + i16;
-                r = r < S ? r : S - 1;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(qbn) + (unsigned)(r * 3 * D) * 2u),
-                                                 (__attribute__((address_space(3))) void*)touch, 4, 0, 0);
-            }
-        }
-        if (tile_wave) {
-            lds_c* const Ks = (lds_c*)(smem + par * 2 * IMG);
-            lds_c* const Vs = Ks + IMG;
-            const int q0 = wid << 4;
-            // ---- S^T tiles, K fragments read one tile ahead of their MFMAs ----
-            f32x4 sc[NKT];
-            bf16x8 kf[2][KS];
-            auto k_issue = [&](int kt, bf16x8 (&f)[KS]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(f[ks]) : "v"(Ks + foff[ks] + kt * TB));
-            };
-            k_issue(0, kf[0]);
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                if (kt + 1 < NKT) {
-                    k_issue(kt + 1, kf[(kt + 1) & 1]);
-                    if constexpr (KS == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[kt & 1][0]), "+v"(kf[kt & 1][1])::"memory");
-                    else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kf[kt & 1][0])::"memory");
-                } else {
-                    if constexpr (KS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[kt & 1][0]), "+v"(kf[kt & 1][1])::"memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[kt & 1][0])::"memory");
-                }
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a = PV_MFMA_16x16x32(kf[kt & 1][ks], qf[ks], a, 0, 0, 0);
-                sc[kt] = a;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if ((NKT - 1) * 16 + 4 * g + r >= S) sc[NKT - 1][r] = -INFINITY;
-            float m = -INFINITY;
-            // (the maxima are inline asm the hazard recognizer does not look into: pinned behind the MFMAs, see pv_attn_kernel)
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) asm volatile("" : "+v"(sc[kt]));
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(m));
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(sc[kt][0]), "v"(sc[kt][1]));
-                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(sc[kt][2]), "v"(sc[kt][3]));
-            }
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            pv_score_guard(m, flag);
-            const float nm = -m * 1.44269504088896340736f + PV_P_SHIFT;
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.44269504088896340736f, nm));
-                    sc[kt][r] = pe;
-                    l += pe;
-                }
-            }
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
-            if constexpr (LSE)
-                if (g == 0 && q0 + i16 < S)
-                    lse[((int64_t)b * H + h) * S + q0 + i16] = m * 1.44269504088896340736f + (__builtin_amdgcn_logf(l) - PV_P_SHIFT);
-            // ---- O^T = V^T . P^T, the transposed V reads of 32-key step tt + 1 issued before the MFMAs of step tt ----
-            f32x4 o[NDT];
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            s16x4 vf[2][NDT][2];
-            auto v_issue = [&](int tt, s16x4 (&f)[NDT][2]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0]) : "v"(Vs + toff[dt] + tt * (2 * TB)));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][1]) : "v"(Vs + toff[dt] + tt * (2 * TB) + TB));
-                }
-            };
-            auto v_wait = [&](bool more, s16x4 (&f)[NDT][2]) __attribute__((always_inline)) {
-                if constexpr (NDT == 4) {
-                    if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1])::"memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1])::"memory");
-                } else {
-                    if (more) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1])::"memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1])::"memory");
-                }
-            };
-            if (NKT32 > 0) v_issue(0, vf[0]);
-#pragma unroll
-            for (int tt = 0; tt < NKT32; ++tt) {
-                const bool more = tt + 1 < NKT32;
-                if (more) v_issue(tt + 1, vf[(tt + 1) & 1]);
-                v_wait(more, vf[tt & 1]);
-                u32x4 pw = {pv_pack_bf16x2(sc[2 * tt][0], sc[2 * tt][1]), pv_pack_bf16x2(sc[2 * tt][2], sc[2 * tt][3]),
-                            pv_pack_bf16x2(sc[2 * tt + 1][0], sc[2 * tt + 1][1]), pv_pack_bf16x2(sc[2 * tt + 1][2], sc[2 * tt + 1][3])};
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const s16x8 vv = __builtin_shufflevector(vf[tt & 1][dt][0], vf[tt & 1][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = PV_MFMA_16x16x32(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
-                }
-            }
-            if (NKT & 1) {             // odd last 16-key tile: K = 16 MFMA
-                constexpr int kt = NKT - 1;
-                s16x4 v0[NDT];
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0[dt]) : "v"(Vs + toff[dt] + kt * TB));
-                if constexpr (NDT == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3])::"memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2])::"memory");
-                u32x2 pw = {pv_pack_bf16x2(sc[kt][0], sc[kt][1]), pv_pack_bf16x2(sc[kt][2], sc[kt][3])};
-                const s16x4 pf = __builtin_bit_cast(s16x4, pw);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) o[dt] = PV_MFMA_16x16x16(v0[dt], pf, o[dt], 0, 0, 0);
-            }
-            if (q0 + i16 < S) {
-                const float inv = 1.0f / l;
-                uint16_t* op = out + ((int64_t)b * S + q0 + i16) * D + h * DH + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    u32x2 ov = {pv_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pv_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
-                    *reinterpret_cast<u32x2*>(op + dt * 16) = ov;
-                }
-            }
-        }
-        if (nit >= n_items) break;
-        if (tile_wave) {
-            int bn, hn;
-            pv_bh_map(nit, B, H, bn, hn);
-            qrows(qkv + (int64_t)bn * S * ld + hn * DH, qf);
-        }
-        it = nit;
-        par ^= 1;
-    }
-}
-
-template <int DH, int NKT>
-static int pv_launch_attn_p(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse) {
-    constexpr int DHP = (DH + 31) / 32 * 32;
-    constexpr int lds = 4 * NKT * 16 * DHP * 2 + 16 * 256;      // two K | V buffer pairs + the touch slots
-    static PvPerDevice attr_set;
-    if (attr_set.first_use()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_p_kernel<DH, NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pv_attn_p_kernel<DH, NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
-    const int cus = pv_attn_cu_count();
-    const int64_t items = B * H;
-    const unsigned grid = (unsigned)(items < cus ? items : cus);
-    if (lse) PV_LAUNCH((pv_attn_p_kernel<DH, NKT, true>), dim3(grid), dim3(1024), lds, stream, qkv, out, S, H, flag, (int)B, lse, (int)items);
-    else PV_LAUNCH((pv_attn_p_kernel<DH, NKT, false>), dim3(grid), dim3(1024), lds, stream, qkv, out, S, H, flag, (int)B, lse, (int)items);
-    return pv_check_launch();
-}
-
 template <int DH>
 static int pv_dispatch_attn(const uint16_t* qkv, uint16_t* out, int64_t B, int S, int H, uint32_t* flag, hipStream_t stream, float* lse = nullptr) {
-    if constexpr (DH == 48 || DH == 64) {
-        // the persistent kernel: ViT at 224 / 16 (S = 197, + registers / budget token), where a CU has at least four items to walk over
-        const int nkt = (S + 15) / 16, cus = pv_attn_cu_count();
-        if (nkt >= 12 && nkt <= 14 && cus > 0 && B * H >= 4 * (int64_t)cus && pv_attn_persist_enabled()) {
-            switch (nkt) {
-                case 12: return pv_launch_attn_p<DH, 12>(qkv, out, B, S, H, flag, stream, lse);
-                case 13: return pv_launch_attn_p<DH, 13>(qkv, out, B, S, H, flag, stream, lse);
-                default: return pv_launch_attn_p<DH, 14>(qkv, out, B, S, H, flag, stream, lse);
-            }
-        }
-    }
     switch ((S + 15) / 16) {
 #define PV_ATTN_CASE(N) case N: return pv_launch_attn<DH, N>(qkv, out, B, S, H, flag, stream, lse);
         PV_ATTN_CASE(1) PV_ATTN_CASE(2) PV_ATTN_CASE(3) PV_ATTN_CASE(4) PV_ATTN_CASE(5) PV_ATTN_CASE(6) PV_ATTN_CASE(7)

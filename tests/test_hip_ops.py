@@ -608,43 +608,3 @@ def test_patch_embed_without_a_patch_matrix_is_bit_identical_to_im2col_plus_gemm
     ops.gemm(cols, w, None, want2.view(B * S, D), PV_EPI_BIAS_POS_F32, M=B * Np, pos=pos, rows_per_img_in=Np, rows_per_img_out=S, row_off=row_off)
     ops.patch_embed(x, w, None, pos, got2, P, row_off)
     assert torch.equal(got2, want2)
-
-
-@pytest.mark.parametrize("operand", ["f16", "bf16"])
-@pytest.mark.parametrize("B,S,H,dh", [(90, 197, 12, 64), (130, 197, 8, 48), (350, 193, 3, 64), (100, 177, 12, 64), (90, 192, 12, 48), (100, 209, 12, 64), (86, 224, 12, 64),
-                                      (1100, 208, 1, 48)])
-def test_persistent_attention_forward_is_bit_identical_to_the_one_item_kernel(B, S, H, dh, operand):
-    """pv_attn_p_kernel (round 6): one 16-wave workgroup per CU walking over its (image, head) items, K | V of the next item landing under the current one's
-    arithmetic - chosen for 12 - 14 query tiles at dh 48 / 64 when every CU has at least four items.  Same arithmetic in the same order as pv_attn_kernel:
-    the outputs (and the training forward's row statistics) are the same bits, launch after launch, with items unevenly spread over the workgroups."""
-    import ctypes as C
-    from peekvit_amd import _lib, ops
-    D = H * dh
-    dt = torch.float16 if operand == "f16" else torch.bfloat16
-    g = torch.Generator(device="cuda").manual_seed(S + dh + B)
-    qkv = torch.randn(B, S, 3 * D, generator=g, device="cuda") * 1.5
-    qkv[..., :D] *= dh ** -0.5
-    q16 = qkv.view(B * S, 3 * D).to(dt)
-    old = _lib.set_operand(operand)
-    try:
-        lib = _lib.load()
-        lib.pv_debug_set_attn_persist.restype, lib.pv_debug_set_attn_persist.argtypes = None, [C.c_int]
-        outs = {}
-        for mode in (0, 1, 1):
-            lib.pv_debug_set_attn_persist(mode)
-            out = torch.full((B * S, D), float("nan"), device="cuda", dtype=dt)
-            lse = torch.full((B, H, S), float("nan"), device="cuda")
-            out2 = torch.full((B * S, D), float("nan"), device="cuda", dtype=dt)
-            ops.attention(q16, out, B, S, H, dh)
-            ops.attention(q16, out2, B, S, H, dh, lse=lse)
-            outs.setdefault(mode, []).append((out, out2, lse))
-    finally:
-        lib.pv_debug_set_attn_persist(-1)
-        _lib.set_operand(old)
-    ref = outs[0][0]
-    assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[2]).all()
-    for got in outs[1]:
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
-    q, k, v = (t.reshape(B, S, H, dh).permute(0, 2, 1, 3)[:4].double() for t in q16.view(B, S, 3 * D).split(D, dim=-1))
-    want = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).permute(0, 2, 1, 3).reshape(4 * S, D)
-    assert rel_l2(ref[0][:4 * S], want) < (2e-3 if operand == "f16" else 1.2e-2)
