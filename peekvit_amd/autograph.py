@@ -185,7 +185,8 @@ def note_clean_eager(owner: nn.Module, x: torch.Tensor, probe_key, st, verdict_o
     engine._region.autograph_busy = True
     was_active, engine._region.active = getattr(engine._region, "active", False), False
     try:
-        g = GraphedForward(owner, x, warmup=1, capture_error_mode="thread_local")
+        with torch.inference_mode(False):          # (the graph's static tensors outlive this call: never inference tensors, which refuse in-place updates outside inference mode)
+            g = GraphedForward(owner, x, warmup=1, capture_error_mode="thread_local")
         if not g._guarded:
             ent.dead = True                                     # (the capture did not end in the guarded fp16 forward: nothing to replay safely)
             return

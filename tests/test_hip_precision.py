@@ -686,6 +686,18 @@ def test_mode_auto_replays_a_hipgraph_for_launch_bound_forwards_by_itself(monkey
             assert engine.fallback_count == f0 + 1
             with engine.precision("bf16x3"):
                 assert torch.equal(big, m(x2 * 3.0e4))
+    # captured under torch.inference_mode(), replayed under torch.no_grad() and back: the graph's static tensors are ordinary tensors
+    cfg2, m2 = _model("vit", "vit_tiny")
+    c1 = autograph.captures
+    with torch.inference_mode():
+        first = [m2(x) for _ in range(1 + autograph.WARM + 1)]
+    assert autograph.captures == c1 + 1
+    r3 = autograph.replays
+    with torch.no_grad():
+        again = m2(x)
+    with torch.inference_mode():
+        once_more = m2(x)
+    assert autograph.replays == r3 + 2 and torch.equal(again, first[0]) and torch.equal(once_more, first[0])
     # not launch-bound: never captured
     cfg_b, mb = _model("vit", "vit_b_16")
     assert not autograph.launch_bound(mb, 64)
