@@ -150,10 +150,10 @@ class RankVisionTransformer(_ViTBase):
             # a dense boundary (random weights on random images: 87 % of the images sit within 4e-4 of a tie, profiles/r06_rank_tie_calibration.json):
             # the whole batch in split precision, no gather
             engine.rank_repaired_images += int(x.shape[0])
-            with engine.precision(engine.FALLBACK_MODE):
+            with engine.precision(engine.FALLBACK_MODE), engine._hooks_held(self):      # (module hooks have seen this batch once already)
                 return plain(x)
         keeps = [blk.last_keep for blk in ranked]
-        with engine.precision(engine.FALLBACK_MODE):
+        with engine.precision(engine.FALLBACK_MODE), engine._hooks_held(self):
             fixed = plain(x.index_select(0, idx))
         out = out.clone() if out.is_inference() else out
         out.index_copy_(0, idx, fixed.to(out.dtype))

@@ -639,6 +639,7 @@ def test_mode_auto_replays_a_hipgraph_for_launch_bound_forwards_by_itself(monkey
     clean eager forwards of the key and replayed from then on - bit-identical logits in fresh tensors - and the graph is dropped the moment what it was
     captured under changes: a parameter edited in place, a module hook, a guard trip, the knob that switches it off."""
     from peekvit_amd import autograph, engine
+    monkeypatch.setattr(autograph, "ENABLED", True)            # (whatever PEEKVIT_AMD_AUTO_GRAPH says in this environment)
     cfg, m = _model("vit", "vit_tiny")
     x = torch.from_numpy(synth.synth_images(32, cfg["image_size"], seed=11)).to(DEV)
     assert autograph.launch_bound(m, 32)
