@@ -1258,7 +1258,18 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         if (!SPLIT) pv_range_commit(vmax, p.range_flag);
     } else {
         // fp32 image: 128 rows x 1 KiB per pass (pass ps = the rows of wave group wr == ps), chunk c of row r at c ^ (r & 7)
-        f32x4 csum = {0.f, 0.f, 0.f, 0.f};          // PV_EPI_GELU_GRAD_BF16: this lane's 4 columns summed over the rows its wave stores
+        // PV_EPI_GELU_GRAD_BF16 (round 6): its rows are 16-BIT on both sides (the saved derivative in, the gradient out: 512 B each), and a wave instruction that
+        // moves a row of them at 8 bytes per lane is half a request - the epilogue ran at 14.7 B/clk where the fp32 forms reach 23.  Here a lane owns 8 columns
+        // and a wave instruction TWO rows (lanes 0-31 / 32-63): 16-byte loads of the derivative, two 16-byte reads of the fp32 image, 16-byte stores.
+        constexpr bool DG = EPI == PV_EPI_GELU_GRAD_BF16;
+        float cs8[DG ? 8 : 1];                      // this lane's 8 columns summed over the rows it stores
+        if constexpr (DG) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs8[e] = 0.f;
+        }
+        u32x4 dg[DG ? 2 : 1][DG ? 4 : 1];          // the derivative rows of two passes in flight
+        const int dg_col = n0 + 8 * (lane & 31);
+        const bool dg_col_ok = FULL || dg_col + 8 <= p.N;
         float vmax = 0.f;                           // operand-range guard of the x16_out copy (fp16 build)
         // FOUR passes of 64 tile rows; the fp32 image of a pass (64 rows x 1 KiB, chunk c of row r at c ^ (r & 7)) lives in K-tile buffer 1
         // ONLY - buffer 0 stays free for the prefetching launch to stage the next tile's first K-tile during this epilogue.  Pass q: the
@@ -1280,6 +1291,15 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             return m;
         };
         auto fetch = [&](int q) __attribute__((always_inline)) {
+            if constexpr (DG) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    int m = m0 + q * 64 + wid * 8 + 2 * jj + (lane >> 5);
+                    m = (FULL || m < p.M) ? m : p.M - 1;
+                    dg[q & 1][jj] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + (dg_col_ok ? dg_col : 0));
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int m = m0 + q * 64 + wid * 8 + j;
@@ -1287,9 +1307,6 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 f32x4& r = rr[q & 1][j];
                 if (EPI == PV_EPI_BIAS_F32) {
                     r = (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {          // the saved 16-bit gelu'(pre-activation) row, 512 B per instruction
-                    const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.res) + (int64_t)m * p.ldr + ncol);
-                    r = (f32x4){pv_unpack_lo(w[0]), pv_unpack_hi(w[0]), pv_unpack_lo(w[1]), pv_unpack_hi(w[1])};
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     r = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + ncol);
                 } else {
@@ -1326,6 +1343,29 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
             __builtin_amdgcn_s_barrier();
             if (PFM == 1 && q == 0 && pf_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's K-tile 0 (and this tile's first rows) before any store
             float fs[8], fq[8];            // LayerNorm folding (producer) / rank norms: per-lane partial (sum, sum of squares) of the 8 rows
+            if constexpr (DG) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = wid * 8 + 2 * jj + (lane >> 5), c0 = 2 * (lane & 31);
+                    const f32x4 va = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(img + row * 1024 + ((c0 ^ (row & 7)) << 4));
+                    const f32x4 vb = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(img + row * 1024 + (((c0 + 1) ^ (row & 7)) << 4));
+                    const u32x4 d = dg[q & 1][jj];
+                    // (scalar products: the next derivative rows are still returning into registers)
+                    const u32x4 pk = {pv_pack_bf16x2(pv_mul_s(va[0], pv_unpack_lo(d[0])), pv_mul_s(va[1], pv_unpack_hi(d[0]))),
+                                      pv_pack_bf16x2(pv_mul_s(va[2], pv_unpack_lo(d[1])), pv_mul_s(va[3], pv_unpack_hi(d[1]))),
+                                      pv_pack_bf16x2(pv_mul_s(vb[0], pv_unpack_lo(d[2])), pv_mul_s(vb[1], pv_unpack_hi(d[2]))),
+                                      pv_pack_bf16x2(pv_mul_s(vb[2], pv_unpack_lo(d[3])), pv_mul_s(vb[3], pv_unpack_hi(d[3])))};
+                    const int mrow = m0 + q * 64 + row;
+                    if (FULL || (mrow < p.M && dg_col_ok)) {
+                        PV_STORE16(reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)mrow * p.ldo + dg_col), pk);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {               // column sums of exactly the stored values
+                            cs8[2 * e] = pv_add_s(cs8[2 * e], pv_unpack_lo(pk[e]));
+                            cs8[2 * e + 1] = pv_add_s(cs8[2 * e + 1], pv_unpack_hi(pk[e]));
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = wid * 8 + j;                        // local image row; tile row 64 q + row
@@ -1339,22 +1379,13 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
                 if (EPI == PV_EPI_BIAS_F32) {
                     const float qs = ncol < p.qcols ? p.qscale : 1.0f;
                     o = (f32x4){v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs};
-                } else if (EPI == PV_EPI_GELU_GRAD_BF16) {
-                    o = (f32x4){pv_mul_s(v[0], r[0]), pv_mul_s(v[1], r[1]), pv_mul_s(v[2], r[2]), pv_mul_s(v[3], r[3])};      // (scalar: the next rows are still returning)
                 } else if (EPI == PV_EPI_BIAS_RES_F32) {
                     const float tr = p.res_scaled ? sc : 1.0f;
                     o = (f32x4){fmaf(sc, v[0], tr * r[0]), fmaf(sc, v[1], tr * r[1]), fmaf(sc, v[2], tr * r[2]), fmaf(sc, v[3], tr * r[3])};
                 }
                 else o = (f32x4){r[0] + v[0], r[1] + v[1], r[2] + v[2], r[3] + v[3]};
                 const bool ok = FULL || (m0 + q * 64 + row < p.M && col_ok);
-                if (ok) {
-                    if (EPI == PV_EPI_GELU_GRAD_BF16) {
-                        const u32x2 pk = {pv_pack_bf16x2(o[0], o[1]), pv_pack_bf16x2(o[2], o[3])};
-                        PV_STORE16(reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + ncol), pk);
-                        csum += (f32x4){pv_unpack_lo(pk[0]), pv_unpack_hi(pk[0]), pv_unpack_lo(pk[1]), pv_unpack_hi(pk[1])};
-                    } else
-                        PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol), o);
-                }
+                if (ok) PV_STORE32(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + ncol), o);
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.rowsq_out)      // (workgroup-uniform) token norms for the next block's ranking
                     fq[j] = ok ? pv_add_s(pv_add_s(o[0] * o[0], o[1] * o[1]), pv_add_s(o[2] * o[2], o[3] * o[3])) : 0.f;     // reduced over the lanes after the pass (pv_add_s: no packed horizontal add under the row loads in flight)
                 if (EPI == PV_EPI_BIAS_RES_F32 && p.x16_out) {      // (workgroup-uniform) LayerNorm folding, producer side
@@ -1387,7 +1418,14 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         if (EPI == PV_EPI_GELU_GRAD_BF16 && p.colsum_partial) {      // (workgroup-uniform) combine the 8 waves through LDS: [8][256] floats
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // the last image has been consumed by every wave
-            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + G2_BUF + wid * 1024 + lane * 16) = csum;
+            if constexpr (DG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs8[e] = pv_add_s(cs8[e], __shfl_xor(cs8[e], 32, 64));       // the two rows of an instruction: lanes l and l + 32 hold the same columns
+                if (lane < 32) {
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + G2_BUF + wid * 1024 + lane * 32) = (f32x4){cs8[0], cs8[1], cs8[2], cs8[3]};
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(cimg + G2_BUF + wid * 1024 + lane * 32 + 16) = (f32x4){cs8[4], cs8[5], cs8[6], cs8[7]};
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < 256 && n0 + tid < p.N) {
@@ -1403,7 +1441,8 @@ __device__ __forceinline__ void pv_gemm256_tile(const GemmDev& p, char* smem, co
         // A full tile issues at least 16 (16-bit outputs: 2 rows per instruction) / 32 (fp32 and gelu' epilogues: 1 row) stores per wave
         // after the prefetch; a ragged tile may skip some, so it drains.
         const bool full = FULL || (m0 + G2_BM <= p.M && n0 + G2_BN <= p.N);
-        constexpr bool B16 = EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16;
+        // (the gelu' product's fp32-image form issues 16 two-row stores per wave since round 6, like the 16-bit pipelines)
+        constexpr bool B16 = EPI == PV_EPI_BIAS_BF16 || EPI == PV_EPI_BIAS_GELU_BF16 || EPI == PV_EPI_BIAS_GELU_PAIR_BF16 || EPI == PV_EPI_GELU_GRAD_BF16;
         if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (B16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -2480,6 +2519,8 @@ static int pv_gemm_dispatch(const pv_gemm_args* a, void* stream, bool query_only
                      (force == 256 || (force != 128 && n_ok && k_eff % (2 * G2_BK) == 0 &&
                                        ((tiles256 >= 128 && !ragged_short) || feat ||
                                         (p.ksplit > 1 && (int64_t)p.M * p.N >= 256 * 256 && tiles256 * p.ksplit >= 64))));   // (a few-row split-K GEMM - small-batch residual GEMMs - fills more CUs with 128^2 tiles)
+    // (the 256^2 kernel's gelu' product moves its 16-bit rows 16 bytes per lane since round 6)
+    if (big && a->epilogue == PV_EPI_GELU_GRAD_BF16 && (p.N % 8 || a->ldr % 8 || a->ldo % 8 || ((uintptr_t)a->res & 15) || ((uintptr_t)a->out & 15))) return PV_ERR_UNSUPPORTED;
     if (big && (k_eff % (2 * G2_BK) || k_eff < 2 * G2_BK)) return PV_ERR_UNSUPPORTED;
     if ((a->colsum_partial || a->x16_out || a->fold_stat || a->rowsq_out) && !big) return PV_ERR_UNSUPPORTED;   // 256-row tile kernel only (pv_gemm_tile_rows)
     if (query_only) return big ? G2_BM : G1_BM;
