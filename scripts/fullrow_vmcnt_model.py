@@ -4,7 +4,7 @@ reads - the immediates of the counted s_waitcnt vmcnt.  NP phases per K-tile, PW
 python scripts/fullrow_vmcnt_model.py"""
 
 
-def sim(NP, PW, nk):
+def sim(NP, PW, nk, AP=2):      # AP: A pieces per wave and K-tile (2; 3 for the 160-row tile of round 6)
     seq = []
 
     def issue(lbl, cnt):
@@ -13,11 +13,11 @@ def sim(NP, PW, nk):
     def younger(labels):
         return len(seq) - 1 - max(i for i, l in enumerate(seq) if l in labels)
 
-    issue(("A", 0), 2)
+    issue(("A", 0), AP)
     for g in range(NP):
         issue(("W", g, 0), PW)
     if nk >= 2:
-        issue(("A", 1), 2)
+        issue(("A", 1), AP)
         for g in range(NP - 1):
             issue(("W", g, 1), PW)
     waits = {("pro",): younger([("A", 0), ("W", 0, 0)])}
@@ -28,7 +28,7 @@ def sim(NP, PW, nk):
                     issue(("W", NP - 1, s + 1), PW)
             elif s + 2 < nk:
                 if j == 1:
-                    issue(("A", s + 2), 2)
+                    issue(("A", s + 2), AP)
                     issue(("W", 0, s + 2), PW)
                 else:
                     issue(("W", j - 1, s + 2), PW)
@@ -45,3 +45,7 @@ if __name__ == "__main__":
         print(f"N = {64 * NT}, {NP} phases of {8 * NT // NP} MFMAs, 8 K-tiles:  prologue {w[('pro',)]}  steady " +
               " ".join(str(w[(3, j)]) for j in range(NP)) + "  K-tile nk-2 " + " ".join(str(w[(6, j)]) for j in range(NP)) +
               "  K-tile nk-1 " + " ".join(str(w[(7, j)]) for j in range(NP - 1)))
+    for NT in (4, 6):          # round 6: the 160-row tile stages three A pieces per wave
+        w = sim(2, NT // 2, 8, AP=3)
+        print(f"N = {64 * NT}, 160-row tile (3 A pieces), 2 phases:  prologue {w[('pro',)]}  steady " + " ".join(str(w[(3, j)]) for j in range(2)) +
+              "  K-tile nk-2 " + " ".join(str(w[(6, j)]) for j in range(2)) + "  K-tile nk-1 " + str(w[(7, 0)]))
