@@ -54,3 +54,24 @@ def test_launch_bound_rule_picks_the_small_shapes():
     assert lb("vit_small", 8) and not lb("vit_small", 512)
     assert lb("vit_b_16", 1) and lb("vit_b_16", 8) and not lb("vit_b_16", 64) and not lb("vit_b_16", 2048)
     assert not autograph.launch_bound(torch.nn.Linear(4, 4), 1)          # (not one of the model classes: no attributes to estimate from)
+
+
+def test_new_entry_points_validate_their_arguments_before_touching_the_gpu():
+    """pv_patch_embed_f32 / pv_rank_topk_gap / pv_rank_topk_partials_gap (ABI v10) refuse null pointers, misaligned buffers and shapes outside their contract
+    with an error code - no launch, so this runs without a GPU."""
+    import ctypes as C
+    from peekvit_amd import _lib
+    lib = _lib.load()
+    INVALID, UNSUPPORTED = -1, -2
+    z = C.c_void_p(0)
+    a = C.c_void_p(4096)           # (never dereferenced: every call below is refused first)
+    assert lib.pv_patch_embed_f32(z, a, a, a, a, 2, 3, 224, 16, 384, 197, 1, z, z) == INVALID            # no image
+    assert lib.pv_patch_embed_f32(a, a, a, a, a, 2, 3, 224, 16, 384, 150, 1, z, z) == INVALID            # 1 + 196 patch rows do not fit S = 150
+    assert lib.pv_patch_embed_f32(a, a, a, a, a, 2, 3, 224, 14, 384, 257, 1, z, z) == UNSUPPORTED        # P = 14: not a multiple of 8
+    assert lib.pv_patch_embed_f32(a, a, a, a, a, 2, 3, 225, 16, 384, 197, 1, z, z) == UNSUPPORTED        # R % P
+    assert lib.pv_patch_embed_f32(C.c_void_p(4100), a, a, a, a, 2, 3, 224, 16, 384, 197, 1, z, z) == UNSUPPORTED      # misaligned image
+    assert lib.pv_rank_topk_gap(z, a, z, 4, 196, 98, z) == INVALID and lib.pv_rank_topk_gap(a, a, z, 4, 196, 197, z) == INVALID      # k > N
+    assert lib.pv_rank_topk_gap(a, a, a, 4, 5000, 98, z) == UNSUPPORTED                                   # N > 4096
+    assert lib.pv_rank_topk_partials_gap(a, 3, a, a, 4, 1, 0, z) == INVALID                               # S < 2
+    assert lib.pv_rank_topk_partials_gap(a, 100, a, a, 4, 197, 98, z) == UNSUPPORTED                      # more than 64 column tiles
+    assert lib.pv_version() == 10
