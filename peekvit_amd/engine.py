@@ -989,7 +989,8 @@ def _residual_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out2d: 
     """out = res + a . w^T + bias (PV_EPI_BIAS_RES_F32); for few rows split-K + one finish pass.  ln = (gamma, beta, eps, out16): the LayerNorm
     the consumer applies to the finished rows - the finish pass emits it when the split form runs (returns True), else the caller launches it."""
     N, K = w.shape[0], a.shape[-1]
-    ks = _splitk_slices(M, N, K, 512 if ln is not None else 2048) if res2d.is_contiguous() and out2d.is_contiguous() else 1
+    # (round 6: 1 024 instead of 2 048 - vit_small's class-row fc2, 512 x 384 x 1536, is 12 tiles of 24 K-steps in one pass: 24 us; six slices + the finish pass: 12)
+    ks = _splitk_slices(M, N, K, 512 if ln is not None else 1024) if res2d.is_contiguous() and out2d.is_contiguous() else 1
     if ks > 1:
         part = workspace.get("splitk", (ks, M, N), torch.float32, a.device)
         ops.gemm(a, w, bias, part, PV_EPI_BIAS_F32, M=M, ksplit=ks)
