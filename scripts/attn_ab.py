@@ -18,13 +18,13 @@ if "--build" in sys.argv:
         subprocess.check_call([_build.HIPCC, *_build.FLAGS, "-DPV_OPERAND_F16", *flags, *d, "-shared", src, "-o", path(t)])
     sys.exit(0)
 import torch
-B, S, H, dh = 2048, 197, 12, 64
+B, S, H, dh = (int(a) for a in os.environ.get("PV_AB_SHAPE", "2048,197,12,64").split(","))
 dev = "cuda:0"
 qkv = (torch.randn(B, S, 3 * H * dh, device=dev) * 0.7).to(torch.float16)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 libs, outs = {}, {}
 flagbuf = torch.zeros(1, dtype=torch.int32, device=dev)
-for t in ["r2", "nw8", "g0", "cur"]:
+for t in ["r2", *V, "cur"]:
     if not os.path.exists(path(t)):
         continue
     lib = C.CDLL(path(t))
