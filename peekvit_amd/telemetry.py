@@ -61,6 +61,8 @@ class PowerSampler(threading.Thread):
                         pass
                 row["cards"].append(c)
             self.samples.append(row)
+            if len(self.samples) > 400_000:               # (~2 h at 50 Hz: a long-lived process keeps the recent half)
+                del self.samples[:200_000]
             self._halt.wait(self.period)
 
     def stop(self):
