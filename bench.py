@@ -285,7 +285,7 @@ def extra_config(kind, dev, steps, warmup):
                                                    "repaired_images": getattr(engine, "rank_repaired_images", 0) - rep0,
                                                    "note": "probe images in which a ranked layer kept a different token SET than the "
                                                    "split-operand arithmetic did (a near-tie at the keep boundary resolved by 16-bit noise in the norms): their logits move "
-                                                   "by percents and they are excluded from the comparison above; PEEKVIT_AMD_RANK_STRICT=1 sends the model to bf16x3 instead"}
+                                                   "by a median 6.5e-4 (profiles/r06_rank_tie_calibration.json: beyond operand rounding, within the order of the contract) and they are excluded from the comparison above; PEEKVIT_AMD_RANK_STRICT=1 sends the model to bf16x3 instead"}
     if train:
         from peekvit_amd import train_engine
         st = train_engine.train_state(model)

@@ -251,7 +251,7 @@ selfcheck_last = None       # (relative L2 of the fp16 logits against the FALLBA
 selfcheck_totals = {"probes": 0, "images": 0, "tie_flips": 0, "worst_rel_l2": 0.0}
 # RankViT: ranking is a DISCRETE decision on token norms that carry the 16-bit layers' noise (~1e-4 relative on ViT-B/16), and at keep ratio
 # 0.5 the boundary sits where the norms are densest (neighbouring norms ~6e-4 apart): on random images 1 - 2 of 8 resolve one near-tie
-# differently from the split-operand arithmetic, which moves THAT image's logits by percents (one survivor swapped) - with any 16-bit operand
+# differently from the split-operand arithmetic, which moves THAT image's logits beyond operand rounding (one survivor swapped: a median 6.5e-4, profiles/r06_rank_tie_calibration.json; rounds 3 - 5 wrote "percents") - with any 16-bit operand
 # type, and with the reference's own unstable fp32 sort at its own noise level.  The op itself is bit-exact on identical norms (tests).  The
 # self-check therefore compares the images whose discrete state (`probe_state`: the kept sets of every ranked layer) agrees, and reports the
 # others as tie flips; PEEKVIT_AMD_RANK_STRICT=1 counts a flip as a contract violation instead (-> FALLBACK_MODE for that model / budget).
@@ -1472,7 +1472,7 @@ def sort_and_drop(x: torch.Tensor, budget: float):
 # ---- ranking near-ties (round 6) -----------------------------------------------------------------------------------------------------
 # RankViT's ranking is a DISCRETE decision on token norms that carry the 16-bit layers' noise (~1e-4 relative on ViT-B/16).  At keep ratio 0.5 the
 # boundary sits where the norms are densest: on random images about one in eight resolves one near-tie differently from the reference's fp32
-# arithmetic, which moves THAT image's logits by percents (one survivor swapped).  The ranking kernels report each image's narrowest relative gap at
+# arithmetic, which moves THAT image's logits by a median 6.5e-4 (one survivor swapped).  The ranking kernels report each image's narrowest relative gap at
 # a keep boundary (pv_rank_topk_gap); with PEEKVIT_AMD_RANK_REPAIR=1 (implied by PEEKVIT_AMD_RANK_STRICT=1) a model forward re-runs exactly the images
 # whose gap is under RANK_TIE_GAP in the split-operand arithmetic (kept sets bit-exact end to end) and leaves every other image on fp16 operands.
 # RANK_TIE_GAP is calibrated against observed flips (scripts/rank_tie_calibration.py, profiles/r06_rank_tie_calibration.json).
